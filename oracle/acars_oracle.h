@@ -1,0 +1,103 @@
+/*
+ * acars_oracle.h -- CPU restatement of the acarsdec per-channel DSP hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and there only as the checker.  The product path
+ * (acarsdec_amd/) never links, imports or calls it.
+ *
+ * Parity pinning: the reference ships no golden vectors of its own (no tests
+ * at all).  This restatement is pinned against (1) the unmodified reference
+ * sources compiled by oracle/Makefile into oracle/_ref/ (bit-identical state,
+ * bits and frames on test.wav and on synthetic IQ, see tests/test_oracle_vs_ref.py)
+ * and (2) the committed fixtures under tests/golden/ generated from that build.
+ *
+ * All file:line citations are into the reference tree (TLeconte/acarsdec v3.7).
+ */
+#ifndef ACARS_ORACLE_H
+#define ACARS_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_INTRATE 12500          /* acarsdec.h:31 */
+#define ORC_FLEN 11                /* msk.c:25  (INTRATE/1200)+1 */
+#define ORC_MFLTOVER 12            /* msk.c:26 */
+#define ORC_FLENO 133              /* msk.c:27  FLEN*MFLTOVER+1 */
+#define ORC_TXTMAX 250             /* acarsdec.h:55 */
+
+/* frame-FSM states, acarsdec.h:88 */
+enum { ORC_WSYN = 0, ORC_SYN2, ORC_SOH1, ORC_TXT, ORC_CRC1, ORC_CRC2, ORC_END };
+
+/* a message block as it reaches the block queue (acarsdec.h:48-57, acars.c:350-364) */
+typedef struct {
+	int chn;
+	int len;
+	int err;
+	float lvl;
+	unsigned char crc[2];
+	unsigned char txt[ORC_TXTMAX];
+	long long end_bit;      /* index (per channel, from 0) of the bit that completed the block */
+} orc_frame;
+
+/* per-bit log entry (what putbit() receives + the level, msk.c:110-126) */
+typedef struct {
+	float vo;               /* signed soft symbol handed to putbit (after the MskS&2 polarity) */
+	float lvl;              /* cabsf(v) before normalisation */
+} orc_bit;
+
+/* per-channel state: the MSK + framing fields of channel_t (acarsdec.h:76-89) */
+typedef struct {
+	int chn;
+	double MskPhi;
+	double MskDf;
+	float MskClk;
+	double MskLvlSum;
+	int MskBitCount;
+	unsigned int MskS, idx;
+	float inb[2 * ORC_FLEN];        /* re,im interleaved */
+	unsigned char outbits;
+	int nbits;
+	int Acarsstate;
+	int blk_len, blk_err;
+	unsigned char blk_txt[ORC_TXTMAX + 6];
+	unsigned char blk_crc[2];
+	long long nbit_total;           /* bits produced so far (not in the reference; bookkeeping) */
+
+	/* sinks (may be NULL) */
+	orc_bit *bitlog; size_t bitlog_cap, bitlog_n;
+	orc_frame *frames; size_t frames_cap, frames_n;
+} orc_chan;
+
+/* msk.c:30-51 + acars.c:218-237 */
+void orc_chan_init(orc_chan *ch, int chn);
+/* msk.c:44-48: the matched-filter prototype h[133] */
+void orc_msk_h(float *h);
+/* msk.c:67-137 (+ putbit msk.c:53-63, decodeAcars acars.c:246-375) */
+void orc_demod_msk(orc_chan *ch, const float *dm, int len);
+
+/* rtl.c:283-286: taps for one channel. wf is [M][2] (re,im) */
+void orc_rtl_taps(int Fr, int Fc, int M, float *wf);
+/* rtl.c:131-168. Fd is sorted in place. rtlInRate = INTRATE*M */
+int orc_choose_fc(unsigned int *Fd, unsigned int nbch, int rtlInRate);
+/* rtl.c:332-354 for one channel: nout windows of M samples, first ntaps (<=M) used. */
+void orc_fir_u8(const uint8_t *iq, size_t nout, int M, int ntaps,
+		const float *wf, float *dm);
+/* the whole in_callback for nch channels sharing one stream (rtl.c:314-361) */
+void orc_in_callback(orc_chan *chs, int nch, const uint8_t *iq, int nout, int M,
+		     const float *wf /* [nch][M][2] */, float *dm_scratch /* [nch][nout] */);
+
+/* acars.c:123-207 parity + CRC verdict of a queued block (no repair):
+ * returns 0 if it would be output with err==0, >0 = number of parity errors,
+ * -1 = dropped (too short), -2 = crc error with clean parity. */
+int orc_frame_check(const orc_frame *f);
+unsigned short orc_crc_update(unsigned short crc, unsigned char c);   /* syndrom.h:49 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,291 @@
+"""ctypes bindings for the CPU checkers in oracle/ -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module, and only as the checker.  The product (acarsdec_amd/) never does.
+
+Two libraries:
+  * liboracle.so          -- the C restatement (acars_oracle.c)
+  * _ref/libacarsref*.so  -- the unmodified reference sources + ref_glue.c (built only where
+                             /root/reference exists; the built .so travels to the GPU box)
+"""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+INTRATE = 12500
+FLEN = 11
+TXTMAX = 250
+
+
+def build(verbose=False):
+    """(Re)build liboracle.so and, when the reference tree is present, _ref/."""
+    r = subprocess.run(["make", "-C", HERE], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("oracle build failed:\n" + r.stdout + r.stderr)
+    if verbose:
+        print(r.stdout)
+
+
+# --------------------------------------------------------------------------- restatement
+class OrcFrame(C.Structure):
+    _fields_ = [("chn", C.c_int), ("len", C.c_int), ("err", C.c_int), ("lvl", C.c_float),
+                ("crc", C.c_ubyte * 2), ("txt", C.c_ubyte * TXTMAX), ("end_bit", C.c_longlong)]
+
+
+class OrcBit(C.Structure):
+    _fields_ = [("vo", C.c_float), ("lvl", C.c_float)]
+
+
+class OrcChan(C.Structure):
+    _fields_ = [("chn", C.c_int), ("MskPhi", C.c_double), ("MskDf", C.c_double),
+                ("MskClk", C.c_float), ("MskLvlSum", C.c_double), ("MskBitCount", C.c_int),
+                ("MskS", C.c_uint), ("idx", C.c_uint), ("inb", C.c_float * (2 * FLEN)),
+                ("outbits", C.c_ubyte), ("nbits", C.c_int), ("Acarsstate", C.c_int),
+                ("blk_len", C.c_int), ("blk_err", C.c_int),
+                ("blk_txt", C.c_ubyte * (TXTMAX + 6)), ("blk_crc", C.c_ubyte * 2),
+                ("nbit_total", C.c_longlong),
+                ("bitlog", C.POINTER(OrcBit)), ("bitlog_cap", C.c_size_t), ("bitlog_n", C.c_size_t),
+                ("frames", C.POINTER(OrcFrame)), ("frames_cap", C.c_size_t), ("frames_n", C.c_size_t)]
+
+
+_orc = None
+
+
+def lib():
+    global _orc
+    if _orc is None:
+        path = os.path.join(HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.orc_chan_init.argtypes = [C.POINTER(OrcChan), C.c_int]
+        L.orc_msk_h.argtypes = [C.c_void_p]
+        L.orc_demod_msk.argtypes = [C.POINTER(OrcChan), C.c_void_p, C.c_int]
+        L.orc_rtl_taps.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_choose_fc.argtypes = [C.c_void_p, C.c_uint, C.c_int]
+        L.orc_choose_fc.restype = C.c_int
+        L.orc_fir_u8.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_frame_check.argtypes = [C.POINTER(OrcFrame)]
+        L.orc_frame_check.restype = C.c_int
+        L.orc_crc_update.argtypes = [C.c_ushort, C.c_ubyte]
+        L.orc_crc_update.restype = C.c_ushort
+        _orc = L
+    return _orc
+
+
+def frame_tuple(f):
+    """Hashable, comparable view of a frame: (chn, len, err, crc bytes, txt bytes)."""
+    return (int(f.chn), int(f.len), int(f.err), bytes(f.crc), bytes(f.txt[: max(0, f.len)]))
+
+
+class Channel:
+    """One oracle channel with bit and frame sinks."""
+
+    def __init__(self, chn=0, max_bits=0, max_frames=256):
+        self.c = OrcChan()
+        self._bits = (OrcBit * max_bits)() if max_bits else None
+        self._frames = (OrcFrame * max_frames)()
+        if max_bits:
+            self.c.bitlog = C.cast(self._bits, C.POINTER(OrcBit))
+            self.c.bitlog_cap = max_bits
+        self.c.frames = C.cast(self._frames, C.POINTER(OrcFrame))
+        self.c.frames_cap = max_frames
+        lib().orc_chan_init(C.byref(self.c), chn)
+
+    def demod(self, dm):
+        dm = np.ascontiguousarray(dm, dtype=np.float32)
+        lib().orc_demod_msk(C.byref(self.c), dm.ctypes.data, int(dm.size))
+
+    @property
+    def frames(self):
+        return [self._frames[i] for i in range(min(self.c.frames_n, self.c.frames_cap))]
+
+    @property
+    def bits(self):
+        n = min(self.c.bitlog_n, self.c.bitlog_cap)
+        a = np.frombuffer(self._bits, dtype=np.float32, count=2 * n).reshape(n, 2)
+        return a[:, 0].copy(), a[:, 1].copy()
+
+    def state(self):
+        c = self.c
+        return dict(MskPhi=c.MskPhi, MskDf=c.MskDf, MskClk=c.MskClk, MskLvlSum=c.MskLvlSum,
+                    MskBitCount=c.MskBitCount, MskS=c.MskS, idx=c.idx,
+                    inb=np.array(c.inb[:], dtype=np.float32), outbits=c.outbits, nbits=c.nbits,
+                    Acarsstate=c.Acarsstate)
+
+
+def msk_h():
+    h = np.zeros(133, dtype=np.float32)
+    lib().orc_msk_h(h.ctypes.data)
+    return h
+
+
+def rtl_taps(Fr, Fc, M):
+    wf = np.zeros((M, 2), dtype=np.float32)
+    lib().orc_rtl_taps(int(Fr), int(Fc), int(M), wf.ctypes.data)
+    return wf
+
+
+def choose_fc(freqs_hz, M):
+    fd = np.array(freqs_hz, dtype=np.uint32)
+    return lib().orc_choose_fc(fd.ctypes.data, len(fd), INTRATE * M)
+
+
+def fir_u8(iq, M, wf, nout=None, ntaps=None):
+    iq = np.ascontiguousarray(iq, dtype=np.uint8).reshape(-1)
+    wf = np.ascontiguousarray(wf, dtype=np.float32)
+    if ntaps is None:
+        ntaps = wf.shape[0]
+    if nout is None:
+        nout = iq.size // (2 * M)
+    dm = np.zeros(nout, dtype=np.float32)
+    lib().orc_fir_u8(iq.ctypes.data, nout, M, ntaps, wf.ctypes.data, dm.ctypes.data)
+    return dm
+
+
+def crc_ccitt(data, crc=0):
+    for b in bytes(data):
+        crc = lib().orc_crc_update(crc, b)
+    return crc
+
+
+# --------------------------------------------------------------------------- real reference
+class RefFrame(C.Structure):
+    _fields_ = [("chn", C.c_int), ("len", C.c_int), ("err", C.c_int), ("lvl", C.c_float),
+                ("crc", C.c_ubyte * 2), ("txt", C.c_ubyte * TXTMAX)]
+
+
+class RefBit(C.Structure):
+    _fields_ = [("vr", C.c_float), ("vi", C.c_float), ("MskS", C.c_uint), ("chn", C.c_int)]
+
+
+class RefState(C.Structure):
+    _fields_ = [("MskPhi", C.c_double), ("MskDf", C.c_double), ("MskLvlSum", C.c_double),
+                ("MskClk", C.c_float), ("MskBitCount", C.c_int), ("MskS", C.c_uint),
+                ("idx", C.c_uint), ("inb", C.c_float * 22), ("outbits", C.c_int),
+                ("nbits", C.c_int), ("Acarsstate", C.c_int)]
+
+
+def ref_path(variant=""):
+    return os.path.join(HERE, "_ref", "libacarsref%s.so" % variant)
+
+
+def ref_available(variant=""):
+    return os.path.exists(ref_path(variant))
+
+
+class Ref:
+    """The unmodified reference (one instance per process: it is all global state)."""
+
+    def __init__(self, variant=""):
+        L = C.CDLL(ref_path(variant))
+        L.ref_init_rtl.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_int]
+        L.ref_init_rtl.restype = C.c_long
+        L.ref_init_file.argtypes = [C.c_int]
+        L.ref_in_callback.argtypes = [C.c_void_p, C.c_uint]
+        L.ref_demod.argtypes = [C.c_int, C.c_void_p, C.c_int]
+        L.ref_get_wf.argtypes = [C.c_int, C.c_void_p, C.c_int]
+        L.ref_get_wf.restype = C.c_int
+        L.ref_get_dm.argtypes = [C.c_int]
+        L.ref_get_dm.restype = C.POINTER(C.c_float)
+        L.ref_get_state.argtypes = [C.c_int, C.POINTER(RefState)]
+        L.ref_raw.restype = C.POINTER(RefFrame)
+        L.ref_out.restype = C.POINTER(RefFrame)
+        L.ref_bitlog_enable.argtypes = [C.c_size_t]
+        L.ref_bitlog_count.restype = C.c_size_t
+        L.ref_bitlog.restype = C.POINTER(RefBit)
+        self.L = L
+        self.M = None
+
+    def init_rtl(self, freqs_mhz, mult):
+        """freqs_mhz: strings as on the acarsdec command line. Returns Fc (Hz)."""
+        arr = (C.c_char_p * len(freqs_mhz))(*[f.encode() for f in freqs_mhz])
+        fc = self.L.ref_init_rtl(len(freqs_mhz), arr, mult)
+        if fc <= 0:
+            raise RuntimeError("initRtl failed (%d)" % fc)
+        self.M = mult
+        return fc
+
+    def init_file(self, nch):
+        if self.L.ref_init_file(nch):
+            raise RuntimeError("ref_init_file failed")
+
+    def in_callback(self, buf):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8).reshape(-1)
+        self.L.ref_in_callback(buf.ctypes.data, buf.size)
+
+    def demod(self, n, dm):
+        dm = np.ascontiguousarray(dm, dtype=np.float32)
+        assert dm.size <= 4096
+        self.L.ref_demod(n, dm.ctypes.data, dm.size)
+
+    def wf(self, n):
+        out = np.zeros((self.M, 2), dtype=np.float32)
+        fr = self.L.ref_get_wf(n, out.ctypes.data, self.M)
+        return fr, out
+
+    def dm(self, n, count=1024):
+        return np.ctypeslib.as_array(self.L.ref_get_dm(n), shape=(count,)).copy()
+
+    def state(self, n):
+        s = RefState()
+        self.L.ref_get_state(n, C.byref(s))
+        return dict(MskPhi=s.MskPhi, MskDf=s.MskDf, MskClk=s.MskClk, MskLvlSum=s.MskLvlSum,
+                    MskBitCount=s.MskBitCount, MskS=s.MskS, idx=s.idx,
+                    inb=np.array(s.inb[:], dtype=np.float32), outbits=s.outbits, nbits=s.nbits,
+                    Acarsstate=s.Acarsstate)
+
+    def drain(self):
+        self.L.ref_drain()
+
+    def raw_frames(self):
+        p = self.L.ref_raw()
+        return [p[i] for i in range(self.L.ref_nraw())]
+
+    def out_frames(self):
+        p = self.L.ref_out()
+        return [p[i] for i in range(self.L.ref_nout())]
+
+    def bitlog_enable(self, cap):
+        self.L.ref_bitlog_enable(cap)
+
+    def bitlog(self):
+        n = self.L.ref_bitlog_count()
+        p = self.L.ref_bitlog()
+        a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(n, 4)).copy()
+        v = a[:, :2].copy().view(np.float32)
+        return v[:, 0], v[:, 1], a[:, 2].copy(), a[:, 3].view(np.int32).copy()
+
+
+# --------------------------------------------------------------------------- WAV (PCM16, incl. WAVE_FORMAT_EXTENSIBLE)
+def read_wav_pcm16(path):
+    """Returns (rate, int16 array [frames, channels]).  Stand-in for libsndfile (soundfile.c:36)."""
+    with open(path, "rb") as f:
+        data = f.read()
+    assert data[:4] == b"RIFF" and data[8:12] == b"WAVE"
+    pos = 12
+    fmt = None
+    pcm = None
+    while pos + 8 <= len(data):
+        cid, sz = data[pos:pos + 4], struct.unpack("<I", data[pos + 4:pos + 8])[0]
+        body = data[pos + 8:pos + 8 + sz]
+        if cid == b"fmt ":
+            tag, nch, rate, _, _, bits = struct.unpack("<HHIIHH", body[:16])
+            if tag == 0xFFFE:
+                tag = struct.unpack("<H", body[24:26])[0]
+            assert tag == 1 and bits == 16, (tag, bits)
+            fmt = (nch, rate)
+        elif cid == b"data":
+            pcm = np.frombuffer(body, dtype="<i2")
+        pos += 8 + sz + (sz & 1)
+    nch, rate = fmt
+    return rate, pcm[: (pcm.size // nch) * nch].reshape(-1, nch).copy()
+
+
+def wav_to_float(pcm16):
+    """libsndfile's sf_read_float normalisation for PCM16: x / 32768 (soundfile.c:65)."""
+    return (pcm16.astype(np.float32) / np.float32(32768.0)).astype(np.float32)

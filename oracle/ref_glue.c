@@ -1,0 +1,284 @@
+/*
+ * ref_glue.c -- harness around the UNMODIFIED reference sources (msk.c, acars.c, rtl.c),
+ * which oracle/Makefile compiles in place from /root/reference into oracle/_ref/.
+ * TEST INFRASTRUCTURE ONLY: used to pin oracle/acars_oracle.c and, optionally, as the
+ * "reference" CPU baseline of bench.py.  No reference source is copied into this repo;
+ * this file only supplies what the reference expects from its environment:
+ *   - the globals of acarsdec.c (acarsdec.c:34-58) that the three files read,
+ *   - no-op librtlsdr entry points (see stub/rtl-sdr.h),
+ *   - outputmsg() (output.c:486), replaced by a capture buffer,
+ *   - pthread_create / pthread_cond_wait hooks (injected with -D on acars.c) that turn
+ *     the asynchronous blk_thread (acars.c:93) into an on-demand synchronous drain,
+ *   - linker --wrap hooks on decodeAcars()/demodMSK() that snapshot blocks as they are
+ *     queued (acars.c:356-364), and a cabsf hook (-D on msk.c, -O2 build only) that logs
+ *     the matched-filter output of every bit (msk.c:110).
+ */
+#define _GNU_SOURCE
+#include <stdlib.h>
+#include <stdio.h>
+#include <string.h>
+#include <setjmp.h>
+#include <math.h>
+#include <complex.h>
+#include <rtl-sdr.h>
+#include "acarsdec.h"
+
+/* ---- globals the reference files expect (acarsdec.c:34-58) ---- */
+channel_t channel[MAXNBCHANNELS];
+unsigned int nbch;
+int verbose = 0;
+int signalExit = 0;
+int gain = -100;
+int ppm = 0;
+int rtlMult = 160;
+
+/* ---- librtlsdr stand-ins ---- */
+static uint32_t g_center_freq;
+uint32_t rtlsdr_get_device_count(void) { return 1; }
+const char *rtlsdr_get_device_name(uint32_t index) { (void)index; return "oracle-stub"; }
+int rtlsdr_get_device_usb_strings(uint32_t index, char *m, char *p, char *s)
+{
+	(void)index;
+	if (m) strcpy(m, "stub");
+	if (p) strcpy(p, "stub");
+	if (s) strcpy(s, "00000000");
+	return 0;
+}
+int rtlsdr_open(rtlsdr_dev_t **dev, uint32_t index) { (void)index; *dev = (rtlsdr_dev_t *)&g_center_freq; return 0; }
+int rtlsdr_close(rtlsdr_dev_t *dev) { (void)dev; return 0; }
+int rtlsdr_set_center_freq(rtlsdr_dev_t *dev, uint32_t freq) { (void)dev; g_center_freq = freq; return 0; }
+int rtlsdr_set_freq_correction(rtlsdr_dev_t *dev, int p) { (void)dev; (void)p; return 0; }
+int rtlsdr_get_tuner_gains(rtlsdr_dev_t *dev, int *gains) { (void)dev; if (gains) gains[0] = 0; return 1; }
+int rtlsdr_set_tuner_gain(rtlsdr_dev_t *dev, int g) { (void)dev; (void)g; return 0; }
+int rtlsdr_set_tuner_gain_mode(rtlsdr_dev_t *dev, int m) { (void)dev; (void)m; return 0; }
+int rtlsdr_set_sample_rate(rtlsdr_dev_t *dev, uint32_t r) { (void)dev; (void)r; return 0; }
+int rtlsdr_reset_buffer(rtlsdr_dev_t *dev) { (void)dev; return 0; }
+int rtlsdr_read_async(rtlsdr_dev_t *dev, rtlsdr_read_async_cb_t cb, void *ctx, uint32_t n, uint32_t l)
+{ (void)dev; (void)cb; (void)ctx; (void)n; (void)l; return 0; }
+int rtlsdr_cancel_async(rtlsdr_dev_t *dev) { (void)dev; return 0; }
+
+/* ---- capture buffers ---- */
+typedef struct {
+	int chn, len, err;
+	float lvl;
+	unsigned char crc[2];
+	unsigned char txt[250];
+} ref_frame;
+
+#define REF_MAXFRAMES 65536
+static ref_frame *g_raw;       /* blocks as queued by decodeAcars (before blk_thread) */
+static int g_nraw;
+static ref_frame *g_out;       /* blocks as they reach outputmsg (after parity/CRC repair + strip) */
+static int g_nout;
+
+static void grab(ref_frame *dst, const msgblk_t *blk)
+{
+	dst->chn = blk->chn;
+	dst->len = blk->len;
+	dst->err = blk->err;
+	dst->lvl = blk->lvl;
+	dst->crc[0] = blk->crc[0];
+	dst->crc[1] = blk->crc[1];
+	memset(dst->txt, 0, sizeof(dst->txt));
+	if (blk->len > 0)
+		memcpy(dst->txt, blk->txt, (size_t)(blk->len < 250 ? blk->len : 250));
+}
+
+void outputmsg(const msgblk_t *blk)           /* stands in for output.c:486 */
+{
+	if (!g_out)
+		g_out = calloc(REF_MAXFRAMES, sizeof(ref_frame));
+	if (g_nout < REF_MAXFRAMES)
+		grab(&g_out[g_nout], blk);
+	g_nout++;
+}
+
+/* ---- blk_thread made synchronous ---- */
+static void *(*g_blk_fn)(void *);
+static jmp_buf g_jb;
+static int g_draining;
+
+int ref_hook_pthread_create(pthread_t *t, const pthread_attr_t *a, void *(*fn)(void *), void *arg)
+{
+	(void)a; (void)arg;
+	if (t) memset(t, 0, sizeof(*t));
+	g_blk_fn = fn;                     /* acars.c:225: remember blk_thread, do not start it */
+	return 0;
+}
+
+int ref_hook_cond_wait(pthread_cond_t *c, pthread_mutex_t *m)
+{
+	(void)c;
+	/* acars.c:106-107: queue empty -> blk_thread would sleep: leave it instead */
+	if (g_draining) {
+		pthread_mutex_unlock(m);
+		longjmp(g_jb, 1);
+	}
+	return 0;
+}
+
+void ref_drain(void)
+{
+	if (!g_blk_fn)
+		return;
+	g_draining = 1;
+	if (setjmp(g_jb) == 0)
+		g_blk_fn(NULL);
+	g_draining = 0;
+}
+
+/* ---- --wrap hooks ---- */
+void __real_decodeAcars(channel_t *ch);
+void __wrap_decodeAcars(channel_t *ch)
+{
+	msgblk_t *before = ch->blk;
+	int st = ch->Acarsstate;
+	__real_decodeAcars(ch);
+	if (before && ch->blk == NULL && ch->Acarsstate == END && (st == CRC2 || st == TXT)) {
+		/* acars.c:356-366: `before` has just been queued; blk_thread has not touched it */
+		if (!g_raw)
+			g_raw = calloc(REF_MAXFRAMES, sizeof(ref_frame));
+		if (g_nraw < REF_MAXFRAMES)
+			grab(&g_raw[g_nraw], before);
+		g_nraw++;
+	}
+}
+
+static channel_t *g_cur;
+void __real_demodMSK(channel_t *ch, int len);
+void __wrap_demodMSK(channel_t *ch, int len)
+{
+	g_cur = ch;
+	__real_demodMSK(ch, len);
+	g_cur = NULL;
+}
+
+/* per-bit matched-filter log (msk.c:110 `lvl=cabsf(v)`), filled by the cabsf hook */
+typedef struct { float vr, vi; unsigned int MskS; int chn; } ref_bit;
+static ref_bit *g_bits;
+static size_t g_nbits, g_bits_cap;
+
+float ref_hook_cabsf(float complex v)
+{
+	if (g_cur && g_bits) {
+		if (g_nbits < g_bits_cap) {
+			g_bits[g_nbits].vr = crealf(v);
+			g_bits[g_nbits].vi = cimagf(v);
+			g_bits[g_nbits].MskS = g_cur->MskS;
+			g_bits[g_nbits].chn = g_cur->chn;
+		}
+		g_nbits++;
+	}
+	return cabsf(v);
+}
+
+void ref_bitlog_enable(size_t cap)
+{
+	free(g_bits);
+	g_bits = cap ? calloc(cap, sizeof(ref_bit)) : NULL;
+	g_bits_cap = cap;
+	g_nbits = 0;
+}
+size_t ref_bitlog_count(void) { return g_nbits; }
+const ref_bit *ref_bitlog(void) { return g_bits; }
+
+/* ---- driver API (ctypes) ---- */
+void ref_rtl_in_callback(unsigned char *buf, uint32_t nread);   /* ref_rtl_unit.c */
+
+static void common_init(void)
+{
+	unsigned int n;
+	g_nraw = g_nout = 0;
+	for (n = 0; n < nbch; n++) {           /* acarsdec.c:445-454 */
+		channel[n].chn = n;
+		channel[n].MskLvlSum = 0;          /* static storage in the reference: zero at start */
+		channel[n].MskBitCount = 0;
+		channel[n].blk = NULL;
+		initMsk(&channel[n]);
+		initAcars(&channel[n]);
+	}
+}
+
+/* RTL path: freqs are decimal MHz strings exactly as on the reference command line
+ * (acarsdec -m mult -r 0 f1 f2 ...).  Returns the centre frequency chosen (rtl.c:268), <0 on error. */
+long ref_init_rtl(int nfreq, const char **freqs, int mult)
+{
+	char *argv[MAXNBCHANNELS + 3];
+	int i, r;
+	if (nfreq > MAXNBCHANNELS)
+		return -1;
+	rtlMult = mult;
+	argv[0] = (char *)"0";
+	for (i = 0; i < nfreq; i++)
+		argv[1 + i] = (char *)freqs[i];
+	argv[1 + nfreq] = NULL;
+	g_center_freq = 0;
+	r = initRtl(argv, 0);
+	if (r)
+		return -2;
+	common_init();
+	return (long)g_center_freq;
+}
+
+/* sound-file path (soundfile.c:30-56): nch channels of 12.5 kHz real samples */
+int ref_init_file(int nch)
+{
+	int n;
+	if (nch > MAXNBCHANNELS)
+		return -1;
+	nbch = nch;
+	for (n = 0; n < nch; n++)
+		channel[n].dm_buffer = malloc(sizeof(float) * 4096);
+	common_init();
+	return 0;
+}
+
+void ref_in_callback(unsigned char *buf, unsigned int nread) { ref_rtl_in_callback(buf, nread); }
+
+/* soundfile.c:71-77 for one channel: len <= 4096 */
+void ref_demod(int n, const float *dm, int len)
+{
+	memcpy(channel[n].dm_buffer, dm, sizeof(float) * (size_t)len);
+	demodMSK(&channel[n], len);
+}
+
+int ref_get_wf(int n, float *out, int M)
+{
+	int i;
+	for (i = 0; i < M; i++) {
+		out[2 * i] = crealf(channel[n].wf[i]);
+		out[2 * i + 1] = cimagf(channel[n].wf[i]);
+	}
+	return channel[n].Fr;
+}
+
+const float *ref_get_dm(int n) { return channel[n].dm_buffer; }
+
+typedef struct {
+	double MskPhi, MskDf, MskLvlSum;
+	float MskClk;
+	int MskBitCount;
+	unsigned int MskS, idx;
+	float inb[22];
+	int outbits, nbits, Acarsstate;
+} ref_state;
+
+void ref_get_state(int n, ref_state *s)
+{
+	channel_t *ch = &channel[n];
+	int i;
+	s->MskPhi = ch->MskPhi; s->MskDf = ch->MskDf; s->MskLvlSum = ch->MskLvlSum;
+	s->MskClk = ch->MskClk; s->MskBitCount = ch->MskBitCount;
+	s->MskS = ch->MskS; s->idx = ch->idx;
+	for (i = 0; i < 11; i++) {
+		s->inb[2 * i] = crealf(ch->inb[i]);
+		s->inb[2 * i + 1] = cimagf(ch->inb[i]);
+	}
+	s->outbits = ch->outbits; s->nbits = ch->nbits; s->Acarsstate = ch->Acarsstate;
+}
+
+int ref_nraw(void) { return g_nraw; }
+int ref_nout(void) { return g_nout; }
+const ref_frame *ref_raw(void) { return g_raw; }
+const ref_frame *ref_out(void) { return g_out; }
+unsigned int ref_nbch(void) { return nbch; }
