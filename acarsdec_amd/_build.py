@@ -1,0 +1,90 @@
+"""Builds the native parts of acarsdec_amd in-tree (no JIT cache: the built .so travels to the
+GPU box with the repo snapshot).
+
+  lib/libacarsdec_amd.so   HIP kernels (gfx950) + C ABI           -- the product
+  lib/acarsdec_gpu         (only where /root/reference exists) the reference's UNCHANGED
+                           acarsdec.c/acars.c/output.c/label.c/... linked against compat_msk.c
+                           instead of msk.c: the end-to-end drop-in demo
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INC = os.path.join(os.path.dirname(HERE), "include")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(LIBDIR, "obj")
+LIB = os.path.join(LIBDIR, "libacarsdec_amd.so")
+DEMO = os.path.join(LIBDIR, "acarsdec_gpu")
+REF = os.environ.get("ACARSDEC_REF", "/root/reference")
+ARCH = "gfx950"
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("build step failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))
+
+
+def _newer(src, dst):
+    return (not os.path.exists(dst)) or any(os.path.getmtime(s) > os.path.getmtime(dst) for s in src)
+
+
+def hipcc():
+    for c in ("/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def build_lib(force=False):
+    os.makedirs(OBJDIR, exist_ok=True)
+    hdrs = [os.path.join(CSRC, "acg_internal.h"), os.path.join(INC, "acarsdec_amd.h")]
+    units = [
+        ("fir.hip", ["-O3"]),
+        ("msk.hip", ["-O3", "-ffp-contract=off"]),      # keep the reference's separate mul/add roundings
+        ("synth.hip", ["-O3"]),
+        ("acg_api.cpp", ["-O2"]),
+    ]
+    objs = []
+    hc = hipcc()
+    for name, flags in units:
+        src = os.path.join(CSRC, name)
+        obj = os.path.join(OBJDIR, name + ".o")
+        if force or _newer([src] + hdrs, obj):
+            _run([hc, "--offload-arch=" + ARCH, "-std=c++17", "-fPIC", "-I" + INC, "-I" + CSRC] + flags +
+                 ["-c", src, "-o", obj])
+        objs.append(obj)
+    src = os.path.join(CSRC, "host_setup.c")
+    obj = os.path.join(OBJDIR, "host_setup.o")
+    if force or _newer([src] + hdrs, obj):
+        _run(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-I" + INC, "-c", src, "-o", obj])
+    objs.append(obj)
+    if force or _newer(objs, LIB):
+        _run([hc, "--offload-arch=" + ARCH, "-shared", "-o", LIB] + objs + ["-lm"])
+    return LIB
+
+
+def build_demo(force=False):
+    """Reference program, unchanged, on top of the GPU library.  Needs the reference tree."""
+    if not os.path.exists(os.path.join(REF, "acars.c")):
+        return DEMO if os.path.exists(DEMO) else None
+    build_lib()
+    ref_units = ["acarsdec.c", "acars.c", "output.c", "label.c", "cJSON.c", "netout.c", "fileout.c"]
+    mine = [os.path.join(CSRC, "compat_msk.c"), os.path.join(CSRC, "wav_frontend.c")]
+    srcs = [os.path.join(REF, u) for u in ref_units] + mine
+    if force or _newer(srcs + [LIB], DEMO):
+        _run(["gcc", "-O2", "-w", "-DWITH_SNDFILE", "-I" + REF, "-I" + INC] + srcs +
+             ["-o", DEMO, "-L" + LIBDIR, "-lacarsdec_amd", "-Wl,-rpath,$ORIGIN", "-lm", "-lpthread"])
+    return DEMO
+
+
+def build_all(force=False):
+    lib = build_lib(force)
+    demo = build_demo(force)
+    return lib, demo
+
+
+if __name__ == "__main__":
+    print(build_all())

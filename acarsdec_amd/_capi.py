@@ -1,0 +1,95 @@
+"""ctypes binding of libacarsdec_amd.so (include/acarsdec_amd.h) -- the same stub a cffi/ctypes
+host would write against the C ABI.  No compute happens in Python."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libacarsdec_amd.so")
+
+OK, EINVAL, ENOMEM, EHIP, ENODEV, EOVERFLOW, ESTATE = 0, -1, -2, -3, -4, -5, -6
+F_BITLOG, F_TIMING = 1, 2
+INTRATE, BLOCK, MAXDECIM, FLEN, TXTMAX = 12500, 1024, 320, 11, 250
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int), ("nch", C.c_int), ("nstreams", C.c_int), ("decim", C.c_int),
+                ("ntaps", C.c_int), ("max_blocks", C.c_int), ("flags", C.c_uint32)]
+
+
+class ChanState(C.Structure):
+    _fields_ = [("MskPhi", C.c_double), ("MskDf", C.c_double), ("MskLvlSum", C.c_double),
+                ("MskClk", C.c_float), ("MskBitCount", C.c_int), ("MskS", C.c_uint), ("idx", C.c_uint),
+                ("inb", C.c_float * (2 * FLEN)), ("outbits", C.c_int), ("nbits", C.c_int),
+                ("Acarsstate", C.c_int), ("blk_len", C.c_int), ("blk_err", C.c_int)]
+
+
+class Frame(C.Structure):
+    _fields_ = [("chn", C.c_int), ("len", C.c_int), ("err", C.c_int), ("lvl", C.c_float),
+                ("crc", C.c_ubyte * 2), ("txt", C.c_ubyte * TXTMAX),
+                ("end_bit", C.c_longlong), ("end_sample", C.c_longlong)]
+
+
+BIT_SINK = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_float, C.c_float)
+
+# name -> (restype, argtypes): every symbol include/acarsdec_amd.h declares
+SYMBOLS = {
+    "acg_device_count": (C.c_int, []),
+    "acg_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(Config)]),
+    "acg_destroy": (None, [C.c_void_p]),
+    "acg_strerror": (C.c_char_p, [C.c_int]),
+    "acg_last_error": (C.c_char_p, [C.c_void_p]),
+    "acg_version": (C.c_char_p, []),
+    "acg_rtl_choose_fc": (C.c_uint, [C.c_void_p, C.c_uint, C.c_int]),
+    "acg_rtl_taps": (C.c_int, [C.c_int, C.c_uint, C.c_int, C.c_void_p]),
+    "acg_set_taps": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "acg_set_channel_streams": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "acg_reset": (C.c_int, [C.c_void_p]),
+    "acg_process_iq_u8_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "acg_process_iq_u8_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "acg_process_dm_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "acg_process_dm_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "acg_fir_only_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "acg_sync": (C.c_int, [C.c_void_p]),
+    "acg_drain_frames": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.c_int, C.POINTER(C.c_int)]),
+    "acg_read_bits": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "acg_read_bits_all": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "acg_bit_capacity": (C.c_int, [C.c_void_p]),
+    "acg_read_dm": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "acg_get_state": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(ChanState)]),
+    "acg_set_state": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(ChanState)]),
+    "acg_replay_bits": (C.c_int, [C.c_void_p, BIT_SINK, C.c_void_p]),
+    "acg_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int),
+                                 C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "acg_fill_random_u8_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_uint64, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the native library.  Raises (never falls back) if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+        try:
+            # PyTorch bundles its own libamdhip64.so.7; importing it first makes this library bind
+            # to the SAME HIP runtime instance so torch device pointers / streams are usable here.
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is plumbing, not required by the library
+            pass
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class AcgError(RuntimeError):
+    def __init__(self, code, msg=""):
+        self.code = code
+        super().__init__("acarsdec_amd error %d: %s %s" % (code, load().acg_strerror(code).decode(), msg))

@@ -1,0 +1,592 @@
+// acg_api.cpp -- the C ABI of include/acarsdec_amd.h on top of the HIP kernels.
+// Host runtime only: buffers, launches, result queues.  There is deliberately no CPU compute
+// path here: without a GPU acg_create() fails with ACG_ENODEV.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "acarsdec_amd.h"
+#include "acg_internal.h"
+
+extern "C" void acg_host_msk_h(float* h);
+extern "C" float acg_host_level_db(double lvlsum, int bitcount);
+
+namespace {
+
+struct EvPair { hipEvent_t a, b; };
+
+}  // namespace
+
+struct acg_ctx {
+    acg_config cfg{};
+    std::string err;
+    hipStream_t stream = nullptr;
+    bool tile_path = true;          // decim % 8 == 0 -> LDS-tiled kernel
+    int ntaps_pad = 0;
+    int max_len = 0;                // max_blocks * 1024
+    size_t dm_pitch = 0;
+    int bit_cap = 0;
+    unsigned int frame_cap = 0;
+    int last_len = 0;               // samples per channel of the last demod call
+    bool last_had_demod = false;
+
+    float* d_taps = nullptr;
+    int* d_stream_of = nullptr;
+    float* d_dm = nullptr;
+    AcgChan* d_st = nullptr;
+    float* d_h = nullptr;
+    unsigned char* d_txt = nullptr;
+    AcgFrameRec* d_frames = nullptr;
+    unsigned int* d_frame_count = nullptr;
+    float2* d_bits = nullptr;
+    int* d_nbits = nullptr;
+    void* d_stage = nullptr;        // staging for *_host entry points
+    size_t stage_bytes = 0;
+
+    std::vector<EvPair> fir_ev, msk_ev;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+#define HIPCHK(ctx, call)                                                                  \
+    do {                                                                                   \
+        hipError_t e__ = (call);                                                           \
+        if (e__ != hipSuccess) {                                                           \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);               \
+            return ACG_EHIP;                                                               \
+        }                                                                                  \
+    } while (0)
+
+static int fail(acg_ctx* ctx, int code, const char* msg)
+{
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+// zero device memory and make sure it has happened before any later launch on any stream
+static int zero_sync(acg_ctx* c, void* p, size_t bytes)
+{
+    HIPCHK(c, hipMemset(p, 0, bytes));
+    HIPCHK(c, hipDeviceSynchronize());
+    return ACG_OK;
+}
+
+extern "C" const char* acg_version(void) { return "acarsdec_amd 0.1 (gfx950)"; }
+
+extern "C" const char* acg_strerror(int code)
+{
+    switch (code) {
+    case ACG_OK: return "ok";
+    case ACG_EINVAL: return "invalid argument";
+    case ACG_ENOMEM: return "out of memory";
+    case ACG_EHIP: return "HIP runtime error";
+    case ACG_ENODEV: return "no GPU available (this library has no CPU fallback)";
+    case ACG_EOVERFLOW: return "output queue overflow";
+    case ACG_ESTATE: return "bad call sequence";
+    default: return "unknown error";
+    }
+}
+
+extern "C" const char* acg_last_error(const acg_ctx* ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+extern "C" int acg_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static void free_all(acg_ctx* c)
+{
+    if (!c) return;
+    hipFree(c->d_taps); hipFree(c->d_stream_of); hipFree(c->d_dm); hipFree(c->d_st);
+    hipFree(c->d_h); hipFree(c->d_txt); hipFree(c->d_frames); hipFree(c->d_frame_count);
+    hipFree(c->d_bits); hipFree(c->d_nbits); hipFree(c->d_stage);
+    for (auto& p : c->fir_ev) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    for (auto& p : c->msk_ev) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    for (auto e : c->ev_pool) hipEventDestroy(e);
+    if (c->stream) hipStreamDestroy(c->stream);
+}
+
+extern "C" void acg_destroy(acg_ctx* ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->cfg.device);
+    hipDeviceSynchronize();
+    free_all(ctx);
+    delete ctx;
+}
+
+extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
+{
+    if (!out || !cfg) return ACG_EINVAL;
+    *out = nullptr;
+    if (cfg->nch < 1 || cfg->nstreams < 1 || cfg->nstreams > cfg->nch || cfg->decim < 1 ||
+        cfg->decim > ACG_MAXDECIM || cfg->ntaps < 1 || cfg->ntaps > cfg->decim || cfg->max_blocks < 1)
+        return ACG_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || cfg->device < 0 || cfg->device >= ndev)
+        return ACG_ENODEV;
+
+    acg_ctx* c = new (std::nothrow) acg_ctx;
+    if (!c) return ACG_ENOMEM;
+    c->cfg = *cfg;
+    c->tile_path = (cfg->decim % 8) == 0;
+    c->ntaps_pad = c->tile_path ? ((cfg->ntaps + 7) & ~7) : cfg->ntaps;
+    c->max_len = cfg->max_blocks * ACG_BLOCK;
+    c->dm_pitch = ((size_t)c->max_len + 63) & ~(size_t)63;
+    c->bit_cap = c->max_len / 4 + 8;
+    // shortest possible block: SYN SYN SOH ETX CRC CRC + END byte = 56 bits ~ 291 samples
+    c->frame_cap = (unsigned int)cfg->nch * (unsigned int)(c->max_len / 291 + 2);
+
+    int rc = ACG_OK;
+    auto body = [&]() -> int {
+        HIPCHK(c, hipSetDevice(cfg->device));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        const size_t nch = (size_t)cfg->nch;
+        HIPCHK(c, hipMalloc(&c->d_taps, nch * c->ntaps_pad * 2 * sizeof(float)));
+        HIPCHK(c, hipMemset(c->d_taps, 0, nch * c->ntaps_pad * 2 * sizeof(float)));
+        HIPCHK(c, hipMalloc(&c->d_stream_of, nch * sizeof(int)));
+        HIPCHK(c, hipMalloc(&c->d_dm, nch * c->dm_pitch * sizeof(float)));
+        HIPCHK(c, hipMalloc(&c->d_st, nch * sizeof(AcgChan)));
+        HIPCHK(c, hipMalloc(&c->d_h, 136 * sizeof(float)));
+        HIPCHK(c, hipMalloc(&c->d_txt, nch * 256));
+        HIPCHK(c, hipMemset(c->d_txt, 0, nch * 256));
+        HIPCHK(c, hipMalloc(&c->d_frames, (size_t)c->frame_cap * sizeof(AcgFrameRec)));
+        HIPCHK(c, hipMalloc(&c->d_frame_count, sizeof(unsigned int)));
+        HIPCHK(c, hipMemset(c->d_frame_count, 0, sizeof(unsigned int)));
+        if (cfg->flags & ACG_F_BITLOG)
+            HIPCHK(c, hipMalloc(&c->d_bits, nch * (size_t)c->bit_cap * sizeof(float2)));
+        HIPCHK(c, hipMalloc(&c->d_nbits, nch * sizeof(int)));
+        HIPCHK(c, hipMemset(c->d_nbits, 0, nch * sizeof(int)));
+
+        float h[136] = {0};
+        acg_host_msk_h(h);                               // msk.c:44-48
+        HIPCHK(c, hipMemcpy(c->d_h, h, sizeof(h), hipMemcpyHostToDevice));
+        std::vector<int> so(nch);
+        for (size_t i = 0; i < nch; ++i) so[i] = (int)(i % (size_t)cfg->nstreams);
+        HIPCHK(c, hipMemcpy(c->d_stream_of, so.data(), nch * sizeof(int), hipMemcpyHostToDevice));
+        return ACG_OK;
+    };
+    rc = body();
+    if (rc == ACG_OK) rc = acg_reset(c);
+    if (rc != ACG_OK) {
+        // keep the message reachable through a static for the failing create
+        static thread_local std::string last;
+        last = c->err;
+        free_all(c);
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return ACG_OK;
+}
+
+extern "C" int acg_reset(acg_ctx* ctx)
+{
+    if (!ctx) return ACG_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // initMsk (msk.c:34-41): MskPhi = MskClk = MskS = MskDf = idx = 0, inb zeroed;
+    // static storage: MskLvlSum = MskBitCount = 0; initAcars (acars.c:230-234): outbits 0, nbits 8, WSYN
+    std::vector<AcgChan> st((size_t)ctx->cfg.nch);
+    std::memset(st.data(), 0, st.size() * sizeof(AcgChan));
+    for (auto& s : st) s.nbits = 8;
+    HIPCHK(ctx, hipMemcpy(ctx->d_st, st.data(), st.size() * sizeof(AcgChan), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemset(ctx->d_frame_count, 0, sizeof(unsigned int)));
+    int zr = zero_sync(ctx, ctx->d_nbits, (size_t)ctx->cfg.nch * sizeof(int));
+    if (zr != ACG_OK) return zr;
+    ctx->last_len = 0;
+    ctx->last_had_demod = false;
+    return ACG_OK;
+}
+
+extern "C" int acg_set_taps(acg_ctx* ctx, int ch0, int n, const float* taps)
+{
+    if (!ctx || !taps || ch0 < 0 || n < 1 || ch0 + n > ctx->cfg.nch) return ACG_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t src_pitch = (size_t)ctx->cfg.ntaps * 2 * sizeof(float);
+    const size_t dst_pitch = (size_t)ctx->ntaps_pad * 2 * sizeof(float);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy2D(ctx->d_taps + (size_t)ch0 * ctx->ntaps_pad * 2, dst_pitch, taps, src_pitch,
+                            src_pitch, (size_t)n, hipMemcpyHostToDevice));
+    return ACG_OK;
+}
+
+extern "C" int acg_set_channel_streams(acg_ctx* ctx, const int* stream_of_channel)
+{
+    if (!ctx || !stream_of_channel) return ACG_EINVAL;
+    for (int i = 0; i < ctx->cfg.nch; ++i)
+        if (stream_of_channel[i] < 0 || stream_of_channel[i] >= ctx->cfg.nstreams)
+            return fail(ctx, ACG_EINVAL, "stream index out of range");
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpy(ctx->d_stream_of, stream_of_channel, (size_t)ctx->cfg.nch * sizeof(int),
+                          hipMemcpyHostToDevice));
+    return ACG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+static int get_event(acg_ctx* c, hipEvent_t* e)
+{
+    if (!c->ev_pool.empty()) {
+        *e = c->ev_pool.back();
+        c->ev_pool.pop_back();
+        return ACG_OK;
+    }
+    HIPCHK(c, hipEventCreate(e));
+    return ACG_OK;
+}
+
+static int launch_fir(acg_ctx* c, const uint8_t* iq_dev, size_t pitch, int nblocks, hipStream_t s)
+{
+    const acg_config& g = c->cfg;
+    FirArgs a{};
+    a.iq = iq_dev;
+    a.pitch = pitch;
+    a.stream_of = c->d_stream_of;
+    a.taps = c->d_taps;
+    a.dm = c->d_dm;
+    a.dm_pitch = c->dm_pitch;
+    a.nch = g.nch;
+    a.decim = g.decim;
+    a.ntaps_pad = c->ntaps_pad;
+    a.nwin = nblocks * ACG_BLOCK;
+    a.row_bytes = 2 * g.decim;
+    const bool timing = (g.flags & ACG_F_TIMING) != 0;
+    EvPair ev{};
+    if (timing) {
+        int r;
+        if ((r = get_event(c, &ev.a)) != ACG_OK || (r = get_event(c, &ev.b)) != ACG_OK) return r;
+        HIPCHK(c, hipEventRecord(ev.a, s));
+    }
+    int e;
+    if (c->tile_path) {
+        a.cpr = a.row_bytes / 16;
+        a.row_stride = (a.cpr & 1) ? a.row_bytes : a.row_bytes + 16;
+        a.cpr_magic = ((1u << 20) + (unsigned int)a.cpr - 1) / (unsigned int)a.cpr;
+        const int ntile = a.nwin / ACG_TILE_WIN;
+        int nseg = (4096 + g.nch - 1) / g.nch;          // aim at >= ~4096 workgroups
+        nseg = std::max(1, std::min(nseg, ntile));
+        a.nseg = nseg;
+        e = acg_launch_fir(&a, s);
+    } else {
+        a.nseg = 1;
+        e = acg_launch_fir_generic(&a, s);
+    }
+    if (e != 0) {
+        c->err = std::string("FIR launch: ") + hipGetErrorString((hipError_t)e);
+        return ACG_EHIP;
+    }
+    if (timing) {
+        HIPCHK(c, hipEventRecord(ev.b, s));
+        c->fir_ev.push_back(ev);
+    }
+    return ACG_OK;
+}
+
+static int launch_msk(acg_ctx* c, const float* dm_dev, size_t pitch_floats, int len, hipStream_t s)
+{
+    const acg_config& g = c->cfg;
+    MskArgs a{};
+    a.st = c->d_st;
+    a.dm = dm_dev;
+    a.dm_pitch = pitch_floats;
+    a.h = c->d_h;
+    a.txt = c->d_txt;
+    a.frames = c->d_frames;
+    a.frame_count = c->d_frame_count;
+    a.frame_cap = c->frame_cap;
+    a.bits = c->d_bits;
+    a.nbits_out = c->d_nbits;
+    a.bit_cap = c->bit_cap;
+    a.nch = g.nch;
+    a.len = len;
+    const bool timing = (g.flags & ACG_F_TIMING) != 0;
+    EvPair ev{};
+    if (timing) {
+        int r;
+        if ((r = get_event(c, &ev.a)) != ACG_OK || (r = get_event(c, &ev.b)) != ACG_OK) return r;
+        HIPCHK(c, hipEventRecord(ev.a, s));
+    }
+    const int e = acg_launch_msk(&a, s);
+    if (e != 0) {
+        c->err = std::string("MSK launch: ") + hipGetErrorString((hipError_t)e);
+        return ACG_EHIP;
+    }
+    if (timing) {
+        HIPCHK(c, hipEventRecord(ev.b, s));
+        c->msk_ev.push_back(ev);
+    }
+    c->last_len = len;
+    c->last_had_demod = true;
+    return ACG_OK;
+}
+
+static int check_iq_args(acg_ctx* ctx, const void* p, size_t pitch, int nblocks)
+{
+    if (!ctx || !p) return ACG_EINVAL;
+    if (nblocks < 1 || nblocks > ctx->cfg.max_blocks) return fail(ctx, ACG_EINVAL, "nblocks out of range");
+    const size_t row = (size_t)nblocks * ACG_BLOCK * ctx->cfg.decim * 2;
+    if (ctx->cfg.nstreams > 1 && pitch < row) return fail(ctx, ACG_EINVAL, "pitch smaller than a row");
+    return ACG_OK;
+}
+
+extern "C" int acg_fir_only_dev(acg_ctx* ctx, const uint8_t* iq_dev, size_t pitch_bytes, int nblocks,
+                                void* hip_stream)
+{
+    int r = check_iq_args(ctx, iq_dev, pitch_bytes, nblocks);
+    if (r != ACG_OK) return r;
+    if (ctx->tile_path && (((uintptr_t)iq_dev | pitch_bytes) & 15))
+        return fail(ctx, ACG_EINVAL, "I/Q base and pitch must be 16-byte aligned");
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    r = launch_fir(ctx, iq_dev, pitch_bytes, nblocks, s);
+    if (r == ACG_OK) ctx->last_len = nblocks * ACG_BLOCK;
+    return r;
+}
+
+extern "C" int acg_process_iq_u8_dev(acg_ctx* ctx, const uint8_t* iq_dev, size_t pitch_bytes, int nblocks,
+                                     void* hip_stream)
+{
+    int r = acg_fir_only_dev(ctx, iq_dev, pitch_bytes, nblocks, hip_stream);
+    if (r != ACG_OK) return r;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    return launch_msk(ctx, ctx->d_dm, ctx->dm_pitch, nblocks * ACG_BLOCK, s);
+}
+
+static int ensure_stage(acg_ctx* c, size_t bytes)
+{
+    if (c->stage_bytes >= bytes) return ACG_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->d_stage) hipFree(c->d_stage);
+    c->d_stage = nullptr;
+    c->stage_bytes = 0;
+    HIPCHK(c, hipMalloc(&c->d_stage, bytes));
+    c->stage_bytes = bytes;
+    return ACG_OK;
+}
+
+extern "C" int acg_process_iq_u8_host(acg_ctx* ctx, const uint8_t* iq_host, size_t pitch_bytes, int nblocks)
+{
+    int r = check_iq_args(ctx, iq_host, pitch_bytes, nblocks);
+    if (r != ACG_OK) return r;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    const size_t row = (size_t)nblocks * ACG_BLOCK * ctx->cfg.decim * 2;
+    const size_t dpitch = (row + 15) & ~(size_t)15;
+    if ((r = ensure_stage(ctx, dpitch * ctx->cfg.nstreams)) != ACG_OK) return r;
+    HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_stage, dpitch, iq_host, ctx->cfg.nstreams > 1 ? pitch_bytes : row,
+                                 row, (size_t)ctx->cfg.nstreams, hipMemcpyHostToDevice, ctx->stream));
+    return acg_process_iq_u8_dev(ctx, (const uint8_t*)ctx->d_stage, dpitch, nblocks, nullptr);
+}
+
+extern "C" int acg_process_dm_dev(acg_ctx* ctx, const float* dm_dev, size_t pitch_floats, int len,
+                                  void* hip_stream)
+{
+    if (!ctx || !dm_dev) return ACG_EINVAL;
+    if (len < 0 || len > ctx->max_len) return fail(ctx, ACG_EINVAL, "len out of range");
+    if (ctx->cfg.nch > 1 && pitch_floats < (size_t)len) return fail(ctx, ACG_EINVAL, "pitch smaller than len");
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    return launch_msk(ctx, dm_dev, pitch_floats, len, s);
+}
+
+extern "C" int acg_process_dm_host(acg_ctx* ctx, const float* dm_host, size_t pitch_floats, int len)
+{
+    if (!ctx || !dm_host) return ACG_EINVAL;
+    if (len < 0 || len > ctx->max_len) return fail(ctx, ACG_EINVAL, "len out of range");
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    if (len == 0) return launch_msk(ctx, ctx->d_dm, ctx->dm_pitch, 0, ctx->stream);
+    const size_t rowb = (size_t)len * sizeof(float);
+    HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_dm, ctx->dm_pitch * sizeof(float), dm_host,
+                                 (ctx->cfg.nch > 1 ? pitch_floats : (size_t)len) * sizeof(float), rowb,
+                                 (size_t)ctx->cfg.nch, hipMemcpyHostToDevice, ctx->stream));
+    return launch_msk(ctx, ctx->d_dm, ctx->dm_pitch, len, ctx->stream);
+}
+
+extern "C" int acg_sync(acg_ctx* ctx)
+{
+    if (!ctx) return ACG_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return ACG_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" int acg_drain_frames(acg_ctx* ctx, acg_frame* out, int max_frames, int* nframes)
+{
+    if (!ctx || !nframes || (max_frames > 0 && !out)) return ACG_EINVAL;
+    *nframes = 0;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    unsigned int count = 0;
+    HIPCHK(ctx, hipMemcpy(&count, ctx->d_frame_count, sizeof(count), hipMemcpyDeviceToHost));
+    const unsigned int have = std::min(count, ctx->frame_cap);
+    std::vector<AcgFrameRec> rec(have);
+    if (have) HIPCHK(ctx, hipMemcpy(rec.data(), ctx->d_frames, (size_t)have * sizeof(AcgFrameRec), hipMemcpyDeviceToHost));
+    { int zr = zero_sync(ctx, ctx->d_frame_count, sizeof(unsigned int)); if (zr != ACG_OK) return zr; }
+    std::sort(rec.begin(), rec.end(), [](const AcgFrameRec& a, const AcgFrameRec& b) {
+        return a.chn != b.chn ? a.chn < b.chn : a.end_bit < b.end_bit;
+    });
+    const int n = std::min<int>((int)have, max_frames);
+    for (int i = 0; i < n; ++i) {
+        const AcgFrameRec& r = rec[(size_t)i];
+        acg_frame& f = out[i];
+        std::memset(&f, 0, sizeof(f));
+        f.chn = r.chn;
+        f.len = r.len;
+        f.err = r.err;
+        f.lvl = acg_host_level_db(r.lvlsum, r.bitcount);         // acars.c:351
+        f.crc[0] = r.crc[0];
+        f.crc[1] = r.crc[1];
+        if (r.len > 0) std::memcpy(f.txt, r.txt, (size_t)std::min(r.len, ACG_TXTMAX));
+        f.end_bit = r.end_bit;
+        f.end_sample = r.end_sample;
+    }
+    *nframes = n;
+    if (count > ctx->frame_cap || (int)have > max_frames) return fail(ctx, ACG_EOVERFLOW, "frame queue overflow");
+    return ACG_OK;
+}
+
+extern "C" int acg_bit_capacity(const acg_ctx* ctx) { return ctx ? ctx->bit_cap : 0; }
+
+extern "C" int acg_read_bits(acg_ctx* ctx, int ch, float* vo, float* lvl, int max_bits, int* nbits)
+{
+    if (!ctx || !nbits || ch < 0 || ch >= ctx->cfg.nch) return ACG_EINVAL;
+    if (!ctx->d_bits) return fail(ctx, ACG_ESTATE, "context created without ACG_F_BITLOG");
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    int n = 0;
+    HIPCHK(ctx, hipMemcpy(&n, ctx->d_nbits + ch, sizeof(int), hipMemcpyDeviceToHost));
+    *nbits = n;
+    const int m = std::min(std::min(n, ctx->bit_cap), max_bits);
+    if (m > 0) {
+        std::vector<float2> tmp((size_t)m);
+        HIPCHK(ctx, hipMemcpy(tmp.data(), ctx->d_bits + (size_t)ch * ctx->bit_cap, (size_t)m * sizeof(float2),
+                              hipMemcpyDeviceToHost));
+        for (int i = 0; i < m; ++i) {
+            if (vo) vo[i] = tmp[(size_t)i].x;
+            if (lvl) lvl[i] = tmp[(size_t)i].y;
+        }
+    }
+    return n > ctx->bit_cap ? ACG_EOVERFLOW : ACG_OK;
+}
+
+extern "C" int acg_read_bits_all(acg_ctx* ctx, int* counts, float* vo, float* lvl)
+{
+    if (!ctx || !counts) return ACG_EINVAL;
+    if (!ctx->d_bits) return fail(ctx, ACG_ESTATE, "context created without ACG_F_BITLOG");
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    const size_t nch = (size_t)ctx->cfg.nch, cap = (size_t)ctx->bit_cap;
+    HIPCHK(ctx, hipMemcpy(counts, ctx->d_nbits, nch * sizeof(int), hipMemcpyDeviceToHost));
+    if (vo || lvl) {
+        std::vector<float2> tmp(nch * cap);
+        HIPCHK(ctx, hipMemcpy(tmp.data(), ctx->d_bits, tmp.size() * sizeof(float2), hipMemcpyDeviceToHost));
+        for (size_t c = 0; c < nch; ++c) {
+            const size_t m = (size_t)std::min<int>(counts[c], (int)cap);
+            for (size_t i = 0; i < m; ++i) {
+                if (vo) vo[c * cap + i] = tmp[c * cap + i].x;
+                if (lvl) lvl[c * cap + i] = tmp[c * cap + i].y;
+            }
+        }
+    }
+    return ACG_OK;
+}
+
+extern "C" int acg_replay_bits(acg_ctx* ctx, acg_bit_sink sink, void* user)
+{
+    if (!ctx || !sink) return ACG_EINVAL;
+    if (!ctx->d_bits) return fail(ctx, ACG_ESTATE, "context created without ACG_F_BITLOG");
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    const size_t nch = (size_t)ctx->cfg.nch, cap = (size_t)ctx->bit_cap;
+    std::vector<int> counts(nch);
+    HIPCHK(ctx, hipMemcpy(counts.data(), ctx->d_nbits, nch * sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<float2> tmp(nch * cap);
+    HIPCHK(ctx, hipMemcpy(tmp.data(), ctx->d_bits, tmp.size() * sizeof(float2), hipMemcpyDeviceToHost));
+    int rc = ACG_OK;
+    for (size_t c = 0; c < nch; ++c) {
+        if (counts[c] > (int)cap) rc = ACG_EOVERFLOW;
+        const size_t m = (size_t)std::min<int>(counts[c], (int)cap);
+        for (size_t i = 0; i < m; ++i) sink(user, (int)c, tmp[c * cap + i].x, tmp[c * cap + i].y);
+    }
+    return rc;
+}
+
+extern "C" int acg_read_dm(acg_ctx* ctx, int ch, float* dm, int n)
+{
+    if (!ctx || !dm || ch < 0 || ch >= ctx->cfg.nch || n < 0 || n > ctx->max_len) return ACG_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    if (n) HIPCHK(ctx, hipMemcpy(dm, ctx->d_dm + (size_t)ch * ctx->dm_pitch, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return ACG_OK;
+}
+
+extern "C" int acg_get_state(acg_ctx* ctx, int ch, acg_chan_state* st)
+{
+    if (!ctx || !st || ch < 0 || ch >= ctx->cfg.nch) return ACG_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    AcgChan d;
+    HIPCHK(ctx, hipMemcpy(&d, ctx->d_st + ch, sizeof(d), hipMemcpyDeviceToHost));
+    st->MskPhi = d.phi; st->MskDf = d.df; st->MskLvlSum = d.lvlsum; st->MskClk = d.clk;
+    st->MskBitCount = d.bitcount; st->MskS = d.S; st->idx = d.idx;
+    std::memcpy(st->inb, d.inb, sizeof(d.inb));
+    st->outbits = (int)d.outbits; st->nbits = d.nbits; st->Acarsstate = d.astate;
+    st->blk_len = d.blen; st->blk_err = d.berr;
+    return ACG_OK;
+}
+
+extern "C" int acg_set_state(acg_ctx* ctx, int ch, const acg_chan_state* st)
+{
+    if (!ctx || !st || ch < 0 || ch >= ctx->cfg.nch) return ACG_EINVAL;
+    if (st->idx >= ACG_FLEN) return fail(ctx, ACG_EINVAL, "idx out of range");
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    AcgChan d;
+    HIPCHK(ctx, hipMemcpy(&d, ctx->d_st + ch, sizeof(d), hipMemcpyDeviceToHost));
+    d.phi = st->MskPhi; d.df = st->MskDf; d.lvlsum = st->MskLvlSum; d.clk = st->MskClk;
+    d.bitcount = st->MskBitCount; d.S = st->MskS; d.idx = st->idx;
+    std::memcpy(d.inb, st->inb, sizeof(d.inb));
+    d.outbits = (unsigned int)st->outbits & 0xffu; d.nbits = st->nbits; d.astate = st->Acarsstate;
+    d.blen = st->blk_len; d.berr = st->blk_err;
+    HIPCHK(ctx, hipMemcpy(ctx->d_st + ch, &d, sizeof(d), hipMemcpyHostToDevice));
+    return ACG_OK;
+}
+
+extern "C" int acg_get_timing(acg_ctx* ctx, double* fir_ms, int* fir_launches, double* msk_ms, int* msk_launches)
+{
+    if (!ctx) return ACG_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    auto sum = [&](std::vector<EvPair>& v, double* ms, int* n) -> int {
+        double t = 0;
+        for (auto& p : v) {
+            float f = 0;
+            HIPCHK(ctx, hipEventElapsedTime(&f, p.a, p.b));
+            t += f;
+            ctx->ev_pool.push_back(p.a);
+            ctx->ev_pool.push_back(p.b);
+        }
+        if (ms) *ms = t;
+        if (n) *n = (int)v.size();
+        v.clear();
+        return ACG_OK;
+    };
+    int r = sum(ctx->fir_ev, fir_ms, fir_launches);
+    if (r != ACG_OK) return r;
+    return sum(ctx->msk_ev, msk_ms, msk_launches);
+}
+
+extern "C" int acg_fill_random_u8_dev(uint8_t* dev, size_t pitch_bytes, int nrows, size_t row_bytes,
+                                      uint64_t seed, void* hip_stream)
+{
+    if (!dev || nrows < 1 || (row_bytes & 15) || (pitch_bytes & 15) || ((uintptr_t)dev & 15)) return ACG_EINVAL;
+    const int e = acg_launch_fill_random(dev, pitch_bytes, nrows, row_bytes, seed, hip_stream);
+    return e == 0 ? ACG_OK : ACG_EHIP;
+}

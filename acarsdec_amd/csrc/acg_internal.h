@@ -1,0 +1,91 @@
+// acg_internal.h -- device-side data layout shared by the HIP kernels and the C-ABI host code.
+// Not installed; the public surface is include/acarsdec_amd.h.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#define ACG_WG_FIR 256          // FIR workgroup: 4 waves, one 64-window tile, taps split over waves
+#define ACG_TILE_WIN 64         // windows (12.5 kHz outputs) per FIR tile = one per lane
+#define ACG_WG_MSK 64           // MSK workgroup: one wave, one channel per lane
+
+// Per-channel demodulator + framing state, resident in HBM across calls.
+// Mirrors the MSK/ACARS fields of channel_t (acarsdec.h:76-89) plus bookkeeping.
+struct AcgChan {
+    double phi;                 // MskPhi
+    double df;                  // MskDf
+    double lvlsum;              // MskLvlSum
+    float clk;                  // MskClk
+    int bitcount;               // MskBitCount
+    unsigned int S;             // MskS
+    unsigned int idx;           // idx
+    float inb[22];              // inb[11] complex
+    int nbits;                  // nbits
+    int astate;                 // Acarsstate
+    int blen;                   // blk->len
+    int berr;                   // blk->err
+    unsigned int outbits;       // outbits
+    unsigned int crc0;          // blk->crc[0] (held between CRC1 and CRC2)
+    long long nbit_total;       // bits produced since reset
+    long long nsamp_total;      // 12.5 kHz samples consumed since reset
+};
+
+// One queued block (device layout; converted to acg_frame on the host).
+struct AcgFrameRec {
+    int chn;
+    int len;
+    int err;
+    int bitcount;               // MskBitCount at acars.c:351
+    double lvlsum;              // MskLvlSum at acars.c:351 (host takes 10*log10(lvlsum/bitcount))
+    long long end_bit;
+    long long end_sample;
+    unsigned char crc[2];
+    unsigned char pad[6];
+    unsigned char txt[256];     // 16-byte aligned, 16-byte multiples for vector copies
+};
+
+struct FirArgs {
+    const uint8_t* iq;          // [nstreams] rows
+    size_t pitch;               // bytes between stream rows (multiple of 16)
+    const int* stream_of;       // [nch]
+    const float* taps;          // [nch][ntaps_pad][2]
+    float* dm;                  // [nch][dm_pitch]
+    size_t dm_pitch;            // floats
+    int nch;
+    int decim;                  // M
+    int ntaps_pad;              // taps per channel, zero padded to a multiple of 8
+    int nwin;                   // outputs per channel this launch
+    int nseg;                   // time segments per channel (grid = nch * nseg)
+    int row_bytes;              // 2*M
+    int row_stride;             // LDS row stride in bytes ((row_stride/16) odd)
+    int cpr;                    // 16-byte chunks per row = row_bytes/16
+    unsigned int cpr_magic;     // ceil(2^20 / cpr): c / cpr == (c * magic) >> 20 for c < 2^11
+};
+
+struct MskArgs {
+    AcgChan* st;                // [nch]
+    const float* dm;            // [nch][dm_pitch]
+    size_t dm_pitch;
+    const float* h;             // [133] matched filter prototype (msk.c:44-48)
+    unsigned char* txt;         // [nch][256] blk->txt being assembled
+    AcgFrameRec* frames;        // queue
+    unsigned int* frame_count;  // queue length (atomic)
+    unsigned int frame_cap;
+    float2* bits;               // [nch][bit_cap] {vo, lvl}, may be null
+    int* nbits_out;             // [nch]
+    int bit_cap;
+    int nch;
+    int len;                    // samples per channel this launch
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+// kernel launchers (fir.hip / msk.hip / synth.hip); stream is a hipStream_t
+int acg_launch_fir(const FirArgs* a, void* stream);
+int acg_launch_fir_generic(const FirArgs* a, void* stream);
+size_t acg_fir_lds_bytes(const FirArgs* a);
+int acg_launch_msk(const MskArgs* a, void* stream);
+int acg_launch_fill_random(uint8_t* dev, size_t pitch, int nrows, size_t row_bytes, uint64_t seed, void* stream);
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,199 @@
+// fir.hip -- the RTL down-converter on gfx950: u8 I/Q -> (x-127.37) -> per channel
+// D = sum_k vb[k]*wf[k] over a window of M input samples -> |D|   (rtl.c:332-354).
+//
+// Shape of the problem: each input byte is used once per channel (taps == decimation), 8 flop per
+// 2 bytes -> HBM-read bound, no data reuse, no MFMA (1-D convolution).  Design:
+//   * a workgroup (4 waves) owns a contiguous run of 64-window tiles of ONE channel and walks it
+//     in time (persistent over its segment);
+//   * a tile (64 windows x 2M bytes, contiguous in HBM) is fetched with 16-byte coalesced loads,
+//     staged through registers into LDS rows whose stride is an odd number of 16-byte slots, so
+//     that "lane = window" ds_read_b128 reads are bank-conflict free;
+//   * the loads of tile t+1 are issued before tile t is computed and only waited for at the LDS
+//     write (issue-early / write-late), so HBM latency hides under the VALU work;
+//   * inside a wave every lane is at the same tap index, so taps are wave-uniform: they come in
+//     through scalar loads (SGPRs), not VGPRs or LDS;
+//   * the 4 waves split the tap range; partial sums meet in LDS; wave 0 takes |D| and writes 64
+//     consecutive floats of dm.
+#include <hip/hip_runtime.h>
+#include "acg_internal.h"
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+#define FIR_MAXLD 10   // 64 rows * 640 B (M=320) / 16 B / 256 threads
+
+extern __shared__ __attribute__((aligned(16))) unsigned char fir_smem[];
+
+__device__ __forceinline__ float cabs_like_glibc(float re, float im)
+{
+    // glibc 2.35 cabsf/hypotf == (float)sqrt((double)x*x + (double)y*y) (checked on 2e8 inputs);
+    // products are exact in double, one rounding in the sum, correctly rounded sqrt, one narrowing.
+    double d = (double)re * (double)re + (double)im * (double)im;
+    return (float)__dsqrt_rn(d);
+}
+
+__global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_tile_kernel(const FirArgs a,
+                                                                  const uint8_t* __restrict__ iq_base,
+                                                                  const float* __restrict__ taps_base,
+                                                                  const int* __restrict__ stream_of,
+                                                                  float* __restrict__ dm_base)
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ch = blockIdx.x / a.nseg;
+    const int seg = blockIdx.x - ch * a.nseg;
+    const int ntile = (a.nwin + ACG_TILE_WIN - 1) / ACG_TILE_WIN;
+    const int t0 = (int)((long long)ntile * seg / a.nseg);
+    const int t1 = (int)((long long)ntile * (seg + 1) / a.nseg);
+    if (t0 >= t1) return;
+
+    const uint8_t* __restrict__ src = iq_base + (size_t)stream_of[ch] * a.pitch;
+    const float* __restrict__ taps = taps_base + (size_t)ch * a.ntaps_pad * 2;
+    float* __restrict__ dm = dm_base + (size_t)ch * a.dm_pitch;
+
+    const int cpr = a.cpr;
+    const int tile_chunks = ACG_TILE_WIN * cpr;
+    const int total_chunks = a.nwin * cpr;              // valid 16-byte chunks of this stream row
+    const int pad = a.row_stride - a.row_bytes;
+    const unsigned int magic = a.cpr_magic;
+    unsigned char* tileL = fir_smem;
+    float4* red = (float4*)(fir_smem + ACG_TILE_WIN * a.row_stride);
+
+    const int nck = a.ntaps_pad >> 3;                   // chunks that carry taps
+    const int c0 = nck * wave / 4;
+    const int c1 = nck * (wave + 1) / 4;
+    const int nld = (tile_chunks + ACG_WG_FIR - 1) / ACG_WG_FIR;
+
+    uint4 stage[FIR_MAXLD];
+
+    // ---- prologue: fetch the first tile
+    {
+        const int base = t0 * tile_chunks;
+#pragma unroll
+        for (int i = 0; i < FIR_MAXLD; ++i) {
+            if (i < nld) {
+                const int c = tid + i * ACG_WG_FIR;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (c < tile_chunks && base + c < total_chunks)
+                    v = *(const uint4*)(src + ((size_t)(base + c) << 4));
+                stage[i] = v;
+            }
+        }
+    }
+
+    for (int t = t0; t < t1; ++t) {
+        // ---- registers -> LDS (padded rows)
+#pragma unroll
+        for (int i = 0; i < FIR_MAXLD; ++i) {
+            if (i < nld) {
+                const int c = tid + i * ACG_WG_FIR;
+                if (c < tile_chunks) {
+                    const int r = (int)(((unsigned int)c * magic) >> 20);
+                    *(uint4*)(tileL + (c << 4) + r * pad) = stage[i];
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- issue the next tile's loads; they stay in flight during the compute below
+        if (t + 1 < t1) {
+            const int base = (t + 1) * tile_chunks;
+#pragma unroll
+            for (int i = 0; i < FIR_MAXLD; ++i) {
+                if (i < nld) {
+                    const int c = tid + i * ACG_WG_FIR;
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (c < tile_chunks && base + c < total_chunks)
+                        v = *(const uint4*)(src + ((size_t)(base + c) << 4));
+                    stage[i] = v;
+                }
+            }
+        }
+
+        // ---- this wave's share of the taps, lane = window
+        f2 accA = {0.f, 0.f};       // (sum tr*wr, sum ti*wi)
+        f2 accB = {0.f, 0.f};       // (sum tr*wi, sum ti*wr)
+        const unsigned char* rowp = tileL + lane * a.row_stride;
+        for (int c = c0; c < c1; ++c) {
+            const uint4 q = *(const uint4*)(rowp + (c << 4));
+            const float* __restrict__ w = taps + (c << 4);       // wave-uniform -> scalar loads
+            const unsigned int qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned int word = qq[j >> 1];
+                const unsigned int sh = (j & 1) * 16;
+                f2 t;
+                t.x = (float)((word >> sh) & 0xffu) - 127.37f;          // rtl.c:338 (exact in f32)
+                t.y = (float)((word >> (sh + 8)) & 0xffu) - 127.37f;    // rtl.c:339
+                const f2 wv = {w[2 * j], w[2 * j + 1]};
+                const f2 ws = {w[2 * j + 1], w[2 * j]};
+                accA = __builtin_elementwise_fma(t, wv, accA);
+                accB = __builtin_elementwise_fma(t, ws, accB);
+            }
+        }
+        red[wave * 64 + lane] = make_float4(accA.x, accA.y, accB.x, accB.y);
+        __syncthreads();
+
+        if (wave == 0) {
+            const float4 r0 = red[lane], r1 = red[64 + lane], r2 = red[128 + lane], r3 = red[192 + lane];
+            const float Dr = ((r0.x + r1.x) + (r2.x + r3.x)) - ((r0.y + r1.y) + (r2.y + r3.y));
+            const float Di = ((r0.z + r1.z) + (r2.z + r3.z)) + ((r0.w + r1.w) + (r2.w + r3.w));
+            const int m = t * ACG_TILE_WIN + lane;
+            if (m < a.nwin) dm[m] = cabs_like_glibc(Dr, Di);             // rtl.c:353
+        }
+        // the barrier at the top of the next iteration orders wave 0's reads of `red`
+        // before anyone rewrites it.
+    }
+}
+
+// Fallback for decimations whose window is not a whole number of 16-byte chunks (M % 8 != 0):
+// one thread per output, sequential accumulation exactly in the reference's order.
+__global__ void fir_u8_generic_kernel(const FirArgs a, int ntaps)
+{
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)a.nch * a.nwin;
+    if (gid >= total) return;
+    const int ch = (int)(gid / a.nwin);
+    const int m = (int)(gid - (long long)ch * a.nwin);
+    const uint8_t* p = a.iq + (size_t)a.stream_of[ch] * a.pitch + (size_t)m * a.row_bytes;
+    const float* w = a.taps + (size_t)ch * a.ntaps_pad * 2;
+    float Dr = 0.f, Di = 0.f;
+    for (int k = 0; k < ntaps; ++k) {
+        const float r = (float)p[2 * k] - 127.37f;
+        const float g = (float)p[2 * k + 1] - 127.37f;
+        const float wr = w[2 * k], wi = w[2 * k + 1];
+        Dr = __fadd_rn(Dr, __fsub_rn(__fmul_rn(r, wr), __fmul_rn(g, wi)));
+        Di = __fadd_rn(Di, __fadd_rn(__fmul_rn(r, wi), __fmul_rn(g, wr)));
+    }
+    a.dm[(size_t)ch * a.dm_pitch + m] = cabs_like_glibc(Dr, Di);
+}
+
+extern "C" size_t acg_fir_lds_bytes(const FirArgs* a)
+{
+    return (size_t)ACG_TILE_WIN * a->row_stride + 4 * 64 * sizeof(float4);
+}
+
+extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
+{
+    const size_t lds = acg_fir_lds_bytes(a);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)fir_u8_tile_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    const unsigned int grid = (unsigned int)a->nch * (unsigned int)a->nseg;
+    hipLaunchKernelGGL(fir_u8_tile_kernel, dim3(grid), dim3(ACG_WG_FIR), lds, (hipStream_t)stream, *a,
+                       a->iq, a->taps, a->stream_of, a->dm);
+    return (int)hipGetLastError();
+}
+
+extern "C" int acg_launch_fir_generic(const FirArgs* a, void* stream)
+{
+    const long long total = (long long)a->nch * a->nwin;
+    const unsigned int grid = (unsigned int)((total + 255) / 256);
+    // ntaps_pad == ntaps on this path (no chunk padding)
+    hipLaunchKernelGGL(fir_u8_generic_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, a->ntaps_pad);
+    return (int)hipGetLastError();
+}

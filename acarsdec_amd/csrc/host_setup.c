@@ -1,0 +1,85 @@
+/*
+ * host_setup.c -- the host-side set-up arithmetic of the hot path, in plain C99 so that the
+ * float/double/complex promotions are exactly the ones the reference's C implies.
+ * Compile with -O2 -ffp-contract=off (no fast-math): these values feed the kernels and must be
+ * bit-identical to what the reference computes on the host.
+ *
+ *   acg_rtl_choose_fc   <- rtl.c:131-168  chooseFc()
+ *   acg_rtl_taps        <- rtl.c:283-286  the per-channel NCO*boxcar taps wf[]
+ *   acg_host_msk_h      <- msk.c:44-48    the matched-filter prototype h[]
+ *   acg_host_level_db   <- acars.c:351    blk->lvl
+ */
+#include <math.h>
+#include <complex.h>
+#include <stdlib.h>
+#include "acarsdec_amd.h"
+
+#define FLENO (ACG_FLEN * 12 + 1)
+
+unsigned int acg_rtl_choose_fc(unsigned int *Fd, unsigned int nbch, int decim)
+{
+	const int rate = ACG_INTRATE * decim;          /* rtl.c:214 rtlInRate */
+	const int guard = 2 * ACG_INTRATE;
+	unsigned int i, j;
+	int Fc;
+
+	if (!Fd || nbch == 0)
+		return 0;
+	/* rtl.c:136-147 sorts ascending (any stable sort gives the same array) */
+	for (i = 1; i < nbch; i++) {
+		unsigned int v = Fd[i];
+		for (j = i; j > 0 && Fd[j - 1] > v; j--)
+			Fd[j] = Fd[j - 1];
+		Fd[j] = v;
+	}
+	if (Fd[nbch - 1] - Fd[0] > (unsigned int)(rate - 2 * guard))       /* rtl.c:149 */
+		return 0;
+	/* rtl.c:154-165: walk down from just above the highest channel until every channel is
+	 * inside the usable band, clear of DC, and not the mirror image of its lower neighbour */
+	for (Fc = (int)(Fd[nbch - 1] + guard); (unsigned int)Fc > Fd[0] - guard; Fc--) {
+		int ok = 1;
+		for (i = 0; i < nbch && ok; i++) {
+			const int off = abs(Fc - (int)Fd[i]);
+			if (off > rate / 2 - guard || off < guard)
+				ok = 0;
+			else if (i > 0 && (unsigned int)Fc - Fd[i - 1] == Fd[i] - (unsigned int)Fc)
+				ok = 0;
+		}
+		if (ok)
+			break;
+	}
+	return (unsigned int)Fc;
+}
+
+int acg_rtl_taps(int Fr_hz, unsigned int Fc_hz, int decim, float *taps_out)
+{
+	int k;
+	float AMFreq;
+
+	if (!taps_out || decim < 1 || decim > ACG_MAXDECIM)
+		return ACG_EINVAL;
+	/* rtl.c:283: (int - float)/float in float, then *2.0*M_PI in double, stored as float */
+	AMFreq = (Fr_hz - (float)Fc_hz) / (float)(ACG_INTRATE * decim) * 2.0 * M_PI;
+	for (k = 0; k < decim; k++) {
+		/* rtl.c:285: float complex / int, then / double, narrowed to float complex */
+		const float complex w = cexpf(AMFreq * k * -I) / decim / 127.5;
+		taps_out[2 * k] = crealf(w);
+		taps_out[2 * k + 1] = cimagf(w);
+	}
+	return ACG_OK;
+}
+
+void acg_host_msk_h(float *h)
+{
+	int i;
+	for (i = 0; i < FLENO; i++) {
+		/* msk.c:46-47 */
+		const float c = cosf(2.0 * M_PI * 600.0 / ACG_INTRATE / 12 * (i - (FLENO - 1) / 2));
+		h[i] = c < 0 ? 0 : c;
+	}
+}
+
+float acg_host_level_db(double lvlsum, int bitcount)
+{
+	return 10 * log10(lvlsum / bitcount);          /* acars.c:351, double narrowed to float */
+}

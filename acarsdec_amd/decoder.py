@@ -1,0 +1,175 @@
+"""Host-side mirror of the reference's per-channel interface on top of the C ABI.
+
+Names follow the reference: a Decoder owns `nch` channels (channel_t, acarsdec.h:59-92);
+`init_rtl` is initRtl's tap set-up (rtl.c:243-287), `in_callback` is rtl.c:314-361 for all
+channels, `demod_msk` is demodMSK (msk.c:67-137) fed from 12.5 kHz samples, frames are the
+msgblk_t blocks decodeAcars queues (acars.c:350-364).  Everything numerical happens in
+libacarsdec_amd.so on the GPU; this file only marshals pointers.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as K
+
+
+def _chk(ctx, rc, allow=()):
+    if rc != K.OK and rc not in allow:
+        msg = K.load().acg_last_error(ctx).decode() if ctx else ""
+        raise K.AcgError(rc, msg)
+    return rc
+
+
+def rtl_taps(Fr_hz, Fc_hz, decim):
+    """wf[] of rtl.c:283-286 as float32 [decim, 2]."""
+    out = np.zeros((decim, 2), dtype=np.float32)
+    _chk(None, K.load().acg_rtl_taps(int(Fr_hz), int(Fc_hz), int(decim), out.ctypes.data))
+    return out
+
+
+def choose_fc(freqs_hz, decim):
+    """chooseFc of rtl.c:131-168. Returns (Fc, sorted freqs)."""
+    fd = np.array(freqs_hz, dtype=np.uint32)
+    fc = K.load().acg_rtl_choose_fc(fd.ctypes.data, len(fd), int(decim))
+    return int(fc), fd
+
+
+def parse_freq_mhz(s):
+    """rtl.c:245-247: command-line MHz string -> Hz rounded to the 12.5 kHz raster."""
+    return (int(1000000 * float(s) + K.INTRATE / 2) // K.INTRATE) * K.INTRATE
+
+
+class Decoder:
+    def __init__(self, nch, decim=160, ntaps=None, nstreams=None, max_blocks=1, device=0,
+                 bitlog=True, timing=False):
+        self.L = K.load()
+        self.nch, self.decim = int(nch), int(decim)
+        self.ntaps = int(ntaps if ntaps is not None else decim)
+        self.nstreams = int(nstreams if nstreams is not None else nch)
+        self.max_blocks = int(max_blocks)
+        cfg = K.Config(device, self.nch, self.nstreams, self.decim, self.ntaps, self.max_blocks,
+                       (K.F_BITLOG if bitlog else 0) | (K.F_TIMING if timing else 0))
+        self.ctx = C.c_void_p()
+        rc = self.L.acg_create(C.byref(self.ctx), C.byref(cfg))
+        if rc != K.OK:
+            raise K.AcgError(rc, "acg_create")
+        self.bit_cap = self.L.acg_bit_capacity(self.ctx)
+        self.Fc = None
+
+    def close(self):
+        if self.ctx:
+            self.L.acg_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- set-up -------------------------------------------------------------------------
+    def reset(self):
+        _chk(self.ctx, self.L.acg_reset(self.ctx))
+
+    def set_taps(self, taps, ch0=0):
+        taps = np.ascontiguousarray(taps, dtype=np.float32).reshape(-1, self.ntaps, 2)
+        _chk(self.ctx, self.L.acg_set_taps(self.ctx, ch0, taps.shape[0], taps.ctypes.data))
+
+    def set_channel_streams(self, stream_of):
+        a = np.ascontiguousarray(stream_of, dtype=np.int32)
+        assert a.size == self.nch
+        _chk(self.ctx, self.L.acg_set_channel_streams(self.ctx, a.ctypes.data))
+
+    def init_rtl(self, freqs_mhz):
+        """One dongle, nch channels sharing its stream: rtl.c:243-287.  Returns Fc."""
+        assert len(freqs_mhz) == self.nch
+        fr = [parse_freq_mhz(f) for f in freqs_mhz]
+        fc, _ = choose_fc(fr, self.decim)
+        if fc == 0:
+            raise ValueError("Frequencies too far apart")          # rtl.c:150
+        self.set_taps(np.stack([rtl_taps(f, fc, self.decim) for f in fr]))
+        self.Fc = fc
+        return fc
+
+    # ---- hot path -----------------------------------------------------------------------
+    @staticmethod
+    def _ptr(x):
+        """(pointer, is_device) of a numpy array or a torch tensor."""
+        if hasattr(x, "data_ptr"):
+            return x.data_ptr(), bool(x.is_cuda)
+        return x.ctypes.data, False
+
+    def in_callback(self, iq, nblocks=None, pitch=None, stream=None):
+        """in_callback() for all channels.  iq: uint8, [nstreams, nblocks*1024*decim*2] (numpy = host,
+        torch cuda tensor = device, asynchronous on `stream`)."""
+        row = K.BLOCK * self.decim * 2
+        if hasattr(iq, "data_ptr"):
+            nbytes_row = iq.shape[-1] if iq.dim() > 1 else iq.numel() // self.nstreams
+            pitch = pitch or (iq.stride(0) if iq.dim() > 1 else nbytes_row)
+        else:
+            iq = np.ascontiguousarray(iq, dtype=np.uint8).reshape(self.nstreams, -1)
+            nbytes_row = iq.shape[1]
+            pitch = pitch or nbytes_row
+        nblocks = nblocks or nbytes_row // row
+        p, dev = self._ptr(iq)
+        if dev:
+            _chk(self.ctx, self.L.acg_process_iq_u8_dev(self.ctx, p, pitch, nblocks, stream))
+        else:
+            _chk(self.ctx, self.L.acg_process_iq_u8_host(self.ctx, p, pitch, nblocks))
+
+    def fir_only(self, iq_dev, nblocks, pitch, stream=None):
+        _chk(self.ctx, self.L.acg_fir_only_dev(self.ctx, iq_dev.data_ptr(), pitch, nblocks, stream))
+
+    def demod_msk(self, dm):
+        """demodMSK() for all channels from 12.5 kHz samples: dm float32 [nch, len]."""
+        dm = np.ascontiguousarray(dm, dtype=np.float32)
+        dm = dm.reshape(self.nch, dm.size // self.nch)
+        _chk(self.ctx, self.L.acg_process_dm_host(self.ctx, dm.ctypes.data, dm.shape[1], dm.shape[1]))
+
+    def sync(self):
+        _chk(self.ctx, self.L.acg_sync(self.ctx))
+
+    # ---- results ------------------------------------------------------------------------
+    def drain_frames(self, max_frames=4096):
+        buf = (K.Frame * max_frames)()
+        n = C.c_int(0)
+        _chk(self.ctx, self.L.acg_drain_frames(self.ctx, buf, max_frames, C.byref(n)))
+        return [buf[i] for i in range(n.value)]
+
+    def bits(self, ch):
+        vo = np.zeros(self.bit_cap, dtype=np.float32)
+        lvl = np.zeros(self.bit_cap, dtype=np.float32)
+        n = C.c_int(0)
+        _chk(self.ctx, self.L.acg_read_bits(self.ctx, ch, vo.ctypes.data, lvl.ctypes.data, self.bit_cap, C.byref(n)))
+        return vo[: n.value].copy(), lvl[: n.value].copy()
+
+    def bits_all(self):
+        counts = np.zeros(self.nch, dtype=np.int32)
+        vo = np.zeros((self.nch, self.bit_cap), dtype=np.float32)
+        lvl = np.zeros((self.nch, self.bit_cap), dtype=np.float32)
+        _chk(self.ctx, self.L.acg_read_bits_all(self.ctx, counts.ctypes.data, vo.ctypes.data, lvl.ctypes.data))
+        return counts, vo, lvl
+
+    def dm(self, ch, n):
+        out = np.zeros(n, dtype=np.float32)
+        _chk(self.ctx, self.L.acg_read_dm(self.ctx, ch, out.ctypes.data, n))
+        return out
+
+    def state(self, ch):
+        s = K.ChanState()
+        _chk(self.ctx, self.L.acg_get_state(self.ctx, ch, C.byref(s)))
+        return dict(MskPhi=s.MskPhi, MskDf=s.MskDf, MskClk=s.MskClk, MskLvlSum=s.MskLvlSum,
+                    MskBitCount=s.MskBitCount, MskS=s.MskS, idx=s.idx,
+                    inb=np.array(s.inb[:], dtype=np.float32), outbits=s.outbits, nbits=s.nbits,
+                    Acarsstate=s.Acarsstate, blk_len=s.blk_len, blk_err=s.blk_err)
+
+    def timing(self):
+        f, m = C.c_double(0), C.c_double(0)
+        nf, nm = C.c_int(0), C.c_int(0)
+        _chk(self.ctx, self.L.acg_get_timing(self.ctx, C.byref(f), C.byref(nf), C.byref(m), C.byref(nm)))
+        return dict(fir_ms=f.value, fir_launches=nf.value, msk_ms=m.value, msk_launches=nm.value)
+
+
+def frame_tuple(f):
+    """(chn, len, err, crc, txt) -- the bit-exact part of a block."""
+    return (int(f.chn), int(f.len), int(f.err), bytes(f.crc), bytes(f.txt[: max(0, f.len)]))

@@ -1,0 +1,154 @@
+/*
+ * acarsdec_amd.h -- C ABI of the MI355X-native acarsdec DSP hot path.
+ *
+ * This is the drop-in boundary: a plain-C shared library (libacarsdec_amd.so) that a C host
+ * (the reference's acarsdec, or any FFI) binds instead of the reference's per-channel DSP
+ *      rtl.c:314-361  in_callback()   u8 I/Q -> NCO mix + decimate -> |D| -> dm_buffer
+ *      msk.c:67-137   demodMSK()      MSK matched filter / bit-clock PLL -> putbit()
+ *      msk.c:53-63    putbit()  ->  acars.c:246-375 decodeAcars()   (framing FSM, fed back into the PLL)
+ * All citations are file:line into TLeconte/acarsdec v3.7.  No torch / C++ types cross this
+ * boundary: pointers, sizes, ints.  Every function returns ACG_OK (0) or a negative ACG_E* code;
+ * nothing throws.  One caller thread per context (same rule as the reference: all DSP runs on the
+ * SDR callback thread, rtl.c:363-364).
+ *
+ * Two layers:
+ *   1. batched API (acg_*): thousands of channels per GPU, state resident in HBM across calls;
+ *   2. legacy view (compat_msk.c, built inside the reference tree): initMsk()/demodMSK() with
+ *      the reference's own signatures (acarsdec.h:190-191) on top of (1), so acars.c/output.c
+ *      link unchanged.  See INTEGRATION.md.
+ */
+#ifndef ACARSDEC_AMD_H
+#define ACARSDEC_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACG_OK          0
+#define ACG_EINVAL     -1   /* bad argument / configuration */
+#define ACG_ENOMEM     -2   /* host or device allocation failed */
+#define ACG_EHIP       -3   /* HIP runtime error (acg_last_error has the text) */
+#define ACG_ENODEV     -4   /* no usable GPU: the library has NO CPU fallback */
+#define ACG_EOVERFLOW  -5   /* an output queue was too small; results truncated */
+#define ACG_ESTATE     -6   /* call sequence error */
+
+#define ACG_INTRATE     12500     /* acarsdec.h:31 */
+#define ACG_BLOCK       1024      /* rtl.c:49 RTLOUTBUFSZ: outputs per reference callback */
+#define ACG_MAXDECIM    320       /* rtl.c:39 RTLMULTMAX */
+#define ACG_FLEN        11        /* msk.c:25 */
+#define ACG_TXTMAX      250       /* acarsdec.h:55 */
+
+/* acg_config.flags */
+#define ACG_F_BITLOG    1u        /* keep per-bit {soft symbol, level} records of each call */
+#define ACG_F_TIMING    2u        /* bracket kernels with HIP events (acg_get_timing) */
+
+typedef struct acg_ctx acg_ctx;
+
+typedef struct {
+	int device;         /* HIP device ordinal */
+	int nch;            /* channels */
+	int nstreams;       /* I/Q streams: nch (one stream per channel) or fewer (rtl.c shape: all
+	                       channels of a dongle share one stream, rtl.c:344-354) */
+	int decim;          /* M = rtlMult (rtl.c:35-37): input rate = 12500*M */
+	int ntaps;          /* complex taps per channel, 1..decim.  Reference: ntaps == decim */
+	int max_blocks;     /* capacity: 1024-output blocks per acg_process_* call */
+	uint32_t flags;
+} acg_config;
+
+/* MSK + framing fields of channel_t (acarsdec.h:76-89) */
+typedef struct {
+	double MskPhi, MskDf, MskLvlSum;
+	float MskClk;
+	int MskBitCount;
+	unsigned int MskS, idx;
+	float inb[2 * ACG_FLEN];      /* re,im interleaved (acarsdec.h:83) */
+	int outbits, nbits, Acarsstate;
+	int blk_len, blk_err;
+} acg_chan_state;
+
+/* A message block as decodeAcars() queues it (msgblk_t, acarsdec.h:48-57; acars.c:350-364):
+ * text still carries parity bits, no repair applied. */
+typedef struct {
+	int chn;
+	int len;
+	int err;
+	float lvl;                    /* 10*log10(MskLvlSum/MskBitCount), acars.c:351 */
+	unsigned char crc[2];
+	unsigned char txt[ACG_TXTMAX];
+	long long end_bit;            /* per-channel index of the bit that completed the block */
+	long long end_sample;         /* per-channel 12.5 kHz sample index of that bit (replaces tv) */
+} acg_frame;
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+int  acg_device_count(void);
+int  acg_create(acg_ctx **out, const acg_config *cfg);
+void acg_destroy(acg_ctx *ctx);
+const char *acg_strerror(int code);
+const char *acg_last_error(const acg_ctx *ctx);
+const char *acg_version(void);
+
+/* ---- channel set-up (host side of rtl.c:268-287) ------------------------------------------ */
+/* rtl.c:131-168 chooseFc(): Fd (Hz) is sorted in place; returns Fc or 0 ("too far apart"). */
+unsigned int acg_rtl_choose_fc(unsigned int *Fd, unsigned int nbch, int decim);
+/* rtl.c:283-286: wf[ind] = cexpf(-j*AMFreq*ind)/rtlMult/127.5, taps_out is [decim][2]. */
+int  acg_rtl_taps(int Fr_hz, unsigned int Fc_hz, int decim, float *taps_out);
+/* taps: [n][ntaps][2] float for channels ch0..ch0+n-1 */
+int  acg_set_taps(acg_ctx *ctx, int ch0, int n, const float *taps);
+/* stream index of every channel; default: channel c reads stream c % nstreams */
+int  acg_set_channel_streams(acg_ctx *ctx, const int *stream_of_channel);
+/* initMsk() (msk.c:30-51) + initAcars() (acars.c:230-234) for all channels */
+int  acg_reset(acg_ctx *ctx);
+
+/* ---- the hot path ------------------------------------------------------------------------- */
+/* in_callback() for every channel: iq is [nstreams] rows of interleaved u8 I,Q, row r at
+ * iq + r*pitch_bytes, each nblocks*1024*decim*2 bytes (rtl.c:330).  *_dev: device pointer,
+ * enqueued on hip_stream (NULL = the context's own stream), asynchronous.  *_host copies first. */
+int  acg_process_iq_u8_dev(acg_ctx *ctx, const uint8_t *iq_dev, size_t pitch_bytes, int nblocks,
+			   void *hip_stream);
+int  acg_process_iq_u8_host(acg_ctx *ctx, const uint8_t *iq_host, size_t pitch_bytes, int nblocks);
+/* demodMSK() for every channel straight from 12.5 kHz samples (soundfile.c:71-77, alsa.c:122):
+ * dm is [nch] rows of `len` floats, row c at dm + c*pitch_floats; len <= max_blocks*1024. */
+int  acg_process_dm_dev(acg_ctx *ctx, const float *dm_dev, size_t pitch_floats, int len,
+			void *hip_stream);
+int  acg_process_dm_host(acg_ctx *ctx, const float *dm_host, size_t pitch_floats, int len);
+/* only the down-converter (rtl.c:332-354), no demodMSK: leaves dm readable by acg_read_dm */
+int  acg_fir_only_dev(acg_ctx *ctx, const uint8_t *iq_dev, size_t pitch_bytes, int nblocks,
+		      void *hip_stream);
+int  acg_sync(acg_ctx *ctx);
+
+/* ---- results ------------------------------------------------------------------------------ */
+/* Blocks completed since the last drain, ordered by (chn, end_bit).  Synchronises. */
+int  acg_drain_frames(acg_ctx *ctx, acg_frame *out, int max_frames, int *nframes);
+/* Per-bit records of the LAST process call for one channel (needs ACG_F_BITLOG):
+ * vo = the value putbit() receives (msk.c:122-126), lvl = cabsf(v) (msk.c:110). */
+int  acg_read_bits(acg_ctx *ctx, int ch, float *vo, float *lvl, int max_bits, int *nbits);
+/* all channels at once: counts[nch], vo/lvl [nch][cap] with cap = acg_bit_capacity() */
+int  acg_read_bits_all(acg_ctx *ctx, int *counts, float *vo, float *lvl);
+int  acg_bit_capacity(const acg_ctx *ctx);
+/* dm_buffer of the last call (rtl.c:353), n floats of channel ch */
+int  acg_read_dm(acg_ctx *ctx, int ch, float *dm, int n);
+int  acg_get_state(acg_ctx *ctx, int ch, acg_chan_state *st);
+int  acg_set_state(acg_ctx *ctx, int ch, const acg_chan_state *st);
+
+/* Replays the bit records of the last call through a putbit()-shaped sink, channel by channel
+ * in channel order: for every bit sink(user, ch, vo, lvl).  The legacy shim's sink performs
+ * msk.c:112-113 + putbit() on the caller's channel_t, i.e. calls the UNCHANGED decodeAcars(). */
+typedef void (*acg_bit_sink)(void *user, int ch, float vo, float lvl);
+int  acg_replay_bits(acg_ctx *ctx, acg_bit_sink sink, void *user);
+
+/* ---- measurement -------------------------------------------------------------------------- */
+/* Sums of HIP-event-bracketed kernel time since the last call (ACG_F_TIMING), in ms, and the
+ * number of launches they cover.  Synchronises. */
+int  acg_get_timing(acg_ctx *ctx, double *fir_ms, int *fir_launches, double *msk_ms, int *msk_launches);
+/* device-side generator for large synthetic workloads: fills [nstreams] rows with seeded
+ * uniform bytes */
+int  acg_fill_random_u8_dev(uint8_t *dev, size_t pitch_bytes, int nrows, size_t row_bytes,
+			    uint64_t seed, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACARSDEC_AMD_H */

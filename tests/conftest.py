@@ -1,0 +1,69 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def has_gpu():
+    try:
+        from acarsdec_amd import _capi as K
+        return K.load().acg_device_count() > 0
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def golden():
+    with open(os.path.join(GOLDEN, "testwav_golden.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def testwav():
+    """test.wav as float32 [frames, 4] exactly as sf_read_float delivers it (x/32768)."""
+    z = np.load(os.path.join(GOLDEN, "testwav_pcm16.npz"))
+    pcm = z["pcm"]
+    return (pcm.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+
+
+@pytest.fixture(scope="session")
+def golden_bits():
+    z = np.load(os.path.join(GOLDEN, "testwav_bits.npz"))
+    return {k: z[k] for k in z.files}
+
+
+def fhex(s):
+    return float.fromhex(s)
+
+
+def golden_blocks(lst):
+    """[(chn,len,err,crc,txt)] + levels from a fixture list"""
+    out = []
+    for b in lst:
+        out.append(((b["chn"], b["len"], b["err"], bytes.fromhex(b["crc"]), bytes.fromhex(b["txt"])),
+                    np.float32(fhex(b["lvl"]))))
+    return out
+
+
+def soft_from_v(vr, vi, MskS):
+    """msk.c:110-126 applied to logged matched-filter outputs: returns (signed vo, lvl) float32."""
+    vr = vr.astype(np.float32)
+    vi = vi.astype(np.float32)
+    lvl = np.sqrt(vr.astype(np.float64) ** 2 + vi.astype(np.float64) ** 2).astype(np.float32)
+    d = lvl.astype(np.float64) + 1e-8
+    nr = (vr.astype(np.float64) / d).astype(np.float32)
+    ni = (vi.astype(np.float64) / d).astype(np.float32)
+    vo = np.where(MskS & 1, ni, nr)
+    vo = np.where(MskS & 2, -vo, vo).astype(np.float32)
+    return vo, lvl

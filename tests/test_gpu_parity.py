@@ -1,0 +1,331 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the committed golden
+fixtures.  Runs on the GPU box only (-m gpu); /root/reference does not exist there.
+
+Stated tolerances:
+  * blocks (chn, len, err, crc, txt): bit-exact, per channel in order;
+  * dm (|D| after the down-converter): |gpu - oracle| <= 1e-5*|oracle| + 1e-6  (f32 sums of up to
+    320 products in a different association; the reference's own -Ofast build reassociates too);
+  * soft symbols: hard decisions identical wherever |vo| > 0.05; |d vo| <= 1e-4 for >= 99 % of bits
+    and <= 5e-2 for all (the reference's own -O2 vs -Ofast builds differ by up to 1.4e-2 on isolated
+    bits because `o=(int)(12*(MskClk/s+0.5))`, msk.c:103, truncates);
+  * level: within 0.05 dB.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import golden_blocks, soft_from_v, fhex, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def D():
+    from acarsdec_amd import decoder
+    from acarsdec_amd import _capi as K
+    assert K.load().acg_device_count() > 0, "GPU tests need a GPU; the library has no CPU fallback"
+    return decoder
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def S():
+    from acarsdec_amd import synth
+    return synth
+
+
+def assert_soft_close(vo_g, vo_o, lvl_g=None, lvl_o=None):
+    assert len(vo_g) == len(vo_o)
+    d = np.abs(vo_g - vo_o)
+    strong = np.abs(vo_o) > 0.05
+    assert np.array_equal(vo_g[strong] > 0, vo_o[strong] > 0), "hard decision flipped on a strong bit"
+    assert d.max() <= 5e-2, d.max()
+    assert (d <= 1e-4).mean() >= 0.99, (d <= 1e-4).mean()
+    if lvl_g is not None:
+        assert np.allclose(lvl_g, lvl_o, rtol=1e-4, atol=1e-6)
+
+
+def blocks_by_channel(frames, tup):
+    out = {}
+    for f in frames:
+        out.setdefault(int(f.chn), []).append(tup(f))
+    return out
+
+
+# ------------------------------------------------------------------------------------ FIR stage
+@pytest.mark.parametrize("M,ntaps,nblk", [(160, 160, 2), (200, 200, 1), (192, 192, 1), (200, 192, 1),
+                                          (320, 320, 1), (8, 8, 1), (164, 164, 1), (160, 37, 1)])
+def test_fir_matches_oracle(D, O, M, ntaps, nblk):
+    rng = np.random.default_rng(M * 1000 + ntaps)
+    nch = 5
+    nout = nblk * 1024
+    iq = rng.integers(0, 256, size=(nch, nout * M * 2), dtype=np.uint8)
+    # include the extremes of the u8 range
+    iq[0, :64] = 0
+    iq[1, :64] = 255
+    taps = (rng.normal(size=(nch, ntaps, 2)) / M / 127.5).astype(np.float32)
+    if ntaps == M and M % 8 == 0:
+        taps[0] = O.rtl_taps(131525000, 131850000, M)[:ntaps]
+    dec = D.Decoder(nch, decim=M, ntaps=ntaps, max_blocks=nblk)
+    dec.set_taps(taps)
+    dec.in_callback(iq)
+    for c in range(nch):
+        want = O.fir_u8(iq[c], M, taps[c], nout=nout, ntaps=ntaps)
+        got = dec.dm(c, nout)
+        assert np.all(np.abs(got - want) <= 1e-5 * np.abs(want) + 1e-6), (c, np.abs(got - want).max())
+    dec.close()
+
+
+def test_fir_shared_stream_and_stream_map(D, O):
+    """rtl.c shape: several channels read ONE stream; and an explicit channel->stream map."""
+    rng = np.random.default_rng(5)
+    M, nch = 160, 6
+    iq = rng.integers(0, 256, size=(2, 1024 * M * 2), dtype=np.uint8)
+    taps = np.stack([O.rtl_taps(131525000 + 25000 * c, 131850000, M) for c in range(nch)])
+    dec = D.Decoder(nch, decim=M, nstreams=2, max_blocks=1)
+    dec.set_taps(taps)
+    smap = [0, 1, 1, 0, 1, 0]
+    dec.set_channel_streams(smap)
+    dec.in_callback(iq)
+    for c in range(nch):
+        want = O.fir_u8(iq[smap[c]], M, taps[c])
+        got = dec.dm(c, 1024)
+        assert np.all(np.abs(got - want) <= 1e-5 * np.abs(want) + 1e-6)
+    dec.close()
+
+
+# ------------------------------------------------------------------------------------ MSK stage on test.wav
+def run_wav(D, x, chunk):
+    nch = x.shape[1]
+    dec = D.Decoder(nch, decim=8, ntaps=8, max_blocks=(chunk + 1023) // 1024)
+    frames, vo, lvl = [], [[] for _ in range(nch)], [[] for _ in range(nch)]
+    for s in range(0, x.shape[0], chunk):
+        dec.demod_msk(np.ascontiguousarray(x[s:s + chunk].T))
+        frames += dec.drain_frames()
+        for c in range(nch):
+            a, b = dec.bits(c)
+            vo[c].append(a)
+            lvl[c].append(b)
+    st = [dec.state(c) for c in range(nch)]
+    dec.close()
+    return frames, [np.concatenate(v) for v in vo], [np.concatenate(v) for v in lvl], st
+
+
+@pytest.mark.parametrize("chunk", [4096, 1024, 1000, 53843])
+def test_testwav_blocks_bits_state(D, testwav, golden, golden_bits, chunk):
+    """config 1: the reference's only data fixture; 7 blocks, bit-exact, any chunking."""
+    if chunk > 8192:
+        chunk = ((testwav.shape[0] + 1023) // 1024) * 1024
+    frames, vo, lvl, st = run_wav(D, testwav, chunk)
+    gb = golden_blocks(golden["file"]["raw_blocks"])
+    want = {}
+    for t, l in gb:
+        want.setdefault(t[0], []).append((t, l))
+    got = blocks_by_channel(frames, D.frame_tuple)
+    assert sorted(got) == sorted(want)
+    for c in want:
+        assert got[c] == [t for t, _ in want[c]], "blocks differ on channel %d" % c
+    for f in frames:
+        ref_lvl = [l for t, l in gb if t == D.frame_tuple(f)][0]
+        assert abs(f.lvl - ref_lvl) < 0.05
+    for c in range(4):
+        m = golden_bits["chn"] == c
+        vo_o, lvl_o = soft_from_v(golden_bits["vr"][m], golden_bits["vi"][m], golden_bits["MskS"][m])
+        assert len(vo[c]) == golden["file"]["bits_per_channel"][c]
+        assert_soft_close(vo[c], vo_o, lvl[c], lvl_o)
+        g = golden["file"]["final_state"][c]
+        assert st[c]["MskS"] == g["MskS"] and st[c]["idx"] == g["idx"]
+        assert st[c]["nbits"] == g["nbits"] and st[c]["Acarsstate"] == g["Acarsstate"]
+        assert st[c]["outbits"] == g["outbits"] and st[c]["MskBitCount"] == g["MskBitCount"]
+        assert abs(st[c]["MskDf"] - fhex(g["MskDf"])) < 1e-6
+        assert abs(st[c]["MskClk"] - fhex(g["MskClk"])) < 1e-3
+        assert abs(st[c]["MskPhi"] - fhex(g["MskPhi"])) < 1e-3
+
+
+def test_msk_matches_oracle_noise_and_silence(D, O):
+    """noise-only (the FSM reset path fires ~19x/s), exact silence (v == 0 -> vo == 0) and a
+    saturated level, against the oracle run live."""
+    rng = np.random.default_rng(11)
+    n = 8192
+    x = np.zeros((4, n), dtype=np.float32)
+    x[0] = rng.normal(0.3, 0.1, n)
+    x[1] = 0.0
+    x[2] = 1.42
+    x[3] = np.abs(rng.normal(0, 1e-3, n))
+    dec = D.Decoder(4, decim=8, ntaps=8, max_blocks=8)
+    dec.demod_msk(x)
+    for c in range(4):
+        ch = O.Channel(c, max_bits=4096)
+        ch.demod(x[c])
+        vo_o, lvl_o = ch.bits
+        vo_g, lvl_g = dec.bits(c)
+        if c == 1:
+            assert np.all(vo_g == 0) and np.all(lvl_g == 0) and len(vo_g) == len(vo_o)
+        else:
+            assert_soft_close(vo_g, vo_o, lvl_g, lvl_o)
+        s, o = dec.state(c), ch.state()
+        for k in ("MskS", "idx", "nbits", "Acarsstate", "outbits", "MskBitCount"):
+            assert s[k] == o[k], (c, k, s[k], o[k])
+    dec.close()
+
+
+def test_msk_ragged_and_empty_lengths(D, O):
+    """lengths that are not multiples of anything, including 0 and 1; state carries across calls."""
+    rng = np.random.default_rng(3)
+    from acarsdec_amd import synth as S
+    a, _ = S.channel_audio(rng, 30000, nframes=3, gap=(3000, 5000), text_len=(5, 60))
+    e = S.envelope(a, noise=0.01, rng=rng)
+    dec = D.Decoder(1, decim=8, ntaps=8, max_blocks=8)
+    ch = O.Channel(0, max_bits=8000)
+    pos, got = 0, []
+    for ln in [0, 1, 7, 1023, 1025, 4096, 5, 0, 8192, 3333]:
+        seg = e[pos:pos + ln]
+        pos += ln
+        dec.demod_msk(seg.reshape(1, -1))
+        got += dec.drain_frames()
+        ch.demod(seg)
+    seg = e[pos:pos + 8000]
+    dec.demod_msk(seg.reshape(1, -1))
+    got += dec.drain_frames()
+    ch.demod(seg)
+    assert [D.frame_tuple(f) for f in got] == [O.frame_tuple(f) for f in ch.frames]
+    assert len(got) >= 2
+    s, o = dec.state(0), ch.state()
+    for k in ("MskS", "idx", "nbits", "Acarsstate", "outbits", "MskBitCount"):
+        assert s[k] == o[k]
+    dec.close()
+
+
+# ------------------------------------------------------------------------------------ config 2: 8 channels, 2.0 Msps
+def _config2(S, testwav, fc, offsets, phases):
+    env = S.pad_blocks(0.5 + 0.5 * testwav.T.astype(np.float64), 1024, 0.5)
+    env8 = np.concatenate([env, env[::-1]])          # 4 wav channels used twice
+    return env8
+
+
+def test_config2_shared_stream_8ch(D, O, S, testwav):
+    """8 channels on ONE 2.0 Msps stream (the rtl.c shape), blocks bit-exact vs the oracle."""
+    M = 160
+    freqs = ["131.525", "131.725", "131.825", "131.550", "131.450", "131.475", "131.650", "131.125"]
+    dec = D.Decoder(8, decim=M, nstreams=1, max_blocks=53)
+    fc = dec.init_rtl(freqs)
+    fr = [D.parse_freq_mhz(f) for f in freqs]
+    assert fc == O.choose_fc(fr, M)
+    env8 = _config2(S, testwav, fc, None, None)
+    iq = S.iq_u8_from_envelopes(env8, M, [f - fc for f in fr], phases=np.linspace(0.1, 5.0, 8), scale=0.12)
+    dec.in_callback(iq.reshape(1, -1))
+    got = blocks_by_channel(dec.drain_frames(), D.frame_tuple)
+    total = 0
+    for c in range(8):
+        ch = O.Channel(c, max_bits=12000)
+        dm_o = O.fir_u8(iq, M, O.rtl_taps(fr[c], fc, M))
+        dm_g = dec.dm(c, dm_o.size)
+        assert np.all(np.abs(dm_g - dm_o) <= 1e-5 * np.abs(dm_o) + 1e-6)
+        ch.demod(dm_o)
+        assert got.get(c, []) == [O.frame_tuple(f) for f in ch.frames], "channel %d" % c
+        total += len(ch.frames)
+        # soft symbols: the MSK stage in isolation, i.e. the oracle demodulator fed the GPU's own dm
+        # (between blocks dm is u8 quantisation noise ~1e-3, where the 1e-5-relative dm differences of
+        # the two summation orders legitimately decorrelate the free-running PLLs)
+        ch2 = O.Channel(c, max_bits=12000)
+        ch2.demod(dm_g)
+        assert [O.frame_tuple(f) for f in ch2.frames] == [O.frame_tuple(f) for f in ch.frames]
+        vo_g, lvl_g = dec.bits(c)
+        vo_o, lvl_o = ch2.bits
+        assert_soft_close(vo_g, vo_o, lvl_g, lvl_o)
+    assert total == 14       # the 7 blocks of test.wav, twice
+
+
+def test_config2_one_stream_per_channel(D, O, S, testwav):
+    """8 independent 2.0 Msps streams, one channel each (the roofline-relevant shape)."""
+    M = 160
+    env8 = _config2(S, testwav, None, None, None)
+    nblk = 6
+    off = [-325000, -300000, 75000, 150000, -50000, 25000, 400000, -475000]
+    iq = np.stack([S.iq_u8_from_envelopes(env8[c:c + 1, 40 * 1024:(40 + nblk) * 1024], M, [off[c]], phases=[0.3 * c])
+                   for c in range(8)])
+    taps = np.stack([D.rtl_taps(131850000 + off[c], 131850000, M) for c in range(8)])
+    dec = D.Decoder(8, decim=M, max_blocks=nblk)
+    dec.set_taps(taps)
+    dec.in_callback(iq)
+    got = blocks_by_channel(dec.drain_frames(), D.frame_tuple)
+    for c in range(8):
+        ch = O.Channel(c)
+        ch.demod(O.fir_u8(iq[c], M, taps[c]))
+        assert got.get(c, []) == [O.frame_tuple(f) for f in ch.frames]
+    dec.close()
+
+
+# ------------------------------------------------------------------------------------ many channels, synthetic MSK
+def test_many_channels_synthetic_msk(D, O, S):
+    """96 independent noisy MSK channels at 12.5 kHz: every block bit-exact vs the oracle."""
+    rng = np.random.default_rng(2024)
+    nch, n = 96, 8 * 1024
+    x = np.zeros((nch, n), dtype=np.float32)
+    for c in range(nch):
+        a, _ = S.channel_audio(rng, n, gap=(1500, 3000), text_len=(5, 40))
+        x[c] = S.envelope(a, depth=0.5, carrier=0.1 + 0.4 * rng.random(), noise=0.004, rng=rng)
+    dec = D.Decoder(nch, decim=8, ntaps=8, max_blocks=8)
+    dec.demod_msk(x[:, :5000])
+    fr = dec.drain_frames()
+    dec.demod_msk(x[:, 5000:])
+    fr += dec.drain_frames()
+    got = blocks_by_channel(fr, D.frame_tuple)
+    nblocks = 0
+    for c in range(nch):
+        ch = O.Channel(c)
+        ch.demod(x[c])
+        assert got.get(c, []) == [O.frame_tuple(f) for f in ch.frames], "channel %d" % c
+        nblocks += len(ch.frames)
+        for f in ch.frames:
+            assert O.lib().orc_frame_check(f) == 0
+    assert nblocks >= nch
+    dec.close()
+
+
+# ------------------------------------------------------------------------------------ the legacy call surface
+def test_compat_program_output_is_golden(golden, tmp_path):
+    """The reference's UNCHANGED acarsdec.c/acars.c/output.c linked against compat_msk.c
+    (initMsk/demodMSK on the GPU): `acarsdec -o 1 -f test.wav` prints the golden text."""
+    exe = os.path.join(ROOT, "acarsdec_amd", "lib", "acarsdec_gpu")
+    if not os.path.exists(exe):
+        pytest.skip("demo binary not built (needs the reference tree at build time)")
+    import hashlib
+    import struct
+    z = np.load(os.path.join(ROOT, "tests", "golden", "testwav_pcm16.npz"))
+    pcm = z["pcm"].astype("<i2")
+    wav = tmp_path / "t.wav"
+    data = pcm.tobytes()
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVE" + b"fmt " + struct.pack(
+        "<IHHIIHH", 16, 1, pcm.shape[1], 12500, 12500 * 2 * pcm.shape[1], 2 * pcm.shape[1], 16) + b"data" + struct.pack("<I", len(data))
+    wav.write_bytes(hdr + data)
+    for o in ("1", "2", "4"):
+        r = subprocess.run([exe, "-o", o, "-f", str(wav)], capture_output=True, timeout=300)
+        assert hashlib.md5(r.stdout).hexdigest() == golden["program"]["o" + o]["md5"], r.stdout.decode("latin-1") + r.stderr.decode("latin-1")
+
+
+def test_replay_sink_matches_device_blocks(D, O, testwav):
+    """acg_replay_bits hands every bit to a putbit()-shaped sink; feeding an oracle FSM from it
+    yields the same blocks the device assembled."""
+    from acarsdec_amd import _capi as K
+    x = np.ascontiguousarray(testwav[:16384].T)
+    dec = D.Decoder(4, decim=8, ntaps=8, max_blocks=16)
+    dec.demod_msk(x)
+    seen = [[] for _ in range(4)]
+
+    def sink(user, ch, vo, lvl):
+        seen[ch].append((vo, lvl))
+    cb = K.BIT_SINK(sink)
+    assert dec.L.acg_replay_bits(dec.ctx, cb, None) == 0
+    for c in range(4):
+        vo, lvl = dec.bits(c)
+        assert np.array_equal(np.array([v for v, _ in seen[c]], dtype=np.float32), vo)
+        assert np.array_equal(np.array([l for _, l in seen[c]], dtype=np.float32), lvl)
+    dec.close()

@@ -1,0 +1,92 @@
+"""Host-side logic and the C-ABI surface, CPU only: the library loads without a GPU, exports
+every symbol the public header declares, refuses to run without a GPU, and its host set-up
+arithmetic (taps, centre frequency, filter prototype) equals the oracle's bit for bit."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, has_gpu
+from acarsdec_amd import _capi as K, decoder as D, synth as S
+from oracle import oracle as O
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "acarsdec_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(acg_[a-z0-9_]+)\s*\(", txt)) - {"acg_bit_sink"})
+
+
+def test_library_exports_every_declared_symbol():
+    L = K.load()
+    names = header_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(L, n), "missing export: " + n
+    assert set(names) == set(K.SYMBOLS), set(names) ^ set(K.SYMBOLS)
+    assert b"gfx950" in L.acg_version()
+    assert L.acg_strerror(K.ENODEV).startswith(b"no GPU")
+
+
+@pytest.mark.skipif(has_gpu(), reason="only meaningful on a box without a GPU")
+def test_no_gpu_means_loud_failure_not_fallback():
+    with pytest.raises(K.AcgError) as e:
+        D.Decoder(4)
+    assert e.value.code == K.ENODEV
+
+
+def test_create_rejects_bad_configs():
+    L = K.load()
+    ctx = C.c_void_p()
+    for cfg in (K.Config(0, 0, 1, 160, 160, 1, 0), K.Config(0, 4, 5, 160, 160, 1, 0), K.Config(0, 4, 4, 321, 321, 1, 0),
+                K.Config(0, 4, 4, 160, 161, 1, 0), K.Config(0, 4, 4, 160, 160, 0, 0)):
+        assert L.acg_create(C.byref(ctx), C.byref(cfg)) == K.EINVAL
+    assert L.acg_create(None, None) == K.EINVAL
+
+
+@pytest.mark.parametrize("M", [160, 192, 200, 320, 37])
+def test_rtl_taps_equal_oracle(M):
+    for fr, fc in ((131525000, 131850000), (131825000, 131850000), (129125000, 130100000)):
+        assert np.array_equal(D.rtl_taps(fr, fc, M), O.rtl_taps(fr, fc, M))
+
+
+def test_choose_fc_equals_oracle_random_sets():
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        n = int(rng.integers(1, 9))
+        base = 118000000 + int(rng.integers(0, 1500)) * 12500
+        fr = sorted(set(base + int(k) * 12500 for k in rng.integers(0, 150, size=n)))
+        M = int(rng.choice([160, 192, 200]))
+        fc, srt = D.choose_fc(fr, M)
+        assert fc == O.choose_fc(fr, M)
+        assert list(srt) == sorted(fr)
+
+
+def test_parse_freq_rounds_to_raster():
+    assert D.parse_freq_mhz("131.525") == 131525000
+    assert D.parse_freq_mhz("131.5251") == 131525000
+    assert D.parse_freq_mhz("131.53") == 131525000 + 0 * 12500 or D.parse_freq_mhz("131.53") % 12500 == 0
+
+
+def test_modulator_round_trips_through_oracle():
+    """the synthetic ACARS/MSK generator is only trusted because the oracle decodes it clean
+    (the demodulator misses the sync of a few percent of transmissions; none may decode wrong)"""
+    rng = np.random.default_rng(42)
+    a, sent = S.channel_audio(rng, 120000, gap=(2000, 5000))
+    ch = O.Channel(0)
+    ch.demod(S.envelope(a, noise=0.01, rng=rng))
+    bodies = {raw[5:-3]: raw for raw in sent}           # after SOH, before CRC + DEL
+    assert len(sent) >= 6 and len(ch.frames) >= 0.7 * len(sent)
+    for f in ch.frames:
+        assert O.lib().orc_frame_check(f) == 0 and f.err == 0
+        raw = bodies[bytes(f.txt[: f.len])]
+        assert bytes(f.crc) == raw[-3:-1]
+
+
+def test_iq_upconverter_shape_and_range():
+    env = np.full((2, 1024), 0.5)
+    iq = S.iq_u8_from_envelopes(env, 160, [-50000.0, 75000.0])
+    assert iq.dtype == np.uint8 and iq.size == 1024 * 160 * 2
+    assert 90 < iq.min() < iq.max() < 165

@@ -1,0 +1,120 @@
+"""Pins the C restatement to the UNMODIFIED reference (oracle/_ref, built from /root/reference by
+oracle/Makefile) run live on fresh inputs.  CPU only; skipped where no _ref build exists.
+The reference is global state, so every scenario runs in a child process."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from oracle import oracle as O
+
+pytestmark = pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built (no reference tree)")
+
+CHILD = r'''
+import sys, json
+import numpy as np
+sys.path.insert(0, %(root)r)
+from oracle import oracle as O
+from acarsdec_amd import synth as S
+mode, seed = sys.argv[1], int(sys.argv[2])
+rng = np.random.default_rng(seed)
+res = dict(ok=True, why=[])
+def cmp_state(a, b, tag):
+    for k in a:
+        if not np.array_equal(np.asarray(a[k]), np.asarray(b[k])):
+            res["ok"] = False; res["why"].append("%%s %%s %%r %%r" %% (tag, k, a[k], b[k]))
+def tup(f): return [int(f.chn), int(f.len), int(f.err), bytes(f.crc).hex(), bytes(f.txt[:f.len]).hex(), float(f.lvl).hex()]
+ref = O.Ref()
+if mode == "msk":
+    nch, n = 3, 20000
+    x = np.zeros((nch, n), dtype=np.float32)
+    a, _ = S.channel_audio(rng, n, gap=(2000, 4000), text_len=(5, 80))
+    x[0] = S.envelope(a, noise=0.02, rng=rng)
+    x[1] = rng.normal(0.2, 0.2, n)                     # pure noise: exercises the reset path
+    x[2, 5000:] = S.envelope(a[:n-5000], carrier=0.9, noise=0.0)
+    ref.init_file(nch)
+    chs = [O.Channel(c) for c in range(nch)]
+    for s in range(0, n, 4096):
+        for c in range(nch):
+            ref.demod(c, x[c, s:s+4096]); chs[c].demod(x[c, s:s+4096])
+    for c in range(nch): cmp_state(ref.state(c), chs[c].state(), "ch%%d" %% c)
+    rf = sorted(tup(f) for f in ref.raw_frames()); of = sorted(tup(f) for c in chs for f in c.frames)
+    if rf != of: res["ok"] = False; res["why"].append("frames %%d vs %%d" %% (len(rf), len(of)))
+    res["nframes"] = len(rf)
+else:
+    M = int(mode)
+    freqs = ["131.525", "131.725", "131.825"]
+    fc = ref.init_rtl(freqs, M)
+    fr = [int(round(float(f) * 1e6)) for f in freqs]
+    if O.choose_fc(fr, M) != fc: res["ok"] = False; res["why"].append("Fc")
+    nblk = 3
+    env = []
+    for c in range(3):
+        a, _ = S.channel_audio(rng, nblk * 1024, nframes=1, gap=(300, 600), text_len=(5, 20))
+        env.append(0.5 * (1 + 0.5 * a))
+    iq = S.iq_u8_from_envelopes(np.array(env), M, [f - fc for f in fr], phases=[0.2, 1.0, 4.0], noise=0.01, rng=rng)
+    taps = [O.rtl_taps(fr[c], fc, M) for c in range(3)]
+    for c in range(3):
+        f, wf = ref.wf(c)
+        if not np.array_equal(wf, taps[c]): res["ok"] = False; res["why"].append("taps%%d" %% c)
+    chs = [O.Channel(c) for c in range(3)]
+    blk = 1024 * M * 2
+    for b in range(nblk):
+        buf = iq[b*blk:(b+1)*blk]
+        ref.in_callback(buf)
+        for c in range(3):
+            dm = O.fir_u8(buf, M, taps[c])
+            if not np.array_equal(dm, ref.dm(c)): res["ok"] = False; res["why"].append("dm b%%d c%%d" %% (b, c))
+            chs[c].demod(dm)
+    for c in range(3): cmp_state(ref.state(c), chs[c].state(), "ch%%d" %% c)
+    rf = sorted(tup(f) for f in ref.raw_frames()); of = sorted(tup(f) for c in chs for f in c.frames)
+    if rf != of: res["ok"] = False; res["why"].append("frames")
+    res["nframes"] = len(rf)
+print(json.dumps(res))
+'''
+
+
+def run_child(mode, seed):
+    r = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT), mode, str(seed)], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_msk_and_framing_bit_identical_to_reference(seed):
+    res = run_child("msk", seed)
+    assert res["ok"], res["why"]
+    assert res["nframes"] >= 2
+
+
+@pytest.mark.parametrize("M", [160, 192, 200])
+def test_rtl_front_end_bit_identical_to_reference(M):
+    res = run_child(str(M), 10 + M)
+    assert res["ok"], res["why"]
+    assert res["nframes"] >= 3
+
+
+def test_choose_fc_matches_reference_on_hard_sets():
+    """chooseFc edge cases (mirror-image rejection makes Fc walk in 1 Hz steps, rtl.c:160)."""
+    code = r'''
+import sys, json; sys.path.insert(0, %r)
+from oracle import oracle as O
+ref = O.Ref(); sets = json.loads(sys.argv[1]); out = []
+for s in sets:
+    try: out.append(int(ref.init_rtl(s, 160)))
+    except RuntimeError: out.append(0)
+print(json.dumps(out))
+''' % ROOT
+    sets = [["131.550"], ["131.525", "131.550"], ["130.025", "131.825"], ["131.125", "131.450", "131.475", "131.525", "131.550", "131.650", "131.725", "131.825"],
+            ["129.125", "131.125"]]
+    r = subprocess.run([sys.executable, "-c", code, json.dumps(sets)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    ref_fc = json.loads(r.stdout.strip().splitlines()[-1])
+    for s, fc in zip(sets, ref_fc):
+        fr = [(int(1000000 * float(f) + 6250) // 12500) * 12500 for f in s]
+        assert O.choose_fc(fr, 160) == fc, (s, fc)
