@@ -26,6 +26,10 @@ struct acg_ctx {
     acg_config cfg{};
     std::string err;
     hipStream_t stream = nullptr;
+    hipStream_t fir_stream = nullptr;   // down-converter chunks run here, ahead of the MSK chunks
+    hipEvent_t in_ev = nullptr;
+    std::vector<hipEvent_t> chunk_ev;
+    int pipe_blocks = 1;            // 1024-output blocks per pipelined chunk (0 = no pipelining)
     bool tile_path = true;          // decim % 8 == 0 -> LDS-tiled kernel
     int ntaps_pad = 0;
     int max_len = 0;                // max_blocks * 1024
@@ -33,6 +37,7 @@ struct acg_ctx {
     int bit_cap = 0;
     unsigned int frame_cap = 0;
     int last_len = 0;               // samples per channel of the last demod call
+    int msk_lpc = 8;                // lanes per channel in the MSK kernel
     bool last_had_demod = false;
 
     float* d_taps = nullptr;
@@ -109,6 +114,9 @@ static void free_all(acg_ctx* c)
     for (auto& p : c->fir_ev) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto& p : c->msk_ev) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : c->ev_pool) hipEventDestroy(e);
+    for (auto e : c->chunk_ev) hipEventDestroy(e);
+    if (c->in_ev) hipEventDestroy(c->in_ev);
+    if (c->fir_stream) hipStreamDestroy(c->fir_stream);
     if (c->stream) hipStreamDestroy(c->stream);
 }
 
@@ -142,11 +150,23 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
     c->bit_cap = c->max_len / 4 + 8;
     // shortest possible block: SYN SYN SOH ETX CRC CRC + END byte = 56 bits ~ 291 samples
     c->frame_cap = (unsigned int)cfg->nch * (unsigned int)(c->max_len / 291 + 2);
+    // MSK kernel shape: the chip has 1024 SIMDs; give every channel as many lanes as keeps the
+    // wave count around one per SIMD (latency mode), down to one lane per channel (throughput mode)
+    c->msk_lpc = cfg->nch <= 8192 ? 8 : cfg->nch <= 16384 ? 4 : cfg->nch <= 32768 ? 2 : 1;
+    if (const char* e = std::getenv("ACG_PIPE_BLOCKS")) c->pipe_blocks = std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("ACG_MSK_LPC")) {
+        const int v = std::atoi(e);
+        if (v == 1 || v == 2 || v == 4 || v == 8) c->msk_lpc = v;
+    }
 
     int rc = ACG_OK;
     auto body = [&]() -> int {
         HIPCHK(c, hipSetDevice(cfg->device));
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->fir_stream, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->in_ev, hipEventDisableTiming));
+        c->chunk_ev.resize((size_t)cfg->max_blocks);
+        for (auto& e : c->chunk_ev) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         const size_t nch = (size_t)cfg->nch;
         HIPCHK(c, hipMalloc(&c->d_taps, nch * c->ntaps_pad * 2 * sizeof(float)));
         HIPCHK(c, hipMemset(c->d_taps, 0, nch * c->ntaps_pad * 2 * sizeof(float)));
@@ -242,15 +262,15 @@ static int get_event(acg_ctx* c, hipEvent_t* e)
     return ACG_OK;
 }
 
-static int launch_fir(acg_ctx* c, const uint8_t* iq_dev, size_t pitch, int nblocks, hipStream_t s)
+static int launch_fir(acg_ctx* c, const uint8_t* iq_dev, size_t pitch, int nblocks, hipStream_t s, int block0 = 0)
 {
     const acg_config& g = c->cfg;
     FirArgs a{};
-    a.iq = iq_dev;
+    a.iq = iq_dev + (size_t)block0 * ACG_BLOCK * g.decim * 2;
     a.pitch = pitch;
     a.stream_of = c->d_stream_of;
     a.taps = c->d_taps;
-    a.dm = c->d_dm;
+    a.dm = c->d_dm + (size_t)block0 * ACG_BLOCK;
     a.dm_pitch = c->dm_pitch;
     a.nch = g.nch;
     a.decim = g.decim;
@@ -289,7 +309,7 @@ static int launch_fir(acg_ctx* c, const uint8_t* iq_dev, size_t pitch, int nbloc
     return ACG_OK;
 }
 
-static int launch_msk(acg_ctx* c, const float* dm_dev, size_t pitch_floats, int len, hipStream_t s)
+static int launch_msk(acg_ctx* c, const float* dm_dev, size_t pitch_floats, int len, hipStream_t s, bool append = false)
 {
     const acg_config& g = c->cfg;
     MskArgs a{};
@@ -306,6 +326,7 @@ static int launch_msk(acg_ctx* c, const float* dm_dev, size_t pitch_floats, int 
     a.bit_cap = c->bit_cap;
     a.nch = g.nch;
     a.len = len;
+    a.bit_append = append ? 1 : 0;
     const bool timing = (g.flags & ACG_F_TIMING) != 0;
     EvPair ev{};
     if (timing) {
@@ -313,7 +334,7 @@ static int launch_msk(acg_ctx* c, const float* dm_dev, size_t pitch_floats, int 
         if ((r = get_event(c, &ev.a)) != ACG_OK || (r = get_event(c, &ev.b)) != ACG_OK) return r;
         HIPCHK(c, hipEventRecord(ev.a, s));
     }
-    const int e = acg_launch_msk(&a, s);
+    const int e = acg_launch_msk(&a, c->msk_lpc, s);
     if (e != 0) {
         c->err = std::string("MSK launch: ") + hipGetErrorString((hipError_t)e);
         return ACG_EHIP;
@@ -353,10 +374,35 @@ extern "C" int acg_fir_only_dev(acg_ctx* ctx, const uint8_t* iq_dev, size_t pitc
 extern "C" int acg_process_iq_u8_dev(acg_ctx* ctx, const uint8_t* iq_dev, size_t pitch_bytes, int nblocks,
                                      void* hip_stream)
 {
-    int r = acg_fir_only_dev(ctx, iq_dev, pitch_bytes, nblocks, hip_stream);
+    int r = check_iq_args(ctx, iq_dev, pitch_bytes, nblocks);
     if (r != ACG_OK) return r;
+    if (ctx->tile_path && (((uintptr_t)iq_dev | pitch_bytes) & 15))
+        return fail(ctx, ACG_EINVAL, "I/Q base and pitch must be 16-byte aligned");
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
-    return launch_msk(ctx, ctx->d_dm, ctx->dm_pitch, nblocks * ACG_BLOCK, s);
+    const int cb = ctx->pipe_blocks;
+    if (cb <= 0 || nblocks <= cb) {
+        r = launch_fir(ctx, iq_dev, pitch_bytes, nblocks, s);
+        if (r != ACG_OK) return r;
+        return launch_msk(ctx, ctx->d_dm, ctx->dm_pitch, nblocks * ACG_BLOCK, s);
+    }
+    // Software pipeline over time: the (bandwidth-bound, wide) down-converter of chunk k+1 runs on
+    // its own stream while the (latency-bound, narrow) demodulator of chunk k runs on the caller's
+    // stream.  Demodulator launches stay in order on one stream: they carry the channel state.
+    HIPCHK(ctx, hipEventRecord(ctx->in_ev, s));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->fir_stream, ctx->in_ev, 0));
+    int k = 0;
+    for (int b0 = 0; b0 < nblocks; b0 += cb, ++k) {
+        const int nb = std::min(cb, nblocks - b0);
+        r = launch_fir(ctx, iq_dev, pitch_bytes, nb, ctx->fir_stream, b0);
+        if (r != ACG_OK) return r;
+        HIPCHK(ctx, hipEventRecord(ctx->chunk_ev[(size_t)k], ctx->fir_stream));
+        HIPCHK(ctx, hipStreamWaitEvent(s, ctx->chunk_ev[(size_t)k], 0));
+        r = launch_msk(ctx, ctx->d_dm + (size_t)b0 * ACG_BLOCK, ctx->dm_pitch, nb * ACG_BLOCK, s, b0 > 0);
+        if (r != ACG_OK) return r;
+    }
+    ctx->last_len = nblocks * ACG_BLOCK;
+    return ACG_OK;
 }
 
 static int ensure_stage(acg_ctx* c, size_t bytes)
@@ -581,6 +627,24 @@ extern "C" int acg_get_timing(acg_ctx* ctx, double* fir_ms, int* fir_launches, d
     int r = sum(ctx->fir_ev, fir_ms, fir_launches);
     if (r != ACG_OK) return r;
     return sum(ctx->msk_ev, msk_ms, msk_launches);
+}
+
+extern "C" int acg_selftest_sincos(const double* x_host, double* sin_host, double* cos_host, int n)
+{
+    if (!x_host || !sin_host || !cos_host || n < 1) return ACG_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return ACG_ENODEV;
+    double *dx = nullptr, *ds = nullptr, *dc = nullptr;
+    const size_t b = (size_t)n * sizeof(double);
+    int rc = ACG_EHIP;
+    if (hipMalloc(&dx, b) == hipSuccess && hipMalloc(&ds, b) == hipSuccess && hipMalloc(&dc, b) == hipSuccess &&
+        hipMemcpy(dx, x_host, b, hipMemcpyHostToDevice) == hipSuccess &&
+        acg_launch_sincos_selftest(dx, ds, dc, n, nullptr) == 0 &&
+        hipMemcpy(sin_host, ds, b, hipMemcpyDeviceToHost) == hipSuccess &&
+        hipMemcpy(cos_host, dc, b, hipMemcpyDeviceToHost) == hipSuccess)
+        rc = ACG_OK;
+    hipFree(dx); hipFree(ds); hipFree(dc);
+    return rc;
 }
 
 extern "C" int acg_fill_random_u8_dev(uint8_t* dev, size_t pitch_bytes, int nrows, size_t row_bytes,

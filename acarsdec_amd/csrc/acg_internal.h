@@ -6,7 +6,7 @@
 
 #define ACG_WG_FIR 256          // FIR workgroup: 4 waves, one 64-window tile, taps split over waves
 #define ACG_TILE_WIN 64         // windows (12.5 kHz outputs) per FIR tile = one per lane
-#define ACG_WG_MSK 64           // MSK workgroup: one wave, one channel per lane
+#define ACG_WG_MSK 64           // MSK workgroup: one wave, 64/LPC channels (LPC lanes per channel)
 
 // Per-channel demodulator + framing state, resident in HBM across calls.
 // Mirrors the MSK/ACARS fields of channel_t (acarsdec.h:76-89) plus bookkeeping.
@@ -75,6 +75,7 @@ struct MskArgs {
     int bit_cap;
     int nch;
     int len;                    // samples per channel this launch
+    int bit_append;             // 0: bit records start at 0; 1: append after nbits_out[ch] (same call)
 };
 
 #ifdef __cplusplus
@@ -84,7 +85,8 @@ extern "C" {
 int acg_launch_fir(const FirArgs* a, void* stream);
 int acg_launch_fir_generic(const FirArgs* a, void* stream);
 size_t acg_fir_lds_bytes(const FirArgs* a);
-int acg_launch_msk(const MskArgs* a, void* stream);
+int acg_launch_msk(const MskArgs* a, int lanes_per_channel, void* stream);
+int acg_launch_sincos_selftest(const double* x, double* s, double* c, int n, void* stream);
 int acg_launch_fill_random(uint8_t* dev, size_t pitch, int nrows, size_t row_bytes, uint64_t seed, void* stream);
 #ifdef __cplusplus
 }

@@ -3,8 +3,9 @@
 //
 // The loop is a strict serial recurrence per channel (the PLL feeds the VCO that produced the
 // sample it is fed from; the framing FSM writes MskDf / MskS back into it, acars.c:242,259,274),
-// so the only parallelism is across channels: one lane per channel, one wave per workgroup,
-// state resident in HBM between launches.  Arithmetic follows the reference's C promotions
+// so the bulk parallelism is across channels (state resident in HBM between launches); inside a
+// channel only the <= 6 mixer evaluations between two bit decisions are independent, and those are
+// spread over LPC lanes (see msk_demod_kernel).  Arithmetic follows the reference's C promotions
 // operation for operation (f64 VCO/PLL, f32 clock and filter, f64 divide): this translation unit
 // is compiled with -ffp-contract=off so no multiply-add is fused that the reference's IEEE build
 // keeps separate.
@@ -53,11 +54,11 @@ __device__ __forceinline__ void reset_acars(Lane& L)          // acars.c:239-244
 }
 
 __device__ __forceinline__ void put_frame(Lane& L, const MskArgs& a, int ch, unsigned char crc1,
-                                          const unsigned char* txt, long long sample_index)
+                                          const unsigned char* txt, long long sample_index, bool leader)
 {
     // acars.c:350-369: queue the block.  lvl = 10*log10(MskLvlSum/MskBitCount) is taken on the host
     // from the two operands (same libm call as the reference).
-    const unsigned int slot = atomicAdd(a.frame_count, 1u);
+    const unsigned int slot = leader ? atomicAdd(a.frame_count, 1u) : 0xffffffffu;
     if (slot < a.frame_cap) {
         AcgFrameRec* f = a.frames + slot;
         f->chn = ch;
@@ -79,7 +80,7 @@ __device__ __forceinline__ void put_frame(Lane& L, const MskArgs& a, int ch, uns
 }
 
 __device__ __forceinline__ void decode_acars(Lane& L, const MskArgs& a, int ch, unsigned char* txt,
-                                             long long sample_index)
+                                             long long sample_index, bool leader)
 {
     const unsigned int r = L.outbits & 0xffu;
     switch (L.astate) {
@@ -106,7 +107,7 @@ __device__ __forceinline__ void decode_acars(Lane& L, const MskArgs& a, int ch, 
         reset_acars(L);
         return;
     case TXT:                                                  // acars.c:303-341
-        txt[L.blen] = (unsigned char)r;
+        if (leader) txt[L.blen] = (unsigned char)r;
         L.blen++;
         if ((__popc(r) & 1) == 0) {
             L.berr++;
@@ -118,7 +119,7 @@ __device__ __forceinline__ void decode_acars(Lane& L, const MskArgs& a, int ch, 
             L.crc0 = txt[L.blen];
             const unsigned char c1 = txt[L.blen + 1];
             L.astate = CRC2;
-            put_frame(L, a, ch, c1, txt, sample_index);
+            put_frame(L, a, ch, c1, txt, sample_index, leader);
             return;
         }
         if (L.blen > 240) { reset_acars(L); return; }
@@ -130,7 +131,7 @@ __device__ __forceinline__ void decode_acars(Lane& L, const MskArgs& a, int ch, 
         L.nbits = 8;
         return;
     case CRC2:                                                 // acars.c:348-369
-        put_frame(L, a, ch, (unsigned char)r, txt, sample_index);
+        put_frame(L, a, ch, (unsigned char)r, txt, sample_index, leader);
         return;
     default:                                                   // END, acars.c:370-373
         reset_acars(L);
@@ -139,15 +140,71 @@ __device__ __forceinline__ void decode_acars(Lane& L, const MskArgs& a, int ch, 
     }
 }
 
+// sin/cos of x in [0, 2*pi) (any moderate |x| works): Cody-Waite reduction by pi/2 with a two-term
+// constant, then the classic minimax kernels on |r| <= pi/4 (coefficients: fdlibm k_sin.c/k_cos.c,
+// Sun Microsystems 1993, freely distributable; < 1 ulp).  The reference calls glibc's cexp (also
+// < 1 ulp, different algorithm): results agree to the last bit except in rare last-place cases,
+// and only the float-rounded product in*cos / in*sin is kept (msk.c:90).
+__device__ __forceinline__ void sincos_2pi(double x, double* sn, double* cs)
+{
+    const double kd = __builtin_rint(x * 6.36619772367581382433e-01);           // x * 2/pi
+    const int q = (int)kd;
+    double r = __builtin_fma(-kd, 1.57079632673412561417e+00, x);               // pi/2, high 33 bits
+    r = __builtin_fma(-kd, 6.07710050650619224932e-11, r);                      // pi/2, tail
+    const double z = r * r;
+    // sin kernel
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                 S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                 S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    double ps = __builtin_fma(z, S6, S5);
+    ps = __builtin_fma(z, ps, S4);
+    ps = __builtin_fma(z, ps, S3);
+    ps = __builtin_fma(z, ps, S2);
+    const double v = z * r;
+    const double s = __builtin_fma(v, __builtin_fma(z, ps, S1), r);
+    // cos kernel
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                 C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                 C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double pc = __builtin_fma(z, C6, C5);
+    pc = __builtin_fma(z, pc, C4);
+    pc = __builtin_fma(z, pc, C3);
+    pc = __builtin_fma(z, pc, C2);
+    pc = __builtin_fma(z, pc, C1);
+    const double hz = 0.5 * z;
+    const double w = 1.0 - hz;
+    const double c = w + (((1.0 - w) - hz) + z * (z * pc));
+    // quadrant
+    const double ss = (q & 1) ? c : s;
+    const double cc = (q & 1) ? s : c;
+    *sn = (q & 2) ? -ss : ss;
+    *cs = ((q + 1) & 2) ? -cc : cc;
+}
+
+// LPC lanes cooperate on one channel ("replicated state machine, distributed sincos"): every lane
+// of a group carries an identical copy of the channel's scalar state and executes the same bit
+// logic, so nothing has to be broadcast; only the expensive per-sample work (f64 sin/cos + mix) of
+// the <= 6 samples between two bit decisions is spread over the group's lanes, and the ring buffer
+// lives in LDS where the whole group reads it back for the matched filter.  The VCO phase and the
+// bit clock of those samples are first advanced sequentially (they are cheap adds and their exact
+// rounding order matters), which also tells how many samples this bit period consumes.
+//   LPC = 8: latency mode (few thousand channels: one sincos per lane per bit)
+//   LPC = 1: throughput mode (tens of thousands of channels: no redundant work)
+template <int LPC>
 __global__ __launch_bounds__(ACG_WG_MSK) void msk_demod_kernel(const MskArgs a)
 {
-    __shared__ float2 ring[FLEN][ACG_WG_MSK];      // inb[] of 64 channels, one column per lane
+    constexpr int CPW = ACG_WG_MSK / LPC;          // channels per wave
+    constexpr int SPL = (6 + LPC - 1) / LPC;       // samples per lane per bit period
+    __shared__ float2 ring[FLEN][CPW];             // inb[] of the wave's channels
     __shared__ float hs[FLEN * MFLTOVER + 1];
 
     const int tid = threadIdx.x;
     for (int i = tid; i < FLEN * MFLTOVER + 1; i += ACG_WG_MSK) hs[i] = a.h[i];
 
-    const int ch = blockIdx.x * ACG_WG_MSK + tid;
+    const int slot = tid / LPC;                    // channel slot inside the wave
+    const int g = tid - slot * LPC;                // lane inside the group
+    const bool leader = g == 0;
+    const int ch = blockIdx.x * CPW + slot;
     const bool active = ch < a.nch;
     const int chc = active ? ch : a.nch - 1;
     AcgChan* st = a.st + chc;
@@ -158,39 +215,118 @@ __global__ __launch_bounds__(ACG_WG_MSK) void msk_demod_kernel(const MskArgs a)
     L.nbits = st->nbits; L.astate = st->astate; L.blen = st->blen; L.berr = st->berr;
     L.outbits = st->outbits; L.crc0 = st->crc0; L.nbit_total = st->nbit_total;
     const long long samp0 = st->nsamp_total;
+    if (leader) {
 #pragma unroll
-    for (int j = 0; j < FLEN; ++j) ring[j][tid] = make_float2(st->inb[2 * j], st->inb[2 * j + 1]);
+        for (int j = 0; j < FLEN; ++j) ring[j][slot] = make_float2(st->inb[2 * j], st->inb[2 * j + 1]);
+    }
     __syncthreads();
 
     const float* __restrict__ dm = a.dm + (size_t)chc * a.dm_pitch;
     unsigned char* txt = a.txt + (size_t)chc * 256;
-    float2* bits = a.bits ? a.bits + (size_t)chc * a.bit_cap : nullptr;
+    float2* bits = (a.bits && leader) ? a.bits + (size_t)chc * a.bit_cap : nullptr;
     const int len = active ? a.len : 0;
-    int nb = 0;
+    int nb = (a.bit_append && active) ? a.nbits_out[ch] : 0;
     int n = 0;
     unsigned int idx = L.idx;
     double p = L.phi;
 
-    while (n < len) {
+    // dm samples of the coming bit period, one load ahead of their use (the load latency hides
+    // under the previous bit's decision logic): lane g holds dm[n + g + j*LPC]
+    float in_cur[SPL];
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) in_cur[j] = (g + j * LPC < len) ? dm[g + j * LPC] : 0.f;
+
+    __builtin_amdgcn_s_setprio(3);        // latency-bound serial chain: win issue arbitration
+
+    while (__any(n < len)) {
+        // ---- A: advance VCO phase and bit clock over this bit period (replicated, sequential)
+        const double s = K_VCO + L.df;                                     // msk.c:81
+        const double thr = K_3PI2 - s / 2;                                 // msk.c:96
+        double myp[SPL];
+        int cnt = 0;
         bool fired = false;
-        double s = 0;
-#pragma unroll 1
-        for (int u = 0; u < 6 && !fired && n < len; ++u) {
-            // VCO, msk.c:81-83
-            s = K_VCO + L.df;
-            p += s;
-            if (p >= K_TWOPI) p -= K_TWOPI;
-            // mixer, msk.c:86-91: in * cexp(-j p) in double, narrowed to float complex
-            double sn, cs;
-            sincos(p, &sn, &cs);
-            const double in = (double)dm[n];
-            ring[idx][tid] = make_float2((float)(in * cs), (float)(in * (-sn)));
-            idx = (idx + 1 == FLEN) ? 0 : idx + 1;
-            // bit clock, msk.c:95-96
-            L.clk = (float)((double)L.clk + s);
-            ++n;
-            fired = (double)L.clk >= K_3PI2 - s / 2;
+        // Common case first: a bit period is 5 or 6 samples (the clock advances ~0.905 rad per
+        // sample from within +-s/2 of zero to 3pi/2 - s/2), so the first four steps neither fire
+        // nor hit the end of the buffer.  With s > 0 the clock is monotonic, so "none of the first
+        // four fired" is decided by the fourth value alone.  Same operations, same order, fewer
+        // predicated instructions; anything unusual takes the general loop below.
+        double p4 = p;
+        float c4 = L.clk;
+        double pq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            p4 += s;
+            if (p4 >= K_TWOPI) p4 -= K_TWOPI;
+            c4 = (float)((double)c4 + s);
+            pq[u] = p4;
         }
+        const bool quick = (s > 0) && !((double)c4 >= thr) && (n + 4 <= len);
+        if (__all(quick || n >= len)) {
+            if (n < len) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if ((u % LPC) == g) myp[u / LPC] = pq[u];
+                p = p4;
+                L.clk = c4;
+                cnt = 4;
+#pragma unroll
+                for (int u = 4; u < 6; ++u) {
+                    const bool go = !fired && (n + u < len);
+                    double pn = p + s;                                     // msk.c:82-83
+                    if (pn >= K_TWOPI) pn -= K_TWOPI;
+                    const float cn = (float)((double)L.clk + s);           // msk.c:95
+                    if (go) {
+                        p = pn;
+                        L.clk = cn;
+                        cnt = u + 1;
+                        fired = (double)cn >= thr;
+                    }
+                    if ((u % LPC) == g) myp[u / LPC] = pn;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                const bool go = !fired && (n + u < len);
+                double pn = p + s;                                         // msk.c:82-83
+                if (pn >= K_TWOPI) pn -= K_TWOPI;
+                const float cn = (float)((double)L.clk + s);               // msk.c:95
+                if (go) {
+                    p = pn;
+                    L.clk = cn;
+                    cnt = u + 1;
+                    fired = (double)cn >= thr;
+                }
+                if ((u % LPC) == g) myp[u / LPC] = pn;
+            }
+        }
+        // next period's samples: issue the loads now
+        float in_next[SPL];
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) {
+            const int m = n + cnt + g + j * LPC;
+            in_next[j] = (m < len) ? dm[m] : 0.f;
+        }
+        // ---- B: mixer for the cnt samples, spread over the group's lanes (msk.c:86-91)
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) {
+            const int u = g + j * LPC;
+            if (u < cnt) {
+                double sn, cs;
+                sincos_2pi(myp[j], &sn, &cs);
+                const double in = (double)in_cur[j];
+                unsigned int k = idx + (unsigned int)u;
+                if (k >= FLEN) k -= FLEN;
+                ring[k][slot] = make_float2((float)(in * cs), (float)(in * (-sn)));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) in_cur[j] = in_next[j];
+        n += cnt;
+        idx += (unsigned int)cnt;
+        if (idx >= FLEN) idx -= FLEN;
+        __syncthreads();                  // one wave per block: orders the ring writes before the reads
+        // ---- C: bit decision (replicated; side effects by the group leader only)
         if (fired) {
             L.clk = (float)((double)L.clk - K_3PI2);                      // msk.c:100
             // matched filter, msk.c:103-107
@@ -202,7 +338,7 @@ __global__ __launch_bounds__(ACG_WG_MSK) void msk_demod_kernel(const MskArgs a)
 #pragma unroll
             for (int j = 0; j < FLEN; ++j, o += MFLTOVER) {
                 const float hh = hs[o];
-                const float2 x = ring[k][tid];
+                const float2 x = ring[k][slot];
                 vr = vr + hh * x.x;
                 vi = vi + hh * x.y;
                 k = (k + 1 == FLEN) ? 0 : k + 1;
@@ -231,7 +367,7 @@ __global__ __launch_bounds__(ACG_WG_MSK) void msk_demod_kernel(const MskArgs a)
             L.outbits = (L.outbits >> 1) & 0x7fu;
             if (sv > 0) L.outbits |= 0x80u;
             L.nbits--;
-            if (L.nbits <= 0) decode_acars(L, a, ch, txt, samp0 + n - 1);
+            if (L.nbits <= 0) decode_acars(L, a, ch, txt, samp0 + n - 1, leader);
             L.nbit_total++;
             L.S++;
             // PLL filter, msk.c:130 (float constants promoted to double)
@@ -239,7 +375,7 @@ __global__ __launch_bounds__(ACG_WG_MSK) void msk_demod_kernel(const MskArgs a)
         }
     }
 
-    if (active) {
+    if (active && leader) {
         st->phi = p; st->df = L.df; st->lvlsum = L.lvlsum;
         st->clk = L.clk; st->bitcount = L.bitcount; st->S = L.S; st->idx = idx;
         st->nbits = L.nbits; st->astate = L.astate; st->blen = L.blen; st->berr = L.berr;
@@ -247,7 +383,7 @@ __global__ __launch_bounds__(ACG_WG_MSK) void msk_demod_kernel(const MskArgs a)
         st->nsamp_total = samp0 + len;
 #pragma unroll
         for (int j = 0; j < FLEN; ++j) {
-            const float2 x = ring[j][tid];
+            const float2 x = ring[j][slot];
             st->inb[2 * j] = x.x;
             st->inb[2 * j + 1] = x.y;
         }
@@ -255,9 +391,29 @@ __global__ __launch_bounds__(ACG_WG_MSK) void msk_demod_kernel(const MskArgs a)
     }
 }
 
-extern "C" int acg_launch_msk(const MskArgs* a, void* stream)
+// test hook: the device sin/cos used by the mixer, on n arguments
+__global__ void sincos_selftest_kernel(const double* x, double* s, double* c, int n)
 {
-    const unsigned int grid = (unsigned int)((a->nch + ACG_WG_MSK - 1) / ACG_WG_MSK);
-    hipLaunchKernelGGL(msk_demod_kernel, dim3(grid), dim3(ACG_WG_MSK), 0, (hipStream_t)stream, *a);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) sincos_2pi(x[i], &s[i], &c[i]);
+}
+
+extern "C" int acg_launch_sincos_selftest(const double* x, double* s, double* c, int n, void* stream)
+{
+    hipLaunchKernelGGL(sincos_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, s, c, n);
+    return (int)hipGetLastError();
+}
+
+extern "C" int acg_launch_msk(const MskArgs* a, int lpc, void* stream)
+{
+    const int cpw = ACG_WG_MSK / lpc;
+    const unsigned int grid = (unsigned int)((a->nch + cpw - 1) / cpw);
+    switch (lpc) {
+    case 1: hipLaunchKernelGGL(msk_demod_kernel<1>, dim3(grid), dim3(ACG_WG_MSK), 0, (hipStream_t)stream, *a); break;
+    case 2: hipLaunchKernelGGL(msk_demod_kernel<2>, dim3(grid), dim3(ACG_WG_MSK), 0, (hipStream_t)stream, *a); break;
+    case 4: hipLaunchKernelGGL(msk_demod_kernel<4>, dim3(grid), dim3(ACG_WG_MSK), 0, (hipStream_t)stream, *a); break;
+    case 8: hipLaunchKernelGGL(msk_demod_kernel<8>, dim3(grid), dim3(ACG_WG_MSK), 0, (hipStream_t)stream, *a); break;
+    default: return (int)hipErrorInvalidValue;
+    }
     return (int)hipGetLastError();
 }

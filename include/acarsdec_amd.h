@@ -148,6 +148,10 @@ int  acg_get_timing(acg_ctx *ctx, double *fir_ms, int *fir_launches, double *msk
 int  acg_fill_random_u8_dev(uint8_t *dev, size_t pitch_bytes, int nrows, size_t row_bytes,
 			    uint64_t seed, void *hip_stream);
 
+/* diagnostics: the device sin/cos used by the mixer (msk.c:90 calls cexp), evaluated on the GPU
+ * for n host arguments in [0, 2*pi) -- lets a test bound its error against libm */
+int  acg_selftest_sincos(const double *x_host, double *sin_host, double *cos_host, int n);
+
 #ifdef __cplusplus
 }
 #endif

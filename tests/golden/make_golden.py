@@ -107,6 +107,15 @@ def main():
         prog["o" + o] = dict(md5=hashlib.md5(txt).hexdigest())
         if o == "1":
             prog["o1"]["stdout"] = txt.decode("latin-1")
+        if o == "4":       # JSON lines carry wall-clock time and the host name: keep the rest
+            recs = []
+            for line in txt.decode("latin-1").splitlines():
+                if line.startswith("{"):
+                    d = json.loads(line)
+                    d.pop("timestamp", None)
+                    d.pop("station_id", None)
+                    recs.append(d)
+            prog["o4"]["records"] = recs
     gold["program"] = prog
     with open(os.path.join(HERE, "testwav_golden.json"), "w") as f:
         json.dump(gold, f, indent=1)

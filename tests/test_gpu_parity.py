@@ -290,6 +290,51 @@ def test_many_channels_synthetic_msk(D, O, S):
     dec.close()
 
 
+def test_device_sincos_within_one_ulp_of_libm(D):
+    """the mixer's sin/cos (msk.c:90 calls cexp): device result vs libm on 2e5 phases in [0, 2*pi)"""
+    from acarsdec_amd import _capi as K
+    rng = np.random.default_rng(9)
+    x = np.concatenate([rng.uniform(0, 2 * np.pi, 200000), [0.0, np.pi / 4, np.pi / 2, np.pi, 1.5 * np.pi, 2 * np.pi - 1e-15],
+                        np.arange(8) * (np.pi / 4) + 1e-9, np.arange(1, 9) * (np.pi / 4) - 1e-9])
+    s = np.zeros_like(x)
+    c = np.zeros_like(x)
+    assert K.load().acg_selftest_sincos(x.ctypes.data, s.ctypes.data, c.ctypes.data, x.size) == 0
+    for got, want in ((s, np.sin(x)), (c, np.cos(x))):
+        ulp = np.abs(got - want) / np.maximum(np.spacing(np.abs(want)), 2.0 ** -80)
+        ok = (ulp <= 1.0) | (np.abs(got - want) < 3e-17)      # absolute bound near the zeros
+        assert ok.all(), (ulp.max(), x[np.argmax(ulp)])
+    assert (s == np.sin(x)).mean() > 0.8 and (c == np.cos(x)).mean() > 0.8      # most are bit-identical to libm
+
+
+@pytest.mark.parametrize("lpc", [1, 2, 4, 8])
+def test_msk_lane_layouts_are_bit_identical(D, O, S, lpc, monkeypatch):
+    """1/2/4/8 lanes per channel only change the SIMT schedule: bits, state and blocks identical."""
+    rng = np.random.default_rng(77)
+    nch, n = 19, 6000                      # not a multiple of the channels-per-wave of any layout
+    x = np.zeros((nch, n), dtype=np.float32)
+    for c in range(nch):
+        a, _ = S.channel_audio(rng, n, gap=(800, 2000), text_len=(5, 30))
+        x[c] = S.envelope(a, carrier=0.3, noise=0.01, rng=rng)
+    x[3] = rng.normal(0.2, 0.1, n)         # noise only
+    monkeypatch.setenv("ACG_MSK_LPC", str(lpc))
+    dec = D.Decoder(nch, decim=8, ntaps=8, max_blocks=8)
+    dec.demod_msk(x[:, :2999])
+    fr = dec.drain_frames()
+    dec.demod_msk(x[:, 2999:])
+    fr += dec.drain_frames()
+    got = blocks_by_channel(fr, D.frame_tuple)
+    for c in range(nch):
+        ch = O.Channel(c, max_bits=3000)
+        ch.demod(x[c, :2999])
+        ch.demod(x[c, 2999:])
+        assert got.get(c, []) == [O.frame_tuple(f) for f in ch.frames], (lpc, c)
+        s, o = dec.state(c), ch.state()
+        for k in ("MskS", "idx", "nbits", "Acarsstate", "outbits", "MskBitCount"):
+            assert s[k] == o[k], (lpc, c, k)
+        assert abs(s["MskDf"] - o["MskDf"]) < 1e-6 and abs(s["MskPhi"] - o["MskPhi"]) < 1e-3
+    dec.close()
+
+
 # ------------------------------------------------------------------------------------ the legacy call surface
 def test_compat_program_output_is_golden(golden, tmp_path):
     """The reference's UNCHANGED acarsdec.c/acars.c/output.c linked against compat_msk.c
@@ -306,9 +351,20 @@ def test_compat_program_output_is_golden(golden, tmp_path):
     hdr = b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVE" + b"fmt " + struct.pack(
         "<IHHIIHH", 16, 1, pcm.shape[1], 12500, 12500 * 2 * pcm.shape[1], 2 * pcm.shape[1], 16) + b"data" + struct.pack("<I", len(data))
     wav.write_bytes(hdr + data)
-    for o in ("1", "2", "4"):
-        r = subprocess.run([exe, "-o", o, "-f", str(wav)], capture_output=True, timeout=300)
-        assert hashlib.md5(r.stdout).hexdigest() == golden["program"]["o" + o]["md5"], r.stdout.decode("latin-1") + r.stderr.decode("latin-1")
+    r = subprocess.run([exe, "-o", "1", "-f", str(wav)], capture_output=True, timeout=300)
+    assert hashlib.md5(r.stdout).hexdigest() == golden["program"]["o1"]["md5"], r.stdout.decode("latin-1") + r.stderr.decode("latin-1")
+    assert r.stdout.decode("latin-1") == golden["program"]["o1"]["stdout"]
+    # JSON output (output.c:227-324) minus wall-clock time and host name
+    import json
+    r = subprocess.run([exe, "-o", "4", "-f", str(wav)], capture_output=True, timeout=300)
+    recs = []
+    for line in r.stdout.decode("latin-1").splitlines():
+        if line.startswith("{"):
+            d = json.loads(line)
+            d.pop("timestamp", None)
+            d.pop("station_id", None)
+            recs.append(d)
+    assert recs == golden["program"]["o4"]["records"]
 
 
 def test_replay_sink_matches_device_blocks(D, O, testwav):
