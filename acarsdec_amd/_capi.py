@@ -61,6 +61,8 @@ SYMBOLS = {
     "acg_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int),
                                  C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "acg_fill_random_u8_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_uint64, C.c_void_p]),
+    "acg_synth_iq_u8_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_uint64, C.c_void_p]),
     "acg_selftest_sincos": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
 }
 

@@ -654,3 +654,16 @@ extern "C" int acg_fill_random_u8_dev(uint8_t* dev, size_t pitch_bytes, int nrow
     const int e = acg_launch_fill_random(dev, pitch_bytes, nrows, row_bytes, seed, hip_stream);
     return e == 0 ? ACG_OK : ACG_EHIP;
 }
+
+extern "C" int acg_synth_iq_u8_dev(uint8_t* iq_dev, size_t pitch_bytes, int nrows, int nout, int decim,
+                                   const float* env_dev, size_t env_pitch_floats, const int* env_index_dev,
+                                   const float* off_hz_dev, const float* phase_dev, float scale, float noise_sigma,
+                                   uint64_t seed, void* hip_stream)
+{
+    if (!iq_dev || !env_dev || !env_index_dev || !off_hz_dev || !phase_dev || nrows < 1 || nout < 1 || decim < 1 ||
+        (decim % 8) || (pitch_bytes & 15) || ((uintptr_t)iq_dev & 15) || pitch_bytes < (size_t)nout * decim * 2)
+        return ACG_EINVAL;
+    const int e = acg_launch_synth_iq(iq_dev, pitch_bytes, nrows, nout, decim, env_dev, env_pitch_floats, env_index_dev,
+                                      off_hz_dev, phase_dev, scale, noise_sigma, seed, hip_stream);
+    return e == 0 ? ACG_OK : ACG_EHIP;
+}

@@ -87,6 +87,9 @@ int acg_launch_fir_generic(const FirArgs* a, void* stream);
 size_t acg_fir_lds_bytes(const FirArgs* a);
 int acg_launch_msk(const MskArgs* a, int lanes_per_channel, void* stream);
 int acg_launch_sincos_selftest(const double* x, double* s, double* c, int n, void* stream);
+int acg_launch_synth_iq(uint8_t* iq, size_t pitch, int nrows, int nout, int decim, const float* env,
+                        size_t env_pitch, const int* env_index, const float* off_hz, const float* phase,
+                        float scale, float noise, uint64_t seed, void* stream);
 int acg_launch_fill_random(uint8_t* dev, size_t pitch, int nrows, size_t row_bytes, uint64_t seed, void* stream);
 #ifdef __cplusplus
 }

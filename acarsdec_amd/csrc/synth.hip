@@ -30,6 +30,61 @@ __global__ void fill_random_u8_kernel(uint8_t* dev, size_t pitch, int nrows, siz
     }
 }
 
+// AM up-converter: row r carries envelope env[env_index[r]] (12.5 kHz, zero-order-held `decim`
+// times) on a carrier at off_hz[r] from the tuner centre with phase phase[r], plus white gaussian
+// noise, quantised the way an RTL dongle delivers it: u8 = clip(rint(127.37 + 127.5*x)).
+// One thread per 8 complex samples (16 output bytes).
+__global__ void synth_iq_u8_kernel(uint8_t* iq, size_t pitch, int nrows, int nout, int decim,
+                                   const float* env, size_t env_pitch, const int* env_index,
+                                   const float* off_hz, const float* phase, float scale, float noise,
+                                   uint64_t seed)
+{
+    const size_t cpr = (size_t)nout * decim / 8;                 // 16-byte chunks per row
+    const size_t total = (size_t)nrows * cpr;
+    const double rate = 12500.0 * decim;
+    for (size_t gidx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gidx < total;
+         gidx += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = gidx / cpr;
+        const size_t c = gidx - r * cpr;
+        const float* e = env + (size_t)env_index[r] * env_pitch;
+        const double f = (double)off_hz[r];
+        const float ph = phase[r];
+        unsigned int w[4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const size_t n = c * 8 + j;
+            const double turns = f * (double)n / rate;
+            const float frac = (float)(turns - floor(turns));
+            float sn, cs;
+            __sincosf(6.2831853f * frac + ph, &sn, &cs);
+            const float a = scale * e[n / decim];
+            const uint64_t h = splitmix64(seed ^ (r * 0x9E3779B97F4A7C15ull) ^ (n * 0xD1B54A32D192ED03ull));
+            // Box-Muller from two 24-bit uniforms
+            const float u1 = ((float)((h >> 40) & 0xffffff) + 1.0f) * (1.0f / 16777217.0f);
+            const float u2 = (float)((h >> 8) & 0xffffff) * (1.0f / 16777216.0f);
+            const float rad = noise * sqrtf(-2.0f * __logf(u1));
+            float gs, gc;
+            __sincosf(6.2831853f * u2, &gs, &gc);
+            const float xi = a * cs + rad * gc;
+            const float xq = a * sn + rad * gs;
+            const int bi = (int)fminf(fmaxf(rintf(127.37f + 127.5f * xi), 0.f), 255.f);
+            const int bq = (int)fminf(fmaxf(rintf(127.37f + 127.5f * xq), 0.f), 255.f);
+            const unsigned int pair = (unsigned int)bi | ((unsigned int)bq << 8);
+            if (j & 1) w[j >> 1] |= pair << 16; else w[j >> 1] = pair;
+        }
+        *(uint4*)(iq + r * pitch + (c << 4)) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+extern "C" int acg_launch_synth_iq(uint8_t* iq, size_t pitch, int nrows, int nout, int decim, const float* env,
+                                   size_t env_pitch, const int* env_index, const float* off_hz, const float* phase,
+                                   float scale, float noise, uint64_t seed, void* stream)
+{
+    hipLaunchKernelGGL(synth_iq_u8_kernel, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, iq, pitch, nrows, nout,
+                       decim, env, env_pitch, env_index, off_hz, phase, scale, noise, seed);
+    return (int)hipGetLastError();
+}
+
 extern "C" int acg_launch_fill_random(uint8_t* dev, size_t pitch, int nrows, size_t row_bytes,
                                       uint64_t seed, void* stream)
 {

@@ -52,17 +52,31 @@ def cpu_baseline_child(variant, M, blocks_per_call, seconds):
 
 
 def run_cpu_baseline(M, seconds=12.0):
+    me = os.path.abspath(__file__)
     for variant, label in (("_fast", "-Ofast -march=native"), ("_v3", "-Ofast -march=x86-64-v3"), ("", "-O2")):
         so = os.path.join(ROOT, "oracle", "_ref", "libacarsref%s.so" % variant)
         if not os.path.exists(so):
             continue
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-child", variant, str(M), "4", str(seconds)],
-                           capture_output=True, text=True)
+        cmd = [sys.executable, me, "--cpu-child", variant, str(M), "4", str(seconds)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode == 0 and r.stdout.strip():
             d = json.loads(r.stdout.strip().splitlines()[-1])
-            return dict(value=round(d["value"], 2), unit="channel*Msamples/s", cores=1, kind="reference",
-                        sample="unmodified reference rtl.c in_callback + msk.c + acars.c (%s), 1 channel per stream, "
-                               "rtlMult=%d, %d callbacks of 1024 outputs in %.1f s on one host core" % (label, M, d["blocks"], d["seconds"]))
+            out = dict(value=round(d["value"], 2), unit="channel*Msamples/s", cores=1, kind="reference",
+                       sample="unmodified reference rtl.c in_callback + msk.c + acars.c (%s), 1 channel per stream, "
+                              "rtlMult=%d, %d callbacks of 1024 outputs in %.1f s on one host core (the reference is single-threaded)"
+                              % (label, M, d["blocks"], d["seconds"]))
+            # the fair "all host cores" number: one independent reference process per core
+            ncpu = min(os.cpu_count() or 1, 64)
+            if ncpu > 1:
+                cmd[-1] = str(max(4.0, seconds / 2))
+                ps = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(ncpu)]
+                tot = 0.0
+                for p in ps:
+                    o, _ = p.communicate()
+                    if p.returncode == 0 and o.strip():
+                        tot += json.loads(o.strip().splitlines()[-1])["value"]
+                out["all_cores"] = dict(value=round(tot, 1), processes=ncpu)
+            return out
     # no reference build travelled: time the C restatement instead
     import numpy as np
     from oracle import oracle as O
@@ -78,16 +92,28 @@ def run_cpu_baseline(M, seconds=12.0):
                 sample="oracle/acars_oracle.c (-O2 IEEE), 1 channel, %d callbacks in %.1f s" % (n, dt))
 
 
+PRESETS = {
+    # BASELINE.json configs[2]: 1 GPU, 1024 channels, synthetic 2.5 Msps IQ, FIR decimate + MSK demod throughput
+    "throughput": dict(channels=1024, decim=200, ntaps=200, blocks=8),
+    # BASELINE.json configs[4]: 1 GPU stress, 192-tap LPF FIR, 2.5 Msps, 4096 channels
+    "stress": dict(channels=4096, decim=200, ntaps=192, blocks=4),
+    # BASELINE.json configs[3] per-GPU share: 16384 channels over 8 GPUs
+    "shard2048": dict(channels=2048, decim=200, ntaps=200, blocks=8),
+}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--channels", type=int, default=1024, help="channels per GPU")
-    ap.add_argument("--decim", type=int, default=200, help="rtlMult: 200 = 2.5 Msps")
+    ap.add_argument("--config", choices=sorted(PRESETS), default="throughput")
+    ap.add_argument("--channels", type=int, default=None, help="channels per GPU (overrides the preset)")
+    ap.add_argument("--decim", type=int, default=None, help="rtlMult: 200 = 2.5 Msps")
     ap.add_argument("--ntaps", type=int, default=None)
-    ap.add_argument("--blocks", type=int, default=8, help="1024-output callbacks per channel per step")
-    ap.add_argument("--signal-channels", type=int, default=16, help="channels carrying real MSK traffic (checked vs oracle)")
+    ap.add_argument("--blocks", type=int, default=None, help="1024-output callbacks per channel per step")
+    ap.add_argument("--check-channels", type=int, default=24, help="channels of rank 0 verified against the oracle")
+    ap.add_argument("--random-bytes", action="store_true", help="uniform random input bytes instead of ACARS traffic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-child", nargs=4, default=None)
     args = ap.parse_args()
@@ -95,11 +121,16 @@ def main():
         v, M, b, s = args.cpu_child
         cpu_baseline_child(v, int(M), int(b), float(s))
         return
+    pre = PRESETS[args.config]
+    nch = args.channels or pre["channels"]
+    M = args.decim or pre["decim"]
+    ntaps = args.ntaps or (pre["ntaps"] if args.decim is None else M)
+    nblk = args.blocks or pre["blocks"]
 
     import numpy as np
     import torch
     import torch.distributed as dist
-    from acarsdec_amd import decoder as D, synth as S, _capi as K
+    from acarsdec_amd import decoder as D, synth as S, _capi as K, shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -107,49 +138,69 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
     torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-
-    M = args.decim
-    ntaps = args.ntaps or M
-    nch, nblk = args.channels, args.blocks
-    row = nblk * 1024 * M * 2
-    dev = torch.device("cuda", local)
-    iq = torch.empty((nch, row), dtype=torch.uint8, device=dev)
+        dist.init_process_group("nccl", device_id=dev)
     L = K.load()
-    # distinct pseudo-random bytes per channel and per rank (working set >> 256 MiB Infinity Cache)
-    rc = L.acg_fill_random_u8_dev(iq.data_ptr(), row, nch, row, 0xACA25 + rank, None)
-    assert rc == 0
+
+    # ---- per-channel configuration: made on rank 0 for ALL channels of the job, scattered over RCCL
+    # (the only data that ever crosses xGMI: ~32 B per channel; inputs are generated where they are used)
+    nch_total = nch * world
+    NPOOL = 64
+    cfg_rows = None
+    if rank == 0:
+        r0 = np.random.default_rng(0xACA25)
+        off = r0.integers(-48, 49, size=nch_total) * 25000.0          # multiples of 12.5 kHz within +-1.2 MHz
+        off[np.abs(off) < 25000] = 50000.0                             # >= 25 kHz from DC like chooseFc enforces
+        cfg_rows = np.stack([off, r0.uniform(0, 2 * np.pi, nch_total), r0.integers(0, NPOOL, nch_total).astype(np.float64),
+                             np.arange(nch_total, dtype=np.float64)], axis=1)
+    mine = shard.scatter_channel_config(cfg_rows, world, rank, dist if world > 1 else None)
+    own = shard.owned_channels(nch_total, rank, world)
+    assert mine.shape[0] == nch and np.array_equal(mine[:, 3].astype(np.int64), own)
+    offs, phases, pool_idx = mine[:, 0], mine[:, 1], mine[:, 2].astype(np.int32)
+
+    fc = 131000000
+    taps = np.zeros((nch, ntaps, 2), dtype=np.float32)
+    win = np.ones(ntaps) if ntaps == M else np.hamming(ntaps) / np.hamming(ntaps).mean() * (M / ntaps)
+    tap_cache = {}
+    for c in range(nch):
+        o = int(offs[c])
+        if o not in tap_cache:
+            tap_cache[o] = (D.rtl_taps(fc + o, fc, M)[:ntaps] * win[:, None]).astype(np.float32)
+        taps[c] = tap_cache[o]
+
+    # ---- inputs, resident in HBM: distinct bytes per channel, working set >> 256 MiB Infinity Cache
+    row = nblk * 1024 * M * 2
+    iq = torch.empty((nch, row), dtype=torch.uint8, device=dev)
+    if args.random_bytes:
+        assert L.acg_fill_random_u8_dev(iq.data_ptr(), row, nch, row, 0xACA25 + rank, None) == 0
+        data_desc = "uniform random bytes"
+    else:
+        # a pool of ACARS/MSK audio tracks (SURVEY App. C.2 modulator), every channel = one track on its
+        # own carrier offset / phase / noise realisation, up-converted on the device
+        prng = np.random.default_rng(0xACA25)
+        pool = np.zeros((NPOOL, nblk * 1024), dtype=np.float32)
+        for i in range(NPOOL):
+            a, _ = S.channel_audio(prng, nblk * 1024, gap=(1500, 5000), text_len=(20, 160))
+            pool[i] = 0.5 * (1.0 + 0.5 * a)
+        d_pool = torch.from_numpy(pool).to(dev)
+        d_idx = torch.from_numpy(pool_idx).to(dev)
+        d_off = torch.from_numpy(offs.astype(np.float32)).to(dev)
+        d_ph = torch.from_numpy(phases.astype(np.float32)).to(dev)
+        rc = L.acg_synth_iq_u8_dev(iq.data_ptr(), row, nch, nblk * 1024, M, d_pool.data_ptr(), pool.shape[1], d_idx.data_ptr(),
+                                   d_off.data_ptr(), d_ph.data_ptr(), 0.25, 0.05, 0xACA25 + rank, None)
+        assert rc == 0, rc
+        data_desc = "ACARS/MSK traffic on every channel (%d-track pool, AM depth 0.5, AWGN sigma 0.05, device-side up-converter)" % NPOOL
     torch.cuda.synchronize()
 
     dec = D.Decoder(nch, decim=M, ntaps=ntaps, max_blocks=nblk, device=local, bitlog=True, timing=True)
-    rng = np.random.default_rng(0xACA25 + rank)
-    offs = (rng.integers(-48, 49, size=nch) * 25000 + 12500 * 2).astype(np.int64)   # multiples of 12.5 kHz, >= 25 kHz from DC
-    offs[np.abs(offs) < 25000] = 50000
-    fc = 131000000
-    taps = np.zeros((nch, ntaps, 2), dtype=np.float32)
-    for c in range(nch):
-        taps[c] = D.rtl_taps(fc + int(offs[c]), fc, M)[:ntaps]
     dec.set_taps(taps)
-
-    # a subset of channels carries real ACARS traffic so that the timed path does real decoding
-    nsig = min(args.signal_channels, nch)
-    sig_frames = 0
-    host_rows = []
-    for c in range(nsig):
-        a, frames = S.channel_audio(rng, nblk * 1024, gap=(1500, 4000), text_len=(20, 120))
-        sig_frames += len(frames)
-        r = S.iq_u8_from_envelopes(0.5 * (1 + 0.5 * a)[None, :], M, [float(offs[c])], phases=[rng.uniform(0, 6.28)],
-                                   noise=0.025, rng=rng)
-        host_rows.append(r)
-        iq[c].copy_(torch.from_numpy(r))
-    torch.cuda.synchronize()
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
         dec.in_callback(iq, nblocks=nblk, pitch=row, stream=stream)
-        return dec.drain_frames(max_frames=8192)
+        return dec.drain_frames(max_frames=max(8192, 8 * nch))
 
     def barrier():
         torch.cuda.synchronize()
@@ -157,22 +208,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # correctness gate on the first pass (state starts from reset): signal channels vs the oracle
+    # ---- correctness gate on the first pass (state starts from reset): a subset of rank 0's channels
+    # goes through the CPU oracle on the very bytes the GPU consumed
     first = step()
     parity = None
     if rank == 0:
         from oracle import oracle as O
+        ncheck = min(args.check_channels, nch)
         got = {}
         for f in first:
             got.setdefault(int(f.chn), []).append(D.frame_tuple(f))
         ok, nblocks = True, 0
-        for c in range(nsig):
+        host_rows = iq[:ncheck].cpu().numpy()
+        for c in range(ncheck):
             ch = O.Channel(c)
             ch.demod(O.fir_u8(host_rows[c], M, taps[c], ntaps=ntaps))
             want = [O.frame_tuple(f) for f in ch.frames]
             nblocks += len(want)
             ok &= got.get(c, []) == want
-        parity = dict(channels_checked=nsig, blocks=nblocks, bit_exact=bool(ok))
+        parity = dict(channels_checked=ncheck, blocks=nblocks, bit_exact=bool(ok), blocks_first_pass_all_channels=len(first))
         if not ok:
             raise SystemExit("bench: GPU blocks differ from the oracle: %r" % parity)
 
@@ -187,13 +241,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     tim = dec.timing()
-
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    cnt = torch.tensor([float(nfr)], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
-    dt = float(t.item())
+    dt, nfr_total = shard.reduce_timing(dt, nfr, world, dist if world > 1 else None, dev)
 
     if rank == 0:
         samples_per_step = nch * nblk * 1024 * M                    # complex input samples per GPU per step
@@ -218,13 +266,13 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32 (u8 in; f64 VCO/PLL)",
-            "data": "synthetic",
-            "config": {"workload": "%d channels/GPU x %.1f Msps u8 IQ, one stream per channel, rtlMult=%d, ntaps=%d, "
+            "data": "synthetic: " + data_desc,
+            "config": {"workload": "BASELINE configs[%s]: %d channels/GPU x %.1f Msps u8 IQ, one stream per channel, rtlMult=%d, ntaps=%d, "
                                    "%d callbacks (%.3f s of signal) per step; FIR decimate + MSK demod + framing, blocks drained to host"
-                                   % (nch, 12500 * M / 1e6, M, ntaps, nblk, nblk * 0.08192),
+                                   % ({"throughput": "2", "stress": "4", "shard2048": "3"}[args.config], nch, 12500 * M / 1e6, M, ntaps, nblk, nblk * 0.08192),
                        "channels_per_gpu": nch, "decim": M, "ntaps": ntaps, "blocks_per_step": nblk,
                        "realtime_channels_equiv": int(value / (12500 * M / 1e6)),
-                       "signal_channels": nsig, "blocks_decoded_timed": int(cnt.item())},
+                       "preset": args.config, "channels_total": nch_total, "blocks_decoded_timed": int(nfr_total)},
             "roofline": {"bound": "hbm", "kernel": "fir_u8_tile_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                          "bytes_per_launch": int(fir_bytes), "avg_launch_ms": round(fir_avg_ms, 4), "launches_per_step": lps,

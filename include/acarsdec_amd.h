@@ -148,6 +148,13 @@ int  acg_get_timing(acg_ctx *ctx, double *fir_ms, int *fir_launches, double *msk
 int  acg_fill_random_u8_dev(uint8_t *dev, size_t pitch_bytes, int nrows, size_t row_bytes,
 			    uint64_t seed, void *hip_stream);
 
+/* device-side AM up-converter: row r = scale*env[env_index[r]][n/decim] *
+ * exp(j(2*pi*off_hz[r]*n/(12500*decim) + phase[r])) + N(0, noise_sigma^2), quantised like an RTL
+ * dongle (u8 = clip(rint(127.37 + 127.5 x))).  All pointers are device pointers. */
+int  acg_synth_iq_u8_dev(uint8_t *iq_dev, size_t pitch_bytes, int nrows, int nout, int decim,
+			 const float *env_dev, size_t env_pitch_floats, const int *env_index_dev,
+			 const float *off_hz_dev, const float *phase_dev, float scale, float noise_sigma,
+			 uint64_t seed, void *hip_stream);
 /* diagnostics: the device sin/cos used by the mixer (msk.c:90 calls cexp), evaluated on the GPU
  * for n host arguments in [0, 2*pi) -- lets a test bound its error against libm */
 int  acg_selftest_sincos(const double *x_host, double *sin_host, double *cos_host, int n);

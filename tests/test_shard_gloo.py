@@ -1,0 +1,84 @@
+"""The N>1 path on CPU: world_size-2 gloo processes exercise the channel partition, the config
+scatter, the block gather and the timing reduction that bench.py uses with RCCL.  The per-rank
+"decoder" here is the oracle (test infrastructure) -- what is under test is the sharding logic."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from acarsdec_amd import shard
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_partition_is_a_bijection():
+    for nch, world in ((16384, 8), (1024, 2), (10, 4), (3, 8)):
+        seen = np.concatenate([shard.owned_channels(nch, r, world) for r in range(world)])
+        assert sorted(seen.tolist()) == list(range(nch))
+        for c in (0, nch - 1, nch // 2):
+            r = shard.owner_of(c, world)
+            assert shard.owned_channels(nch, r, world)[shard.local_index(c, world)] == c
+
+
+def _worker(rank, world, port, nch, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from acarsdec_amd import synth as S
+    cfg = None
+    if rank == 0:
+        cfg = np.stack([np.arange(nch) * 1.0, 1000.0 + np.arange(nch)], axis=1)     # [seed, tag]
+    mine = shard.scatter_channel_config(cfg, world, rank, dist)
+    own = shard.owned_channels(nch, rank, world)
+    assert mine.shape == (len(own), 2) and np.array_equal(mine[:, 0], own.astype(np.float64))
+    blocks = []
+    for li, row in enumerate(mine):
+        rng = np.random.default_rng(int(row[0]))
+        a, _ = S.channel_audio(rng, 12000, nframes=1, gap=(2000, 3000), text_len=(5, 20))
+        ch = O.Channel(li)
+        ch.demod(S.envelope(a))
+        for f in ch.frames:
+            blocks.append((li, int(f.len), bytes(f.txt[: f.len]), int(f.end_bit)))
+    merged = shard.gather_blocks(blocks, own, world, rank, dist)
+    t, c = shard.reduce_timing(0.5 + rank, len(blocks), world, dist)
+    if rank == 0:
+        q.put((merged, t, c))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_gloo_shard_scatter_gather():
+    world, nch = 2, 6
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nch, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    merged, t, c = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # single-process ground truth
+    from oracle import oracle as O
+    from acarsdec_amd import synth as S
+    want = []
+    for g in range(nch):
+        rng = np.random.default_rng(g)
+        a, _ = S.channel_audio(rng, 12000, nframes=1, gap=(2000, 3000), text_len=(5, 20))
+        ch = O.Channel(0)
+        ch.demod(S.envelope(a))
+        want += [(g, int(f.len), bytes(f.txt[: f.len]), int(f.end_bit)) for f in ch.frames]
+    assert merged == sorted(want, key=lambda b: (b[0], b[-1])) and len(merged) >= nch - 1
+    assert t == 1.5 and c == len(merged)          # max over ranks, sum over ranks
