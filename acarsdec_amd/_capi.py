@@ -51,6 +51,7 @@ SYMBOLS = {
     "acg_fir_only_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "acg_sync": (C.c_int, [C.c_void_p]),
     "acg_drain_frames": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.c_int, C.POINTER(C.c_int)]),
+    "acg_collect_frames": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Frame), C.c_int, C.POINTER(C.c_int)]),
     "acg_read_bits": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "acg_read_bits_all": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "acg_bit_capacity": (C.c_int, [C.c_void_p]),

@@ -26,10 +26,19 @@ struct acg_ctx {
     acg_config cfg{};
     std::string err;
     hipStream_t stream = nullptr;
-    hipStream_t fir_stream = nullptr;   // down-converter chunks run here, ahead of the MSK chunks
+    hipStream_t msk_stream = nullptr;   // demodulator launches (they carry the channel state) run here, in order
+    hipStream_t copy_stream = nullptr;  // result copies that must not queue behind running kernels
     hipEvent_t in_ev = nullptr;
-    std::vector<hipEvent_t> chunk_ev;
+    std::vector<hipEvent_t> fir_done;   // per chunk slot: FIR of the slot finished (recorded on the caller's stream)
+    std::vector<hipEvent_t> msk_done;   // per chunk slot: MSK has consumed the slot's dm (recorded on msk_stream)
+    std::vector<char> msk_done_valid;
     int pipe_blocks = 1;            // 1024-output blocks per pipelined chunk (0 = no pipelining)
+    // per process call: frame-queue length at its end (pinned host word) + completion event
+    static constexpr int NCALL = 8;
+    hipEvent_t call_done[NCALL] = {};
+    unsigned int* h_call_count = nullptr;   // pinned [NCALL]
+    unsigned long long call_seq = 0;        // process calls issued
+    unsigned int consumed = 0;              // frames already handed to the host (monotonic, wraps with the counter)
     bool tile_path = true;          // decim % 8 == 0 -> LDS-tiled kernel
     int ntaps_pad = 0;
     int max_len = 0;                // max_blocks * 1024
@@ -114,9 +123,13 @@ static void free_all(acg_ctx* c)
     for (auto& p : c->fir_ev) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto& p : c->msk_ev) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : c->ev_pool) hipEventDestroy(e);
-    for (auto e : c->chunk_ev) hipEventDestroy(e);
+    for (auto e : c->fir_done) hipEventDestroy(e);
+    for (auto e : c->msk_done) hipEventDestroy(e);
+    for (auto e : c->call_done) if (e) hipEventDestroy(e);
+    if (c->h_call_count) hipHostFree(c->h_call_count);
     if (c->in_ev) hipEventDestroy(c->in_ev);
-    if (c->fir_stream) hipStreamDestroy(c->fir_stream);
+    if (c->msk_stream) hipStreamDestroy(c->msk_stream);
+    if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     if (c->stream) hipStreamDestroy(c->stream);
 }
 
@@ -149,7 +162,7 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
     c->dm_pitch = ((size_t)c->max_len + 63) & ~(size_t)63;
     c->bit_cap = c->max_len / 4 + 8;
     // shortest possible block: SYN SYN SOH ETX CRC CRC + END byte = 56 bits ~ 291 samples
-    c->frame_cap = (unsigned int)cfg->nch * (unsigned int)(c->max_len / 291 + 2);
+    c->frame_cap = 2u * (unsigned int)cfg->nch * (unsigned int)(c->max_len / 291 + 2);   // two calls' worth (lagged collection)
     // MSK kernel shape: the chip has 1024 SIMDs; give every channel as many lanes as keeps the
     // wave count around one per SIMD (latency mode), down to one lane per channel (throughput mode)
     c->msk_lpc = cfg->nch <= 8192 ? 8 : cfg->nch <= 16384 ? 4 : cfg->nch <= 32768 ? 2 : 1;
@@ -163,10 +176,17 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
     auto body = [&]() -> int {
         HIPCHK(c, hipSetDevice(cfg->device));
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        HIPCHK(c, hipStreamCreateWithFlags(&c->fir_stream, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->msk_stream, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         HIPCHK(c, hipEventCreateWithFlags(&c->in_ev, hipEventDisableTiming));
-        c->chunk_ev.resize((size_t)cfg->max_blocks);
-        for (auto& e : c->chunk_ev) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->fir_done.resize((size_t)cfg->max_blocks);
+        c->msk_done.resize((size_t)cfg->max_blocks);
+        c->msk_done_valid.assign((size_t)cfg->max_blocks, 0);
+        for (auto& e : c->fir_done) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto& e : c->msk_done) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto& e : c->call_done) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIPCHK(c, hipHostMalloc((void**)&c->h_call_count, sizeof(unsigned int) * acg_ctx::NCALL, hipHostMallocDefault));
+        std::memset(c->h_call_count, 0, sizeof(unsigned int) * acg_ctx::NCALL);
         const size_t nch = (size_t)cfg->nch;
         HIPCHK(c, hipMalloc(&c->d_taps, nch * c->ntaps_pad * 2 * sizeof(float)));
         HIPCHK(c, hipMemset(c->d_taps, 0, nch * c->ntaps_pad * 2 * sizeof(float)));
@@ -210,7 +230,10 @@ extern "C" int acg_reset(acg_ctx* ctx)
 {
     if (!ctx) return ACG_EINVAL;
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    ctx->consumed = 0;
+    ctx->call_seq = 0;
+    std::fill(ctx->msk_done_valid.begin(), ctx->msk_done_valid.end(), 0);
     // initMsk (msk.c:34-41): MskPhi = MskClk = MskS = MskDf = idx = 0, inb zeroed;
     // static storage: MskLvlSum = MskBitCount = 0; initAcars (acars.c:230-234): outbits 0, nbits 8, WSYN
     std::vector<AcgChan> st((size_t)ctx->cfg.nch);
@@ -366,9 +389,23 @@ extern "C" int acg_fir_only_dev(acg_ctx* ctx, const uint8_t* iq_dev, size_t pitc
         return fail(ctx, ACG_EINVAL, "I/Q base and pitch must be 16-byte aligned");
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    for (int j = 0; j < nblocks; ++j)
+        if (ctx->msk_done_valid[(size_t)j]) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->msk_done[(size_t)j], 0));
     r = launch_fir(ctx, iq_dev, pitch_bytes, nblocks, s);
     if (r == ACG_OK) ctx->last_len = nblocks * ACG_BLOCK;
     return r;
+}
+
+// Marks the end of one process call on the demodulator stream: the frame-queue length at that
+// point goes to a pinned host word, followed by an event.
+static int end_of_call(acg_ctx* ctx)
+{
+    const int slot = (int)(ctx->call_seq % acg_ctx::NCALL);
+    HIPCHK(ctx, hipMemcpyAsync(&ctx->h_call_count[slot], ctx->d_frame_count, sizeof(unsigned int),
+                               hipMemcpyDeviceToHost, ctx->msk_stream));
+    HIPCHK(ctx, hipEventRecord(ctx->call_done[slot], ctx->msk_stream));
+    ctx->call_seq++;
+    return ACG_OK;
 }
 
 extern "C" int acg_process_iq_u8_dev(acg_ctx* ctx, const uint8_t* iq_dev, size_t pitch_bytes, int nblocks,
@@ -380,29 +417,37 @@ extern "C" int acg_process_iq_u8_dev(acg_ctx* ctx, const uint8_t* iq_dev, size_t
         return fail(ctx, ACG_EINVAL, "I/Q base and pitch must be 16-byte aligned");
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
-    const int cb = ctx->pipe_blocks;
-    if (cb <= 0 || nblocks <= cb) {
-        r = launch_fir(ctx, iq_dev, pitch_bytes, nblocks, s);
-        if (r != ACG_OK) return r;
-        return launch_msk(ctx, ctx->d_dm, ctx->dm_pitch, nblocks * ACG_BLOCK, s);
-    }
-    // Software pipeline over time: the (bandwidth-bound, wide) down-converter of chunk k+1 runs on
-    // its own stream while the (latency-bound, narrow) demodulator of chunk k runs on the caller's
-    // stream.  Demodulator launches stay in order on one stream: they carry the channel state.
-    HIPCHK(ctx, hipEventRecord(ctx->in_ev, s));
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->fir_stream, ctx->in_ev, 0));
+    // Software pipeline.  The (bandwidth-bound, wide) down-converter chunks run on the CALLER's
+    // stream: they are the only consumers of the input, so whatever the caller enqueues next on
+    // that stream (refilling the buffer, the next call) is ordered correctly.  The (latency-bound,
+    // narrow) demodulator chunks run in order on the context's own stream -- they carry the
+    // channel state -- each waiting for its chunk of dm.  A dm chunk slot is rewritten by the
+    // next call only after the demodulator launch that read it has finished.  So FIR(k+1) overlaps
+    // MSK(k) inside a call, and FIR of call i+1 overlaps the MSK tail of call i.
+    int cb = ctx->pipe_blocks;
+    if (cb <= 0 || cb > nblocks) cb = nblocks;
     int k = 0;
     for (int b0 = 0; b0 < nblocks; b0 += cb, ++k) {
         const int nb = std::min(cb, nblocks - b0);
-        r = launch_fir(ctx, iq_dev, pitch_bytes, nb, ctx->fir_stream, b0);
+        // dm blocks [b0, b0+nb) may still be read by demodulator launches of the previous call
+        for (int j = b0; j < b0 + nb; ++j)
+            if (ctx->msk_done_valid[(size_t)j]) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->msk_done[(size_t)j], 0));
+        r = launch_fir(ctx, iq_dev, pitch_bytes, nb, s, b0);
         if (r != ACG_OK) return r;
-        HIPCHK(ctx, hipEventRecord(ctx->chunk_ev[(size_t)k], ctx->fir_stream));
-        HIPCHK(ctx, hipStreamWaitEvent(s, ctx->chunk_ev[(size_t)k], 0));
-        r = launch_msk(ctx, ctx->d_dm + (size_t)b0 * ACG_BLOCK, ctx->dm_pitch, nb * ACG_BLOCK, s, b0 > 0);
+        HIPCHK(ctx, hipEventRecord(ctx->fir_done[(size_t)k], s));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->msk_stream, ctx->fir_done[(size_t)k], 0));
+        r = launch_msk(ctx, ctx->d_dm + (size_t)b0 * ACG_BLOCK, ctx->dm_pitch, nb * ACG_BLOCK, ctx->msk_stream, b0 > 0);
         if (r != ACG_OK) return r;
+        // one event per dm block so that a later call with different chunking still finds its guards
+        HIPCHK(ctx, hipEventRecord(ctx->msk_done[(size_t)b0], ctx->msk_stream));
+        for (int j = b0; j < b0 + nb; ++j) ctx->msk_done_valid[(size_t)j] = (j == b0);
+        for (int j = b0 + 1; j < b0 + nb; ++j) {
+            HIPCHK(ctx, hipEventRecord(ctx->msk_done[(size_t)j], ctx->msk_stream));
+            ctx->msk_done_valid[(size_t)j] = 1;
+        }
     }
     ctx->last_len = nblocks * ACG_BLOCK;
-    return ACG_OK;
+    return end_of_call(ctx);
 }
 
 static int ensure_stage(acg_ctx* c, size_t bytes)
@@ -438,7 +483,11 @@ extern "C" int acg_process_dm_dev(acg_ctx* ctx, const float* dm_dev, size_t pitc
     if (ctx->cfg.nch > 1 && pitch_floats < (size_t)len) return fail(ctx, ACG_EINVAL, "pitch smaller than len");
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
-    return launch_msk(ctx, dm_dev, pitch_floats, len, s);
+    HIPCHK(ctx, hipEventRecord(ctx->in_ev, s));                       // dm produced on the caller's stream
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->msk_stream, ctx->in_ev, 0));
+    int r = launch_msk(ctx, dm_dev, pitch_floats, len, ctx->msk_stream);
+    if (r != ACG_OK) return r;
+    return end_of_call(ctx);
 }
 
 extern "C" int acg_process_dm_host(acg_ctx* ctx, const float* dm_host, size_t pitch_floats, int len)
@@ -446,12 +495,15 @@ extern "C" int acg_process_dm_host(acg_ctx* ctx, const float* dm_host, size_t pi
     if (!ctx || !dm_host) return ACG_EINVAL;
     if (len < 0 || len > ctx->max_len) return fail(ctx, ACG_EINVAL, "len out of range");
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
-    if (len == 0) return launch_msk(ctx, ctx->d_dm, ctx->dm_pitch, 0, ctx->stream);
-    const size_t rowb = (size_t)len * sizeof(float);
-    HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_dm, ctx->dm_pitch * sizeof(float), dm_host,
-                                 (ctx->cfg.nch > 1 ? pitch_floats : (size_t)len) * sizeof(float), rowb,
-                                 (size_t)ctx->cfg.nch, hipMemcpyHostToDevice, ctx->stream));
-    return launch_msk(ctx, ctx->d_dm, ctx->dm_pitch, len, ctx->stream);
+    if (len > 0) {
+        const size_t rowb = (size_t)len * sizeof(float);
+        HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_dm, ctx->dm_pitch * sizeof(float), dm_host,
+                                     (ctx->cfg.nch > 1 ? pitch_floats : (size_t)len) * sizeof(float), rowb,
+                                     (size_t)ctx->cfg.nch, hipMemcpyHostToDevice, ctx->msk_stream));
+    }
+    int r = launch_msk(ctx, ctx->d_dm, ctx->dm_pitch, len, ctx->msk_stream);
+    if (r != ACG_OK) return r;
+    return end_of_call(ctx);
 }
 
 extern "C" int acg_sync(acg_ctx* ctx)
@@ -459,28 +511,42 @@ extern "C" int acg_sync(acg_ctx* ctx)
     if (!ctx) return ACG_EINVAL;
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->msk_stream));
     return ACG_OK;
 }
 
 // ------------------------------------------------------------------------------------------
-extern "C" int acg_drain_frames(acg_ctx* ctx, acg_frame* out, int max_frames, int* nframes)
+// Hands frames [consumed, upto) of the ring to the host, ordered by (chn, end_bit).
+static int fetch_frames(acg_ctx* ctx, unsigned int upto, acg_frame* out, int max_frames, int* nframes)
 {
-    if (!ctx || !nframes || (max_frames > 0 && !out)) return ACG_EINVAL;
-    *nframes = 0;
-    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
-    HIPCHK(ctx, hipDeviceSynchronize());
-    unsigned int count = 0;
-    HIPCHK(ctx, hipMemcpy(&count, ctx->d_frame_count, sizeof(count), hipMemcpyDeviceToHost));
-    const unsigned int have = std::min(count, ctx->frame_cap);
-    std::vector<AcgFrameRec> rec(have);
-    if (have) HIPCHK(ctx, hipMemcpy(rec.data(), ctx->d_frames, (size_t)have * sizeof(AcgFrameRec), hipMemcpyDeviceToHost));
-    { int zr = zero_sync(ctx, ctx->d_frame_count, sizeof(unsigned int)); if (zr != ACG_OK) return zr; }
+    const unsigned int pending = upto - ctx->consumed;            // monotonic counters, wrap-safe
+    int rc = ACG_OK;
+    unsigned int take = pending;
+    if (pending > ctx->frame_cap) {                               // the device lapped the host: oldest lost
+        ctx->consumed = upto - ctx->frame_cap;
+        take = ctx->frame_cap;
+        rc = ACG_EOVERFLOW;
+    }
+    if ((unsigned int)max_frames < take) { take = (unsigned int)max_frames; rc = ACG_EOVERFLOW; }
+    std::vector<AcgFrameRec> rec(take);
+    if (take) {
+        const unsigned int cap = ctx->frame_cap;
+        const unsigned int first = ctx->consumed % cap;
+        const unsigned int n1 = std::min(take, cap - first);
+        HIPCHK(ctx, hipMemcpyAsync(rec.data(), ctx->d_frames + first, (size_t)n1 * sizeof(AcgFrameRec),
+                                   hipMemcpyDeviceToHost, ctx->copy_stream));
+        if (take > n1)
+            HIPCHK(ctx, hipMemcpyAsync(rec.data() + n1, ctx->d_frames, (size_t)(take - n1) * sizeof(AcgFrameRec),
+                                       hipMemcpyDeviceToHost, ctx->copy_stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
+    }
+    ctx->consumed += take;
+    if (rc == ACG_EOVERFLOW) ctx->consumed = upto;                // drop what did not fit
     std::sort(rec.begin(), rec.end(), [](const AcgFrameRec& a, const AcgFrameRec& b) {
         return a.chn != b.chn ? a.chn < b.chn : a.end_bit < b.end_bit;
     });
-    const int n = std::min<int>((int)have, max_frames);
-    for (int i = 0; i < n; ++i) {
-        const AcgFrameRec& r = rec[(size_t)i];
+    for (unsigned int i = 0; i < take; ++i) {
+        const AcgFrameRec& r = rec[i];
         acg_frame& f = out[i];
         std::memset(&f, 0, sizeof(f));
         f.chn = r.chn;
@@ -493,9 +559,33 @@ extern "C" int acg_drain_frames(acg_ctx* ctx, acg_frame* out, int max_frames, in
         f.end_bit = r.end_bit;
         f.end_sample = r.end_sample;
     }
-    *nframes = n;
-    if (count > ctx->frame_cap || (int)have > max_frames) return fail(ctx, ACG_EOVERFLOW, "frame queue overflow");
+    *nframes = (int)take;
+    if (rc != ACG_OK) return fail(ctx, rc, "frame queue overflow");
     return ACG_OK;
+}
+
+extern "C" int acg_collect_frames(acg_ctx* ctx, int lag, acg_frame* out, int max_frames, int* nframes)
+{
+    if (!ctx || !nframes || (max_frames > 0 && !out) || lag < 0 || lag >= acg_ctx::NCALL - 1) return ACG_EINVAL;
+    *nframes = 0;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    if (ctx->call_seq <= (unsigned long long)lag) return ACG_OK;              // nothing old enough yet
+    const unsigned long long call = ctx->call_seq - 1 - (unsigned long long)lag;
+    const int slot = (int)(call % acg_ctx::NCALL);
+    HIPCHK(ctx, hipEventSynchronize(ctx->call_done[slot]));                   // only that call, not newer ones
+    const unsigned int upto = ctx->h_call_count[slot];
+    return fetch_frames(ctx, upto, out, max_frames, nframes);
+}
+
+extern "C" int acg_drain_frames(acg_ctx* ctx, acg_frame* out, int max_frames, int* nframes)
+{
+    if (!ctx || !nframes || (max_frames > 0 && !out)) return ACG_EINVAL;
+    *nframes = 0;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    unsigned int count = 0;
+    HIPCHK(ctx, hipMemcpy(&count, ctx->d_frame_count, sizeof(count), hipMemcpyDeviceToHost));
+    return fetch_frames(ctx, count, out, max_frames, nframes);
 }
 
 extern "C" int acg_bit_capacity(const acg_ctx* ctx) { return ctx ? ctx->bit_cap : 0; }

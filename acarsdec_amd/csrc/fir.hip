@@ -15,6 +15,7 @@
 //   * the 4 waves split the tap range; partial sums meet in LDS; wave 0 takes |D| and writes 64
 //     consecutive floats of dm.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "acg_internal.h"
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -146,6 +147,119 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_tile_kernel(const FirArgs a
     }
 }
 
+// Persistent variant: the grid is exactly the number of workgroups the chip holds at once and the
+// (channel, tile) space is cut into equal contiguous runs, one per workgroup, so that all workgroups
+// finish together (no partial last wave of workgroups).  A run may cross channel boundaries; the
+// stream/tap base pointers follow.  NT selects non-temporal loads for the input, which is read once.
+template <bool NT>
+__global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_persist_kernel(const FirArgs a,
+                                                                     const uint8_t* __restrict__ iq_base,
+                                                                     const float* __restrict__ taps_base,
+                                                                     const int* __restrict__ stream_of,
+                                                                     float* __restrict__ dm_base)
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntile = (a.nwin + ACG_TILE_WIN - 1) / ACG_TILE_WIN;
+    const long long G = (long long)a.nch * ntile;
+    const long long g0 = G * blockIdx.x / gridDim.x;
+    const long long g1 = G * (blockIdx.x + 1) / gridDim.x;
+    if (g0 >= g1) return;
+
+    const int cpr = a.cpr;
+    const int tile_chunks = ACG_TILE_WIN * cpr;
+    const int total_chunks = a.nwin * cpr;
+    const int pad = a.row_stride - a.row_bytes;
+    const unsigned int magic = a.cpr_magic;
+    unsigned char* tileL = fir_smem;
+    float4* red = (float4*)(fir_smem + ACG_TILE_WIN * a.row_stride);
+    const int nck = a.ntaps_pad >> 3;
+    const int c0 = nck * wave / 4;
+    const int c1 = nck * (wave + 1) / 4;
+    const int nld = (tile_chunks + ACG_WG_FIR - 1) / ACG_WG_FIR;
+
+    int ch = (int)(g0 / ntile);
+    int t = (int)(g0 - (long long)ch * ntile);
+    uint4 stage[FIR_MAXLD];
+
+    auto fetch = [&](int fch, int ft) {
+        const uint8_t* __restrict__ src = iq_base + (size_t)stream_of[fch] * a.pitch;
+        const int base = ft * tile_chunks;
+#pragma unroll
+        for (int i = 0; i < FIR_MAXLD; ++i) {
+            if (i < nld) {
+                const int c = tid + i * ACG_WG_FIR;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (c < tile_chunks && base + c < total_chunks) {
+                    const uint4* p = (const uint4*)(src + ((size_t)(base + c) << 4));
+                    if (NT) {
+                        typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+                        const u4v x = __builtin_nontemporal_load((const u4v*)p);
+                        v = make_uint4(x.x, x.y, x.z, x.w);
+                    } else {
+                        v = *p;
+                    }
+                }
+                stage[i] = v;
+            }
+        }
+    };
+
+    fetch(ch, t);
+    for (long long g = g0; g < g1; ++g) {
+#pragma unroll
+        for (int i = 0; i < FIR_MAXLD; ++i) {
+            if (i < nld) {
+                const int c = tid + i * ACG_WG_FIR;
+                if (c < tile_chunks) {
+                    const int r = (int)(((unsigned int)c * magic) >> 20);
+                    *(uint4*)(tileL + (c << 4) + r * pad) = stage[i];
+                }
+            }
+        }
+        __syncthreads();
+
+        int nch_ = ch, nt_ = t + 1;
+        if (nt_ == ntile) { nt_ = 0; ++nch_; }
+        if (g + 1 < g1) fetch(nch_, nt_);
+
+        const float* __restrict__ taps = taps_base + (size_t)ch * a.ntaps_pad * 2;
+        f2 accA = {0.f, 0.f};
+        f2 accB = {0.f, 0.f};
+        const unsigned char* rowp = tileL + lane * a.row_stride;
+        for (int c = c0; c < c1; ++c) {
+            const uint4 q = *(const uint4*)(rowp + (c << 4));
+            const float* __restrict__ w = taps + (c << 4);
+            const unsigned int qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned int word = qq[j >> 1];
+                const unsigned int sh = (j & 1) * 16;
+                f2 tt;
+                tt.x = (float)((word >> sh) & 0xffu) - 127.37f;
+                tt.y = (float)((word >> (sh + 8)) & 0xffu) - 127.37f;
+                const f2 wv = {w[2 * j], w[2 * j + 1]};
+                const f2 ws = {w[2 * j + 1], w[2 * j]};
+                accA = __builtin_elementwise_fma(tt, wv, accA);
+                accB = __builtin_elementwise_fma(tt, ws, accB);
+            }
+        }
+        red[wave * 64 + lane] = make_float4(accA.x, accA.y, accB.x, accB.y);
+        __syncthreads();
+
+        if (wave == 0) {
+            const float4 r0 = red[lane], r1 = red[64 + lane], r2 = red[128 + lane], r3 = red[192 + lane];
+            const float Dr = ((r0.x + r1.x) + (r2.x + r3.x)) - ((r0.y + r1.y) + (r2.y + r3.y));
+            const float Di = ((r0.z + r1.z) + (r2.z + r3.z)) + ((r0.w + r1.w) + (r2.w + r3.w));
+            const int m = t * ACG_TILE_WIN + lane;
+            if (m < a.nwin) dm_base[(size_t)ch * a.dm_pitch + m] = cabs_like_glibc(Dr, Di);
+        }
+        ch = nch_;
+        t = nt_;
+    }
+}
+
 // Fallback for decimations whose window is not a whole number of 16-byte chunks (M % 8 != 0):
 // one thread per output, sequential accumulation exactly in the reference's order.
 __global__ void fir_u8_generic_kernel(const FirArgs a, int ntaps)
@@ -177,15 +291,42 @@ extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
 {
     const size_t lds = acg_fir_lds_bytes(a);
     static bool attr_set = false;
+    static int variant = 2, num_cu = 256;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)fir_u8_tile_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fir_u8_persist_kernel<false>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fir_u8_persist_kernel<true>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         if (e != hipSuccess) return (int)e;
+        int dev = 0;
+        hipGetDevice(&dev);
+        hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (const char* v = getenv("ACG_FIR_VARIANT")) variant = atoi(v);
         attr_set = true;
     }
-    const unsigned int grid = (unsigned int)a->nch * (unsigned int)a->nseg;
-    hipLaunchKernelGGL(fir_u8_tile_kernel, dim3(grid), dim3(ACG_WG_FIR), lds, (hipStream_t)stream, *a,
-                       a->iq, a->taps, a->stream_of, a->dm);
+    if (variant == 0) {
+        const unsigned int grid = (unsigned int)a->nch * (unsigned int)a->nseg;
+        hipLaunchKernelGGL(fir_u8_tile_kernel, dim3(grid), dim3(ACG_WG_FIR), lds, (hipStream_t)stream, *a,
+                           a->iq, a->taps, a->stream_of, a->dm);
+        return (int)hipGetLastError();
+    }
+    // resident workgroups: LDS-limited (160 KiB per CU), at most 5 (VGPR budget of 4-wave workgroups)
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 5) per_cu = 5;
+    if (per_cu < 1) per_cu = 1;
+    if (const char* v = getenv("ACG_FIR_WG_PER_CU")) per_cu = atoi(v);
+    const long long ntile = (a->nwin + ACG_TILE_WIN - 1) / ACG_TILE_WIN;
+    const long long G = (long long)a->nch * ntile;
+    long long grid = (long long)num_cu * per_cu;
+    if (grid > G) grid = G;
+    if (variant == 1)
+        hipLaunchKernelGGL(fir_u8_persist_kernel<false>, dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds,
+                           (hipStream_t)stream, *a, a->iq, a->taps, a->stream_of, a->dm);
+    else
+        hipLaunchKernelGGL(fir_u8_persist_kernel<true>, dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds,
+                           (hipStream_t)stream, *a, a->iq, a->taps, a->stream_of, a->dm);
     return (int)hipGetLastError();
 }
 

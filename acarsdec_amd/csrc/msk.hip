@@ -58,9 +58,10 @@ __device__ __forceinline__ void put_frame(Lane& L, const MskArgs& a, int ch, uns
 {
     // acars.c:350-369: queue the block.  lvl = 10*log10(MskLvlSum/MskBitCount) is taken on the host
     // from the two operands (same libm call as the reference).
-    const unsigned int slot = leader ? atomicAdd(a.frame_count, 1u) : 0xffffffffu;
-    if (slot < a.frame_cap) {
-        AcgFrameRec* f = a.frames + slot;
+    // the queue is a ring with a monotonic counter: the host consumes behind it (acg_collect_frames)
+    if (leader) {
+        const unsigned int slot = atomicAdd(a.frame_count, 1u);
+        AcgFrameRec* f = a.frames + (slot % a.frame_cap);
         f->chn = ch;
         f->len = L.blen;
         f->err = L.berr;

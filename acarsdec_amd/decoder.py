@@ -131,10 +131,27 @@ class Decoder:
 
     # ---- results ------------------------------------------------------------------------
     def drain_frames(self, max_frames=4096):
-        buf = (K.Frame * max_frames)()
+        """Blocks completed since the last drain as a list of ctypes Frame objects."""
+        n, buf = self.drain_frames_raw(max_frames)
+        return [K.Frame.from_buffer_copy(buf[i]) for i in range(n)]      # copies: the array is reused
+
+    def drain_frames_raw(self, max_frames=4096):
+        """(count, ctypes array): no per-block Python objects; the array is reused by the next call."""
+        if getattr(self, "_fbuf_cap", 0) < max_frames:
+            self._fbuf = (K.Frame * max_frames)()
+            self._fbuf_cap = max_frames
         n = C.c_int(0)
-        _chk(self.ctx, self.L.acg_drain_frames(self.ctx, buf, max_frames, C.byref(n)))
-        return [buf[i] for i in range(n.value)]
+        _chk(self.ctx, self.L.acg_drain_frames(self.ctx, self._fbuf, self._fbuf_cap, C.byref(n)))
+        return n.value, self._fbuf
+
+    def collect_frames_raw(self, lag=1, max_frames=4096):
+        """Streaming drain: blocks of all calls but the `lag` newest; waits only for those calls."""
+        if getattr(self, "_fbuf_cap", 0) < max_frames:
+            self._fbuf = (K.Frame * max_frames)()
+            self._fbuf_cap = max_frames
+        n = C.c_int(0)
+        _chk(self.ctx, self.L.acg_collect_frames(self.ctx, lag, self._fbuf, self._fbuf_cap, C.byref(n)))
+        return n.value, self._fbuf
 
     def bits(self, ch):
         vo = np.zeros(self.bit_cap, dtype=np.float32)

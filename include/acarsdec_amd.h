@@ -105,7 +105,10 @@ int  acg_reset(acg_ctx *ctx);
 /* ---- the hot path ------------------------------------------------------------------------- */
 /* in_callback() for every channel: iq is [nstreams] rows of interleaved u8 I,Q, row r at
  * iq + r*pitch_bytes, each nblocks*1024*decim*2 bytes (rtl.c:330).  *_dev: device pointer,
- * enqueued on hip_stream (NULL = the context's own stream), asynchronous.  *_host copies first. */
+ * asynchronous: the down-converter (the only reader of iq) is enqueued on hip_stream (NULL = the
+ * context's own stream) so later work on that stream may overwrite iq; the demodulator follows on
+ * an internal stream.  Results are complete after acg_sync / acg_drain_frames / acg_collect_frames.
+ * *_host copies first. */
 int  acg_process_iq_u8_dev(acg_ctx *ctx, const uint8_t *iq_dev, size_t pitch_bytes, int nblocks,
 			   void *hip_stream);
 int  acg_process_iq_u8_host(acg_ctx *ctx, const uint8_t *iq_host, size_t pitch_bytes, int nblocks);
@@ -120,8 +123,13 @@ int  acg_fir_only_dev(acg_ctx *ctx, const uint8_t *iq_dev, size_t pitch_bytes, i
 int  acg_sync(acg_ctx *ctx);
 
 /* ---- results ------------------------------------------------------------------------------ */
-/* Blocks completed since the last drain, ordered by (chn, end_bit).  Synchronises. */
+/* Blocks completed since the last drain/collect, ordered by (chn, end_bit).  Waits for ALL
+ * enqueued work of the context. */
 int  acg_drain_frames(acg_ctx *ctx, acg_frame *out, int max_frames, int *nframes);
+/* Streaming variant: hands over the blocks of every process call except the `lag` most recent
+ * ones and waits only for those older calls, so that the newest call(s) keep the GPU busy
+ * (lag = 1: classic double buffering; lag = 0: wait for the last call only).  0 <= lag <= 6. */
+int  acg_collect_frames(acg_ctx *ctx, int lag, acg_frame *out, int max_frames, int *nframes);
 /* Per-bit records of the LAST process call for one channel (needs ACG_F_BITLOG):
  * vo = the value putbit() receives (msk.c:122-126), lvl = cabsf(v) (msk.c:110). */
 int  acg_read_bits(acg_ctx *ctx, int ch, float *vo, float *lvl, int max_bits, int *nbits);
