@@ -350,6 +350,7 @@ static int launch_msk(acg_ctx* c, const float* dm_dev, size_t pitch_floats, int 
     a.nch = g.nch;
     a.len = len;
     a.bit_append = append ? 1 : 0;
+    a.dm_vec_ok = ((((uintptr_t)dm_dev) & 15) == 0 && (pitch_floats % 4) == 0) ? 1 : 0;
     const bool timing = (g.flags & ACG_F_TIMING) != 0;
     EvPair ev{};
     if (timing) {

@@ -195,8 +195,14 @@ template <int LPC>
 __global__ __launch_bounds__(ACG_WG_MSK) void msk_demod_kernel(const MskArgs a)
 {
     constexpr int CPW = ACG_WG_MSK / LPC;          // channels per wave
-    constexpr int SPL = (6 + LPC - 1) / LPC;       // samples per lane per bit period
-    __shared__ float2 ring[FLEN][CPW];             // inb[] of the wave's channels
+    constexpr int SPL = (6 + LPC - 1) / LPC;       // mixer samples per lane per bit period
+    constexpr int WB = 32;                         // dm samples per refill block
+    constexpr int SPB = WB / LPC;                  // dm samples per lane per refill
+    constexpr int WSTR = 2 * WB + 1;               // odd row stride: conflict-free across channel slots
+    // inb[] of the wave's channels, every sample stored twice (k and k+FLEN) so that the 11 taps of
+    // the matched filter are always 11 consecutive rows starting at idx: no wrap, constant offsets
+    __shared__ float2 ring[2 * FLEN][CPW];
+    __shared__ float win[CPW][WSTR];               // sliding window of dm: blocks j and j+1
     __shared__ float hs[FLEN * MFLTOVER + 1];
 
     const int tid = threadIdx.x;
@@ -218,9 +224,12 @@ __global__ __launch_bounds__(ACG_WG_MSK) void msk_demod_kernel(const MskArgs a)
     const long long samp0 = st->nsamp_total;
     if (leader) {
 #pragma unroll
-        for (int j = 0; j < FLEN; ++j) ring[j][slot] = make_float2(st->inb[2 * j], st->inb[2 * j + 1]);
+        for (int j = 0; j < FLEN; ++j) {
+            const float2 x = make_float2(st->inb[2 * j], st->inb[2 * j + 1]);
+            ring[j][slot] = x;
+            ring[j + FLEN][slot] = x;
+        }
     }
-    __syncthreads();
 
     const float* __restrict__ dm = a.dm + (size_t)chc * a.dm_pitch;
     unsigned char* txt = a.txt + (size_t)chc * 256;
@@ -231,15 +240,53 @@ __global__ __launch_bounds__(ACG_WG_MSK) void msk_demod_kernel(const MskArgs a)
     unsigned int idx = L.idx;
     double p = L.phi;
 
-    // dm samples of the coming bit period, one load ahead of their use (the load latency hides
-    // under the previous bit's decision logic): lane g holds dm[n + g + j*LPC]
-    float in_cur[SPL];
+    // ---- dm window: lane g owns samples [g*SPB, (g+1)*SPB) of every 32-sample block.  Blocks 0 and 1
+    // go straight into the window, block 2 waits in registers; from then on, whenever consumption
+    // enters block j, the registers (block j+1, requested 32 samples earlier) replace block j-1 in the
+    // window and block j+2 is requested.  Global-memory latency never sits on the per-bit chain.
+    float pend[SPB];
+    auto fetch_block = [&](int blk) {
+        const int base = blk * WB + g * SPB;
 #pragma unroll
-    for (int j = 0; j < SPL; ++j) in_cur[j] = (g + j * LPC < len) ? dm[g + j * LPC] : 0.f;
+        for (int q = 0; q < SPB; q += 4) {
+            if (SPB >= 4 && a.dm_vec_ok && base + q + 4 <= len) {
+                const float4 v = *(const float4*)(dm + base + q);
+                pend[q] = v.x; pend[q + 1] = v.y; pend[q + 2] = v.z; pend[q + 3] = v.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4 && q + e < SPB; ++e) pend[q + e] = (base + q + e < len) ? dm[base + q + e] : 0.f;
+            }
+        }
+    };
+    auto store_block = [&](int blk) {
+        float* w = &win[slot][(blk & 1) * WB + g * SPB];
+#pragma unroll
+        for (int q = 0; q < SPB; ++q) w[q] = pend[q];
+    };
+    fetch_block(0);
+    store_block(0);
+    fetch_block(1);
+    store_block(1);
+    fetch_block(2);
+    int pend_blk = 2;
+    __syncthreads();
 
     __builtin_amdgcn_s_setprio(3);        // latency-bound serial chain: win issue arbitration
 
     while (__any(n < len)) {
+        // ---- window upkeep (rare: once per 32 samples per channel)
+        if (n >= (pend_blk - 1) * WB && n < len) {
+            store_block(pend_blk);
+            ++pend_blk;
+            fetch_block(pend_blk);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // this period's mixer inputs: lane g takes samples n+g, n+g+LPC, ... (issued now, used in B)
+        float in_cur[SPL];
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) in_cur[j] = win[slot][(n + g + j * LPC) & (2 * WB - 1)];
+
         // ---- A: advance VCO phase and bit clock over this bit period (replicated, sequential)
         const double s = K_VCO + L.df;                                     // msk.c:81
         const double thr = K_3PI2 - s / 2;                                 // msk.c:96
@@ -301,13 +348,6 @@ __global__ __launch_bounds__(ACG_WG_MSK) void msk_demod_kernel(const MskArgs a)
                 if ((u % LPC) == g) myp[u / LPC] = pn;
             }
         }
-        // next period's samples: issue the loads now
-        float in_next[SPL];
-#pragma unroll
-        for (int j = 0; j < SPL; ++j) {
-            const int m = n + cnt + g + j * LPC;
-            in_next[j] = (m < len) ? dm[m] : 0.f;
-        }
         // ---- B: mixer for the cnt samples, spread over the group's lanes (msk.c:86-91)
 #pragma unroll
         for (int j = 0; j < SPL; ++j) {
@@ -318,31 +358,39 @@ __global__ __launch_bounds__(ACG_WG_MSK) void msk_demod_kernel(const MskArgs a)
                 const double in = (double)in_cur[j];
                 unsigned int k = idx + (unsigned int)u;
                 if (k >= FLEN) k -= FLEN;
-                ring[k][slot] = make_float2((float)(in * cs), (float)(in * (-sn)));
+                const float2 x = make_float2((float)(in * cs), (float)(in * (-sn)));
+                ring[k][slot] = x;
+                ring[k + FLEN][slot] = x;
             }
         }
-#pragma unroll
-        for (int j = 0; j < SPL; ++j) in_cur[j] = in_next[j];
         n += cnt;
         idx += (unsigned int)cnt;
         if (idx >= FLEN) idx -= FLEN;
-        __syncthreads();                  // one wave per block: orders the ring writes before the reads
+        // one wave per block: LDS operations of a wave execute in order, so the reads below see the
+        // writes above; only the compiler has to be told not to move them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         // ---- C: bit decision (replicated; side effects by the group leader only)
         if (fired) {
             L.clk = (float)((double)L.clk - K_3PI2);                      // msk.c:100
-            // matched filter, msk.c:103-107
+            // matched filter, msk.c:103-107: taps h[o + 12 j] against inb[(j + idx) % 11], oldest first
             int o = (int)(MFLTOVER * ((double)L.clk / s + 0.5));
             if (o > MFLTOVER) o = MFLTOVER;
             if (o < 0) o = 0;      // memory safety only: the reference indexes h[] out of bounds here
-            float vr = 0.f, vi = 0.f;
-            unsigned int k = idx;
+            const float2* rp = &ring[idx][slot];
+            const float* hp = &hs[o];
+            float2 xs[FLEN];
+            float hv[FLEN];
 #pragma unroll
-            for (int j = 0; j < FLEN; ++j, o += MFLTOVER) {
-                const float hh = hs[o];
-                const float2 x = ring[k][slot];
-                vr = vr + hh * x.x;
-                vi = vi + hh * x.y;
-                k = (k + 1 == FLEN) ? 0 : k + 1;
+            for (int j = 0; j < FLEN; ++j) {
+                xs[j] = rp[j * CPW];
+                hv[j] = hp[j * MFLTOVER];
+            }
+            float vr = 0.f, vi = 0.f;
+#pragma unroll
+            for (int j = 0; j < FLEN; ++j) {
+                vr = vr + hv[j] * xs[j].x;
+                vi = vi + hv[j] * xs[j].y;
             }
             // normalise, msk.c:110-113
             const float lvl = (float)__dsqrt_rn((double)vr * (double)vr + (double)vi * (double)vi);
@@ -368,7 +416,12 @@ __global__ __launch_bounds__(ACG_WG_MSK) void msk_demod_kernel(const MskArgs a)
             L.outbits = (L.outbits >> 1) & 0x7fu;
             if (sv > 0) L.outbits |= 0x80u;
             L.nbits--;
-            if (L.nbits <= 0) decode_acars(L, a, ch, txt, samp0 + n - 1, leader);
+            if (L.nbits <= 0) {
+                // hunting for sync (acars.c:252-265) is the common state: keep it off the big switch
+                const unsigned int r = L.outbits & 0xffu;
+                if (L.astate == WSYN && r != SYN && r != (0xffu & ~SYN)) L.nbits = 1;
+                else decode_acars(L, a, ch, txt, samp0 + n - 1, leader);
+            }
             L.nbit_total++;
             L.S++;
             // PLL filter, msk.c:130 (float constants promoted to double)
