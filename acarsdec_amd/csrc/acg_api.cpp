@@ -166,6 +166,12 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
     // MSK kernel shape: the chip has 1024 SIMDs; give every channel as many lanes as keeps the
     // wave count around one per SIMD (latency mode), down to one lane per channel (throughput mode)
     c->msk_lpc = cfg->nch <= 8192 ? 8 : cfg->nch <= 16384 ? 4 : cfg->nch <= 32768 ? 2 : 1;
+    // pipeline chunk: about 2 GB of input per down-converter launch (launch tails cost a few percent
+    // below that), at most 4 callbacks so that the demodulator can start early
+    {
+        const double per_block = (double)cfg->nstreams * ACG_BLOCK * cfg->decim * 2.0;
+        c->pipe_blocks = std::max(1, std::min(4, (int)(2.0e9 / per_block + 0.5)));
+    }
     if (const char* e = std::getenv("ACG_PIPE_BLOCKS")) c->pipe_blocks = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("ACG_MSK_LPC")) {
         const int v = std::atoi(e);

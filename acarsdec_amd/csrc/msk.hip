@@ -245,17 +245,16 @@ __global__ __launch_bounds__(ACG_WG_MSK) void msk_demod_kernel(const MskArgs a)
     // enters block j, the registers (block j+1, requested 32 samples earlier) replace block j-1 in the
     // window and block j+2 is requested.  Global-memory latency never sits on the per-bit chain.
     float pend[SPB];
+    // branch-free on purpose: any control flow around these loads makes the compiler wait for them
+    // on the spot, which would put the whole HBM round trip back on the per-bit chain.  Samples at or
+    // beyond len are never consumed, so out-of-range indices are simply clamped into the row.
+    const int lim = a.len > 0 ? a.len - 1 : 0;
     auto fetch_block = [&](int blk) {
         const int base = blk * WB + g * SPB;
 #pragma unroll
-        for (int q = 0; q < SPB; q += 4) {
-            if (SPB >= 4 && a.dm_vec_ok && base + q + 4 <= len) {
-                const float4 v = *(const float4*)(dm + base + q);
-                pend[q] = v.x; pend[q + 1] = v.y; pend[q + 2] = v.z; pend[q + 3] = v.w;
-            } else {
-#pragma unroll
-                for (int e = 0; e < 4 && q + e < SPB; ++e) pend[q + e] = (base + q + e < len) ? dm[base + q + e] : 0.f;
-            }
+        for (int q = 0; q < SPB; ++q) {
+            const int i = base + q;
+            pend[q] = dm[i < lim ? i : lim];
         }
     };
     auto store_block = [&](int blk) {
@@ -386,12 +385,17 @@ __global__ __launch_bounds__(ACG_WG_MSK) void msk_demod_kernel(const MskArgs a)
                 xs[j] = rp[j * CPW];
                 hv[j] = hp[j * MFLTOVER];
             }
-            float vr = 0.f, vi = 0.f;
+            // (re, im) ride in one packed register pair: v_pk_mul_f32 then v_pk_add_f32 round exactly
+            // like the two scalar multiplies and adds of the reference (no fusion in this TU)
+            typedef float f2v __attribute__((ext_vector_type(2)));
+            f2v acc = {0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < FLEN; ++j) {
-                vr = vr + hv[j] * xs[j].x;
-                vi = vi + hv[j] * xs[j].y;
+                const f2v x = {xs[j].x, xs[j].y};
+                const f2v hh = {hv[j], hv[j]};
+                acc = acc + hh * x;
             }
+            float vr = acc.x, vi = acc.y;
             // normalise, msk.c:110-113
             const float lvl = (float)__dsqrt_rn((double)vr * (double)vr + (double)vi * (double)vi);
             const double d = (double)lvl + 1e-8;
