@@ -24,28 +24,25 @@ def local_index(channel, world):
     return int(channel) // int(world)
 
 
-def scatter_channel_config(cfg_rows, world, rank, dist=None, src=0):
-    """Rank `src` holds one config row per GLOBAL channel (e.g. [offset_hz, phase, seed]); every
-    rank gets the rows of the channels it owns.  cfg_rows may be None on the other ranks."""
+def scatter_channel_config(cfg_rows, world, rank, dist=None, src=0, device=None):
+    """Rank `src` holds one config row per GLOBAL channel (e.g. [offset_hz, phase, track, id]); every
+    rank ends up with the rows of the channels it owns.  The table is tiny (32 B per channel), so it
+    is sent with the most basic collective -- one broadcast -- and sliced locally; the same code
+    runs over gloo (CPU tests) and RCCL (device tensors).  cfg_rows may be None on other ranks."""
     if world == 1 or dist is None:
-        return np.asarray(cfg_rows)[owned_channels(len(cfg_rows), rank, world)]
-    import torch
-    if rank == src:
         rows = np.asarray(cfg_rows, dtype=np.float64)
-        parts = [torch.from_numpy(np.ascontiguousarray(rows[owned_channels(len(rows), r, world)])) for r in range(world)]
-        shapes = [list(p.shape) for p in parts]
-    else:
-        parts, shapes = None, None
-    box = [shapes]
-    dist.broadcast_object_list(box, src=src)
-    shapes = box[0]
-    out = torch.empty(shapes[rank], dtype=torch.float64)
-    if dist.get_backend() == "nccl":            # RCCL moves device tensors
-        dev = torch.device("cuda", torch.cuda.current_device())
-        out = out.to(dev)
-        parts = [p.to(dev) for p in parts] if parts is not None else None
-    dist.scatter(out, scatter_list=parts if rank == src else None, src=src)
-    return out.cpu().numpy()
+        return rows[owned_channels(len(rows), rank, world)]
+    import torch
+    dev = device if device is not None else torch.device("cpu")
+    shape = torch.zeros(2, dtype=torch.int64, device=dev)
+    if rank == src:
+        rows = np.ascontiguousarray(np.asarray(cfg_rows, dtype=np.float64))
+        shape = torch.tensor(list(rows.shape), dtype=torch.int64, device=dev)
+    dist.broadcast(shape, src=src)
+    n, k = int(shape[0].item()), int(shape[1].item())
+    table = torch.from_numpy(rows).to(dev) if rank == src else torch.empty((n, k), dtype=torch.float64, device=dev)
+    dist.broadcast(table, src=src)
+    return table.cpu().numpy()[owned_channels(n, rank, world)]
 
 
 def gather_blocks(local_blocks, own_ids, world, rank, dist=None, dst=0):

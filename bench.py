@@ -155,7 +155,7 @@ def main():
         off[np.abs(off) < 25000] = 50000.0                             # >= 25 kHz from DC like chooseFc enforces
         cfg_rows = np.stack([off, r0.uniform(0, 2 * np.pi, nch_total), r0.integers(0, NPOOL, nch_total).astype(np.float64),
                              np.arange(nch_total, dtype=np.float64)], axis=1)
-    mine = shard.scatter_channel_config(cfg_rows, world, rank, dist if world > 1 else None)
+    mine = shard.scatter_channel_config(cfg_rows, world, rank, dist if world > 1 else None, device=dev)
     own = shard.owned_channels(nch_total, rank, world)
     assert mine.shape[0] == nch and np.array_equal(mine[:, 3].astype(np.int64), own)
     offs, phases, pool_idx = mine[:, 0], mine[:, 1], mine[:, 2].astype(np.int32)
@@ -209,7 +209,7 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
     # ---- correctness gate on the first pass (state starts from reset): a subset of rank 0's channels
@@ -261,6 +261,17 @@ def main():
         fir_avg_ms = tim["fir_ms"] / max(1, tim["fir_launches"])
         msk_avg_ms = tim["msk_ms"] / max(1, tim["msk_launches"])
         achieved = fir_bytes / (fir_avg_ms * 1e-3) / 1e9
+        # HBM traffic of this launch shape from the committed PMC passes (rocprofv3 cannot run inside the
+        # timed process; see profiles/pmc_traffic.json for the counters and the gfx950 correction)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                for e in json.load(f)["entries"]:
+                    if (e["channels"], e["decim"], e["ntaps"]) == (nch, M, ntaps) and abs(e["blocks_per_launch"] - nblk / lps) < 1e-9 \
+                            and e["kernel"].startswith("fir_u8_persist"):
+                        traffic = e["traffic_bytes"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "acars_channels_x_input_msps",
             "value": round(value, 1),
@@ -281,7 +292,7 @@ def main():
                        "realtime_channels_equiv": int(value / (12500 * M / 1e6)),
                        "preset": args.config, "channels_total": nch_total, "blocks_decoded_timed": int(nfr_total)},
             "roofline": {"bound": "hbm", "kernel": "fir_u8_tile_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "bytes_per_launch": int(fir_bytes), "avg_launch_ms": round(fir_avg_ms, 4), "launches_per_step": lps,
                          "frac_of_measured_copy_ceiling_6290": round(achieved / 6290.0, 4)},
             "kernels": {"fir_ms_per_step": round(tim["fir_ms"] / args.steps, 4), "msk_ms_per_step": round(tim["msk_ms"] / args.steps, 4),
