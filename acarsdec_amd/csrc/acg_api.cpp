@@ -57,6 +57,7 @@ struct acg_ctx {
     unsigned char* d_txt = nullptr;
     AcgFrameRec* d_frames = nullptr;
     unsigned int* d_frame_count = nullptr;
+    unsigned int* d_work = nullptr;     // FIR run dispensers, one word per chunk slot
     float2* d_bits = nullptr;
     int* d_nbits = nullptr;
     void* d_stage = nullptr;        // staging for *_host entry points
@@ -119,7 +120,7 @@ static void free_all(acg_ctx* c)
     if (!c) return;
     hipFree(c->d_taps); hipFree(c->d_stream_of); hipFree(c->d_dm); hipFree(c->d_st);
     hipFree(c->d_h); hipFree(c->d_txt); hipFree(c->d_frames); hipFree(c->d_frame_count);
-    hipFree(c->d_bits); hipFree(c->d_nbits); hipFree(c->d_stage);
+    hipFree(c->d_bits); hipFree(c->d_nbits); hipFree(c->d_stage); hipFree(c->d_work);
     for (auto& p : c->fir_ev) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto& p : c->msk_ev) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : c->ev_pool) hipEventDestroy(e);
@@ -208,6 +209,7 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
         if (cfg->flags & ACG_F_BITLOG)
             HIPCHK(c, hipMalloc(&c->d_bits, nch * (size_t)c->bit_cap * sizeof(float2)));
         HIPCHK(c, hipMalloc(&c->d_nbits, nch * sizeof(int)));
+        HIPCHK(c, hipMalloc(&c->d_work, sizeof(unsigned int) * (size_t)(cfg->max_blocks + 1)));
         HIPCHK(c, hipMemset(c->d_nbits, 0, nch * sizeof(int)));
 
         float h[136] = {0};
@@ -306,6 +308,7 @@ static int launch_fir(acg_ctx* c, const uint8_t* iq_dev, size_t pitch, int nbloc
     a.ntaps_pad = c->ntaps_pad;
     a.nwin = nblocks * ACG_BLOCK;
     a.row_bytes = 2 * g.decim;
+    a.work_counter = c->d_work + block0;         // distinct word per chunk: launches of one call may overlap
     const bool timing = (g.flags & ACG_F_TIMING) != 0;
     EvPair ev{};
     if (timing) {

@@ -59,6 +59,7 @@ struct FirArgs {
     int row_stride;             // LDS row stride in bytes ((row_stride/16) odd)
     int cpr;                    // 16-byte chunks per row = row_bytes/16
     unsigned int cpr_magic;     // ceil(2^20 / cpr): c / cpr == (c * magic) >> 20 for c < 2^11
+    unsigned int* work_counter; // run dispenser of the dynamically scheduled kernel (one word per launch in flight)
 };
 
 struct MskArgs {

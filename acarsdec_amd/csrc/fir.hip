@@ -21,6 +21,7 @@
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 #define FIR_MAXLD 10   // 64 rows * 640 B (M=320) / 16 B / 256 threads
+#define FIR_RUN 4      // tiles per dynamically scheduled run (>= 2)
 
 extern __shared__ __attribute__((aligned(16))) unsigned char fir_smem[];
 
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_tile_kernel(const FirArgs a
 // (channel, tile) space is cut into equal contiguous runs, one per workgroup, so that all workgroups
 // finish together (no partial last wave of workgroups).  A run may cross channel boundaries; the
 // stream/tap base pointers follow.  NT selects non-temporal loads for the input, which is read once.
-template <bool NT>
+template <bool NT, bool DYN>
 __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_persist_kernel(const FirArgs a,
                                                                      const uint8_t* __restrict__ iq_base,
                                                                      const float* __restrict__ taps_base,
@@ -163,9 +164,15 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_persist_kernel(const FirArg
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ntile = (a.nwin + ACG_TILE_WIN - 1) / ACG_TILE_WIN;
     const long long G = (long long)a.nch * ntile;
-    const long long g0 = G * blockIdx.x / gridDim.x;
-    const long long g1 = G * (blockIdx.x + 1) / gridDim.x;
+    // static: equal contiguous runs.  dynamic: runs of FIR_RUN tiles handed out by an atomic counter
+    // (zeroed by the launcher), so that workgroups slowed by co-running demodulator waves simply
+    // take fewer runs instead of stretching the kernel's tail.
+    const long long nrun = (G + FIR_RUN - 1) / FIR_RUN;
+    long long run = blockIdx.x;                       // first run: own id (the counter starts at gridDim.x)
+    long long g0 = DYN ? run * FIR_RUN : G * blockIdx.x / gridDim.x;
+    long long g1 = DYN ? (g0 + FIR_RUN < G ? g0 + FIR_RUN : G) : G * (blockIdx.x + 1) / gridDim.x;
     if (g0 >= g1) return;
+    int* s_next = (int*)(fir_smem + ACG_TILE_WIN * a.row_stride + 4 * 64 * sizeof(float4));
 
     const int cpr = a.cpr;
     const int tile_chunks = ACG_TILE_WIN * cpr;
@@ -207,7 +214,8 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_persist_kernel(const FirArg
     };
 
     fetch(ch, t);
-    for (long long g = g0; g < g1; ++g) {
+    int pending_next = 0;                 // thread 0: id of the next run (valid one barrier after the request)
+    for (long long g = g0;;) {
 #pragma unroll
         for (int i = 0; i < FIR_MAXLD; ++i) {
             if (i < nld) {
@@ -218,11 +226,32 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_persist_kernel(const FirArg
                 }
             }
         }
+        if (DYN) {
+            // first tile of a run: ask for the next run; the answer is published at this barrier
+            // one tile later and read when the last tile of the run prefetches across the run boundary
+            if (g == g0 && tid == 0) pending_next = (int)atomicAdd(a.work_counter, 1u);
+            if (g == g0 + 1 && tid == 0) *s_next = pending_next;
+        }
         __syncthreads();
 
+        // where does the stream go next?
         int nch_ = ch, nt_ = t + 1;
         if (nt_ == ntile) { nt_ = 0; ++nch_; }
-        if (g + 1 < g1) fetch(nch_, nt_);
+        bool more = g + 1 < g1;
+        long long ng0 = g0, ng1 = g1, ng = g + 1;
+        if (DYN && !more) {
+            // (runs are >= 2 tiles except possibly the very last one, which has no successor anyway)
+            const long long nr = (g1 - g0 >= 2) ? (long long)*s_next : nrun;
+            if (nr < nrun) {
+                ng0 = nr * FIR_RUN;
+                ng1 = ng0 + FIR_RUN < G ? ng0 + FIR_RUN : G;
+                ng = ng0;
+                nch_ = (int)(ng0 / ntile);
+                nt_ = (int)(ng0 - (long long)nch_ * ntile);
+                more = true;
+            }
+        }
+        if (more) fetch(nch_, nt_);
 
         const float* __restrict__ taps = taps_base + (size_t)ch * a.ntaps_pad * 2;
         f2 accA = {0.f, 0.f};
@@ -255,8 +284,12 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_persist_kernel(const FirArg
             const int m = t * ACG_TILE_WIN + lane;
             if (m < a.nwin) dm_base[(size_t)ch * a.dm_pitch + m] = cabs_like_glibc(Dr, Di);
         }
+        if (!more) break;
         ch = nch_;
         t = nt_;
+        g = ng;
+        g0 = ng0;
+        g1 = ng1;
     }
 }
 
@@ -284,20 +317,22 @@ __global__ void fir_u8_generic_kernel(const FirArgs a, int ntaps)
 
 extern "C" size_t acg_fir_lds_bytes(const FirArgs* a)
 {
-    return (size_t)ACG_TILE_WIN * a->row_stride + 4 * 64 * sizeof(float4);
+    return (size_t)ACG_TILE_WIN * a->row_stride + 4 * 64 * sizeof(float4) + 16;
 }
 
 extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
 {
     const size_t lds = acg_fir_lds_bytes(a);
     static bool attr_set = false;
-    static int variant = 2, num_cu = 256;
+    static int variant = 3, num_cu = 256;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)fir_u8_tile_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fir_u8_persist_kernel<false>,
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fir_u8_persist_kernel<false, false>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fir_u8_persist_kernel<true>,
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fir_u8_persist_kernel<true, false>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fir_u8_persist_kernel<true, true>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         if (e != hipSuccess) return (int)e;
         int dev = 0;
@@ -321,12 +356,22 @@ extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
     const long long G = (long long)a->nch * ntile;
     long long grid = (long long)num_cu * per_cu;
     if (grid > G) grid = G;
-    if (variant == 1)
-        hipLaunchKernelGGL(fir_u8_persist_kernel<false>, dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds,
+    if (variant == 1) {
+        hipLaunchKernelGGL((fir_u8_persist_kernel<false, false>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds,
                            (hipStream_t)stream, *a, a->iq, a->taps, a->stream_of, a->dm);
-    else
-        hipLaunchKernelGGL(fir_u8_persist_kernel<true>, dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds,
+    } else if (variant == 2) {
+        hipLaunchKernelGGL((fir_u8_persist_kernel<true, false>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds,
                            (hipStream_t)stream, *a, a->iq, a->taps, a->stream_of, a->dm);
+    } else {
+        const long long nrun = (G + FIR_RUN - 1) / FIR_RUN;
+        if (grid > nrun) grid = nrun;
+        // the run counter starts behind the statically assigned first runs
+        const unsigned int first = (unsigned int)grid;
+        hipError_t e = hipMemsetD32Async((hipDeviceptr_t)a->work_counter, (int)first, 1, (hipStream_t)stream);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((fir_u8_persist_kernel<true, true>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds,
+                           (hipStream_t)stream, *a, a->iq, a->taps, a->stream_of, a->dm);
+    }
     return (int)hipGetLastError();
 }
 
