@@ -1,0 +1,143 @@
+"""BASELINE.json's full sizes on the GPU, checked through size-independent properties (the oracle
+would need minutes per run at these sizes; 24 channels of every bench run go through it anyway):
+
+  * replication: channels fed the SAME bytes and taps produce identical dm, bits and blocks
+    (a checksum of checksums over 1024 / 4096 channels);
+  * chunking: one call of 4 callbacks == 4 calls of 1 callback == any pipeline chunking, bit for bit;
+  * permutation: permuting which channel reads which stream permutes the outputs;
+  * a sample of channels equals the oracle exactly (blocks) at full width.
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    from acarsdec_amd import decoder as D, synth as S, _capi as K
+    from oracle import oracle as O
+    assert K.load().acg_device_count() > 0
+    return torch, D, S, K, O
+
+
+def make_streams(S, nsrc, nblk, M, seed):
+    rng = np.random.default_rng(seed)
+    rows, offs = [], []
+    for i in range(nsrc):
+        a, _ = S.channel_audio(rng, nblk * 1024, gap=(250, 700), text_len=(1, 12))
+        off = float(rng.integers(-40, 41) * 25000 or 50000)
+        rows.append(S.iq_u8_from_envelopes(0.5 * (1 + 0.5 * a)[None, :], M, [off], phases=[rng.uniform(0, 6)],
+                                           noise=0.02, rng=rng))
+        offs.append(off)
+    return np.stack(rows), offs
+
+
+def digest(dec, nch, nout):
+    """per-channel sha1 over (dm, bit records) + blocks"""
+    counts, vo, lvl = dec.bits_all()
+    out = []
+    for c in range(nch):
+        h = hashlib.sha1()
+        h.update(dec.dm(c, nout).tobytes())
+        h.update(vo[c, :counts[c]].tobytes())
+        h.update(lvl[c, :counts[c]].tobytes())
+        out.append(h.hexdigest())
+    return out
+
+
+@pytest.mark.parametrize("nch,M,ntaps,nblk", [(1024, 200, 200, 2), (4096, 200, 192, 1)])
+def test_replicated_channels_agree_and_match_oracle(env, nch, M, ntaps, nblk):
+    """configs[2] / configs[4] width: nsrc distinct streams, every channel reads stream c % nsrc with the
+    taps of that stream -> all replicas identical; the nsrc originals equal the oracle (blocks)."""
+    torch, D, S, K, O = env
+    nsrc = 8
+    iq, offs = make_streams(S, nsrc, nblk, M, 4242 + nch)
+    win = np.ones(ntaps) if ntaps == M else np.hamming(ntaps) / np.hamming(ntaps).mean() * (M / ntaps)
+    base = [(D.rtl_taps(131000000 + int(o), 131000000, M)[:ntaps] * win[:, None]).astype(np.float32) for o in offs]
+    dec = D.Decoder(nch, decim=M, ntaps=ntaps, nstreams=nsrc, max_blocks=nblk)
+    dec.set_taps(np.stack([base[c % nsrc] for c in range(nch)]))
+    dec.set_channel_streams([c % nsrc for c in range(nch)])
+    dec.in_callback(iq)
+    frames = dec.drain_frames(max_frames=16 * nch)
+    by = {}
+    for f in frames:
+        by.setdefault(int(f.chn), []).append(D.frame_tuple(f)[1:])
+    nout = nblk * 1024
+    counts, vo, lvl = dec.bits_all()
+    ref_dm = [dec.dm(c, nout) for c in range(nsrc)]
+    # replicas: sampled densely for dm (D2H per channel), exhaustively for bits and blocks
+    for c in range(nsrc, nch):
+        s = c % nsrc
+        assert counts[c] == counts[s]
+        assert np.array_equal(vo[c, :counts[c]], vo[s, :counts[s]]) and np.array_equal(lvl[c, :counts[c]], lvl[s, :counts[s]])
+        assert by.get(c, []) == by.get(s, []), c
+    for c in list(range(nsrc, nch, 97)) + [nch - 1]:
+        assert np.array_equal(dec.dm(c, nout), ref_dm[c % nsrc])
+    total = 0
+    for s in range(nsrc):
+        ch = O.Channel(s)
+        ch.demod(O.fir_u8(iq[s], M, base[s], ntaps=ntaps))
+        assert by.get(s, []) == [O.frame_tuple(f)[1:] for f in ch.frames]
+        total += len(ch.frames)
+    assert total >= (1 if nblk >= 2 else 0)
+    dec.close()
+
+
+def test_chunking_and_pipeline_invariance_1024(env, monkeypatch):
+    """1024 channels x 2.5 Msps: 1 call x 4 callbacks == 4 calls x 1 callback == pipeline chunk 1/2/off."""
+    torch, D, S, K, O = env
+    nch, M, nblk, nsrc = 1024, 200, 4, 16
+    iq, offs = make_streams(S, nsrc, nblk, M, 99)
+    taps = np.stack([D.rtl_taps(131000000 + int(offs[c % nsrc]), 131000000, M) for c in range(nch)])
+    smap = [(c * 7) % nsrc for c in range(nch)]
+    taps = np.stack([D.rtl_taps(131000000 + int(offs[s]), 131000000, M) for s in smap])
+    row = 1024 * M * 2
+    results = []
+    for mode in ("one", "four", "pipe0", "pipe2"):
+        if mode.startswith("pipe"):
+            monkeypatch.setenv("ACG_PIPE_BLOCKS", mode[4:])
+        else:
+            monkeypatch.delenv("ACG_PIPE_BLOCKS", raising=False)
+        dec = D.Decoder(nch, decim=M, nstreams=nsrc, max_blocks=nblk)
+        dec.set_taps(taps)
+        dec.set_channel_streams(smap)
+        blocks = []
+        if mode == "four":
+            for k in range(nblk):
+                dec.in_callback(np.ascontiguousarray(iq[:, k * row:(k + 1) * row]))
+                blocks += [D.frame_tuple(f) for f in dec.drain_frames(max_frames=8 * nch)]
+        else:
+            dec.in_callback(iq)
+            blocks += [D.frame_tuple(f) for f in dec.drain_frames(max_frames=8 * nch)]
+        st = [dec.state(c) for c in range(0, nch, 37)]
+        key = [(s["MskPhi"], s["MskDf"], s["MskClk"], s["MskS"], s["idx"], s["nbits"], s["Acarsstate"], s["inb"].tobytes()) for s in st]
+        results.append((sorted(blocks), key))
+        dec.close()
+    for r in results[1:]:
+        assert r[0] == results[0][0]
+        assert r[1] == results[0][1]          # state doubles bit-identical: same arithmetic, any chunking
+    assert len(results[0][0]) > nch // 8
+
+
+def test_stream_permutation_permutes_outputs(env):
+    torch, D, S, K, O = env
+    nch, M, nblk = 256, 160, 1
+    iq, offs = make_streams(S, 4, nblk, M, 7)
+    rng = np.random.default_rng(1)
+    smap = rng.integers(0, 4, size=nch)
+    perm = rng.permutation(nch)
+    outs = []
+    for order in (np.arange(nch), perm):
+        sm = smap[order]
+        dec = D.Decoder(nch, decim=M, nstreams=4, max_blocks=nblk)
+        dec.set_taps(np.stack([D.rtl_taps(131000000 + int(offs[s]), 131000000, M) for s in sm]))
+        dec.set_channel_streams(sm.tolist())
+        dec.in_callback(iq)
+        outs.append(digest(dec, nch, 1024))
+        dec.close()
+    assert [outs[0][p] for p in perm] == outs[1]
