@@ -45,6 +45,7 @@ def build_lib(force=False):
         ("fir.hip", ["-O3"]),
         ("msk.hip", ["-O3", "-ffp-contract=off"]),      # keep the reference's separate mul/add roundings
         ("synth.hip", ["-O3"]),
+        ("blk.hip", ["-O3"]),
         ("acg_api.cpp", ["-O2"]),
     ]
     objs = []

@@ -15,6 +15,7 @@
 
 extern "C" void acg_host_msk_h(float* h);
 extern "C" float acg_host_level_db(double lvlsum, int bitcount);
+extern "C" void acg_host_crc_tables(unsigned short* crc, unsigned short* synd);
 
 namespace {
 
@@ -58,6 +59,8 @@ struct acg_ctx {
     AcgFrameRec* d_frames = nullptr;
     unsigned int* d_frame_count = nullptr;
     unsigned int* d_work = nullptr;     // FIR run dispensers, one word per chunk slot
+    unsigned short* d_crctab = nullptr; // [256] + syndromes [1936] (ACG_F_REPAIR)
+    unsigned int* d_rep_upto = nullptr; // blocks already through the repair kernel
     float2* d_bits = nullptr;
     int* d_nbits = nullptr;
     void* d_stage = nullptr;        // staging for *_host entry points
@@ -120,7 +123,7 @@ static void free_all(acg_ctx* c)
     if (!c) return;
     hipFree(c->d_taps); hipFree(c->d_stream_of); hipFree(c->d_dm); hipFree(c->d_st);
     hipFree(c->d_h); hipFree(c->d_txt); hipFree(c->d_frames); hipFree(c->d_frame_count);
-    hipFree(c->d_bits); hipFree(c->d_nbits); hipFree(c->d_stage); hipFree(c->d_work);
+    hipFree(c->d_bits); hipFree(c->d_nbits); hipFree(c->d_stage); hipFree(c->d_work); hipFree(c->d_crctab); hipFree(c->d_rep_upto);
     for (auto& p : c->fir_ev) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto& p : c->msk_ev) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : c->ev_pool) hipEventDestroy(e);
@@ -212,6 +215,14 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
         HIPCHK(c, hipMalloc(&c->d_work, sizeof(unsigned int) * (size_t)(cfg->max_blocks + 1)));
         HIPCHK(c, hipMemset(c->d_nbits, 0, nch * sizeof(int)));
 
+        if (cfg->flags & ACG_F_REPAIR) {
+            std::vector<unsigned short> tabs(256 + 8 * 242);
+            acg_host_crc_tables(tabs.data(), tabs.data() + 256);
+            HIPCHK(c, hipMalloc(&c->d_crctab, tabs.size() * sizeof(unsigned short)));
+            HIPCHK(c, hipMemcpy(c->d_crctab, tabs.data(), tabs.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+            HIPCHK(c, hipMalloc(&c->d_rep_upto, sizeof(unsigned int)));
+            HIPCHK(c, hipMemset(c->d_rep_upto, 0, sizeof(unsigned int)));
+        }
         float h[136] = {0};
         acg_host_msk_h(h);                               // msk.c:44-48
         HIPCHK(c, hipMemcpy(c->d_h, h, sizeof(h), hipMemcpyHostToDevice));
@@ -249,6 +260,7 @@ extern "C" int acg_reset(acg_ctx* ctx)
     for (auto& s : st) s.nbits = 8;
     HIPCHK(ctx, hipMemcpy(ctx->d_st, st.data(), st.size() * sizeof(AcgChan), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemset(ctx->d_frame_count, 0, sizeof(unsigned int)));
+    if (ctx->d_rep_upto) HIPCHK(ctx, hipMemset(ctx->d_rep_upto, 0, sizeof(unsigned int)));
     int zr = zero_sync(ctx, ctx->d_nbits, (size_t)ctx->cfg.nch * sizeof(int));
     if (zr != ACG_OK) return zr;
     ctx->last_len = 0;
@@ -411,6 +423,11 @@ extern "C" int acg_fir_only_dev(acg_ctx* ctx, const uint8_t* iq_dev, size_t pitc
 static int end_of_call(acg_ctx* ctx)
 {
     const int slot = (int)(ctx->call_seq % acg_ctx::NCALL);
+    if (ctx->d_crctab) {          // ACG_F_REPAIR: the block thread's work on whatever this call queued
+        const int e = acg_launch_blk_repair(ctx->d_frames, ctx->frame_cap, ctx->d_frame_count, ctx->d_rep_upto,
+                                            ctx->d_crctab + 256, ctx->d_crctab, ctx->msk_stream);
+        if (e != 0) return fail(ctx, ACG_EHIP, "block repair launch failed");
+    }
     HIPCHK(ctx, hipMemcpyAsync(&ctx->h_call_count[slot], ctx->d_frame_count, sizeof(unsigned int),
                                hipMemcpyDeviceToHost, ctx->msk_stream));
     HIPCHK(ctx, hipEventRecord(ctx->call_done[slot], ctx->msk_stream));
@@ -555,9 +572,11 @@ static int fetch_frames(acg_ctx* ctx, unsigned int upto, acg_frame* out, int max
     std::sort(rec.begin(), rec.end(), [](const AcgFrameRec& a, const AcgFrameRec& b) {
         return a.chn != b.chn ? a.chn < b.chn : a.end_bit < b.end_bit;
     });
+    unsigned int kept = 0;
     for (unsigned int i = 0; i < take; ++i) {
         const AcgFrameRec& r = rec[i];
-        acg_frame& f = out[i];
+        if (r.status == 2) continue;                              // dropped by the block repair (acars.c:124-207)
+        acg_frame& f = out[kept++];
         std::memset(&f, 0, sizeof(f));
         f.chn = r.chn;
         f.len = r.len;
@@ -569,6 +588,7 @@ static int fetch_frames(acg_ctx* ctx, unsigned int upto, acg_frame* out, int max
         f.end_bit = r.end_bit;
         f.end_sample = r.end_sample;
     }
+    take = kept;
     *nframes = (int)take;
     if (rc != ACG_OK) return fail(ctx, rc, "frame queue overflow");
     return ACG_OK;

@@ -39,7 +39,8 @@ struct AcgFrameRec {
     long long end_bit;
     long long end_sample;
     unsigned char crc[2];
-    unsigned char pad[6];
+    unsigned char status;       // 0 raw (as queued by decodeAcars), 1 processed + kept, 2 processed + dropped
+    unsigned char pad[5];
     unsigned char txt[256];     // 16-byte aligned, 16-byte multiples for vector copies
 };
 
@@ -88,6 +89,8 @@ int acg_launch_fir(const FirArgs* a, void* stream);
 int acg_launch_fir_generic(const FirArgs* a, void* stream);
 size_t acg_fir_lds_bytes(const FirArgs* a);
 int acg_launch_msk(const MskArgs* a, int lanes_per_channel, void* stream);
+int acg_launch_blk_repair(AcgFrameRec* frames, unsigned int cap, const unsigned int* count, unsigned int* done_upto,
+                          const unsigned short* synd, const unsigned short* crctab, void* stream);
 int acg_launch_sincos_selftest(const double* x, double* s, double* c, int n, void* stream);
 int acg_launch_synth_iq(uint8_t* iq, size_t pitch, int nrows, int nout, int decim, const float* env,
                         size_t env_pitch, const int* env_index, const float* off_hz, const float* phase,

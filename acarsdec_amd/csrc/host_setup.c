@@ -83,3 +83,24 @@ float acg_host_level_db(double lvlsum, int bitcount)
 {
 	return 10 * log10(lvlsum / bitcount);          /* acars.c:351, double narrowed to float */
 }
+
+/* syndrom.h:15-49 (reflected CRC-CCITT byte table, poly 0x8408) and syndrom.h:52-295 (entry i + 8k =
+ * remainder of a single wrong bit i in the byte followed by k more bytes), generated from their
+ * definitions.  crc[256], synd[8*242]. */
+void acg_host_crc_tables(unsigned short *crc, unsigned short *synd)
+{
+	int i, k, j;
+	for (i = 0; i < 256; i++) {
+		unsigned short c = (unsigned short)i;
+		for (k = 0; k < 8; k++)
+			c = (c & 1) ? (unsigned short)((c >> 1) ^ 0x8408) : (unsigned short)(c >> 1);
+		crc[i] = c;
+	}
+	for (k = 0; k < 242; k++)
+		for (i = 0; i < 8; i++) {
+			unsigned short s = crc[1 << i];
+			for (j = 0; j < k; j++)
+				s = (unsigned short)((s >> 8) ^ crc[s & 0xff]);
+			synd[8 * k + i] = s;
+		}
+}

@@ -71,6 +71,7 @@ __device__ __forceinline__ void put_frame(Lane& L, const MskArgs& a, int ch, uns
         f->end_sample = sample_index;
         f->crc[0] = (unsigned char)L.crc0;
         f->crc[1] = crc1;
+        f->status = 0;
         const uint4* s = (const uint4*)txt;
         uint4* d = (uint4*)f->txt;
         const int nv = (L.blen + 15) >> 4;

@@ -52,6 +52,31 @@ def acars_frame(text=b"", mode=b"2", addr=b".N12345", ack=b"\x15", label=b"H1", 
     return head + body_p + bytes([crc & 0xFF, crc >> 8]) + bytes([DEL])
 
 
+def corrupt_frame(frame, rng, kind):
+    """Flip bits of a transmission (bytes from acars_frame) the way a noisy channel would, to exercise
+    the block thread's repair (acars.c:39-215).  Only text/CRC bytes are touched (index >= 5, before DEL):
+      'p1','p2','p3','p4' : that many single-bit errors in distinct text bytes (parity errors)
+      'db'                : two bits in one text byte (parity stays odd, CRC fails -> fixdberr)
+      'crc'               : one bit in a CRC byte
+      'p1crc'             : one parity error + one CRC-byte bit (unrepairable by construction)"""
+    b = bytearray(frame)
+    text = list(range(6, len(b) - 4))        # after SOH+mode, before ETX/CRC/DEL; keeps framing bytes intact
+    if kind in ("p1", "p2", "p3", "p4", "p1crc"):
+        n = int(kind[1])
+        for i in rng.choice(text, size=n, replace=False):
+            b[int(i)] ^= 1 << int(rng.integers(0, 8))
+        if kind == "p1crc":
+            b[len(b) - 3] ^= 1 << int(rng.integers(0, 8))
+            b[len(b) - 2] ^= 1 << int(rng.integers(0, 8))
+    elif kind == "db":
+        i = int(rng.choice(text))
+        x, y = rng.choice(8, size=2, replace=False)
+        b[i] ^= (1 << int(x)) | (1 << int(y))
+    elif kind == "crc":
+        b[len(b) - 2 - int(rng.integers(0, 2))] ^= 1 << int(rng.integers(0, 8))
+    return bytes(b)
+
+
 def random_text(rng, nmin=20, nmax=220):
     n = int(rng.integers(nmin, nmax + 1))
     return bytes(rng.integers(0x20, 0x7F, size=n).astype(np.uint8).tolist())
@@ -80,7 +105,7 @@ def msk_audio(bits, lead=0, trail=0, rate=INTRATE, phase0=0.0):
     return np.concatenate([np.zeros(lead), a, np.zeros(trail)])
 
 
-def channel_audio(rng, nsamp, nframes=None, gap=(3000, 12500), text_len=(20, 220)):
+def channel_audio(rng, nsamp, nframes=None, gap=(3000, 12500), text_len=(20, 220), corrupt=None):
     """A 12.5 kHz audio track of length nsamp with random ACARS frames separated by
     silence (un-modulated carrier).  Returns (audio float64 [nsamp], list of frame bytes)."""
     out = np.zeros(nsamp)
@@ -94,6 +119,11 @@ def channel_audio(rng, nsamp, nframes=None, gap=(3000, 12500), text_len=(20, 220
                          addr=b"." + bytes(rng.integers(0x41, 0x5B, size=6).astype(np.uint8).tolist()),
                          label=bytes(rng.integers(0x30, 0x3A, size=2).astype(np.uint8).tolist()),
                          bid=bytes([int(rng.integers(0x30, 0x3A))]))
+        if corrupt is not None:
+            kinds = corrupt if isinstance(corrupt, (list, tuple)) else [corrupt]
+            k = kinds[len(frames) % len(kinds)]
+            if k:
+                fr = corrupt_frame(fr, rng, k)
         a = msk_audio(frame_bits(fr), phase0=float(rng.uniform(0, 2 * np.pi)))
         if pos + len(a) + 64 > nsamp:
             break

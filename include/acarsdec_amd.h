@@ -44,6 +44,10 @@ extern "C" {
 /* acg_config.flags */
 #define ACG_F_BITLOG    1u        /* keep per-bit {soft symbol, level} records of each call */
 #define ACG_F_TIMING    2u        /* bracket kernels with HIP events (acg_get_timing) */
+#define ACG_F_REPAIR    4u        /* run the block thread's check/repair (acars.c:93-215) on the device:
+                                     drain/collect then return what outputmsg() receives -- parity/CRC
+                                     verified or repaired, parity stripped, err = parity errors found --
+                                     and omit the blocks the reference drops */
 
 typedef struct acg_ctx acg_ctx;
 

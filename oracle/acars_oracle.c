@@ -445,3 +445,125 @@ int orc_frame_check(const orc_frame *f)
 		return pn;
 	return crc ? -2 : 0;
 }
+
+/* ------------------------------------------------------------------ */
+/* acars.c:39-215: the block thread's parity / CRC check and repair     */
+/* ------------------------------------------------------------------ */
+
+#define NSYND (8 * 242)
+static unsigned short g_synd[NSYND];
+static int g_synd_ready;
+
+/* syndrom.h:52-295 is not a free-standing table: entry i + 8k is the CRC remainder produced by
+ * flipping bit i of the byte that is followed by k more bytes (text or CRC) -- one pass of that
+ * single bit through the CRC register, then k zero bytes.  Generated here instead of copied. */
+void orc_syndrome_table(unsigned short *out, int n)
+{
+	int i, k, j;
+	if (!g_crc_ready)
+		crc_init();
+	for (k = 0; k * 8 < n; k++)
+		for (i = 0; i < 8 && k * 8 + i < n; i++) {
+			unsigned short s = g_crc_tab[1 << i];
+			for (j = 0; j < k; j++)
+				s = (unsigned short)((s >> 8) ^ g_crc_tab[s & 0xff]);
+			out[k * 8 + i] = s;
+		}
+}
+
+static void synd_init(void)
+{
+	orc_syndrome_table(g_synd, NSYND);
+	g_synd_ready = 1;
+}
+
+static int fixprerr(unsigned char *txt, int len, unsigned short crc, const int *pr, int pn)   /* acars.c:39-64 */
+{
+	int i;
+	if (pn > 0) {
+		for (i = 0; i < 8; i++) {
+			if (fixprerr(txt, len, crc ^ g_synd[i + 8 * (len - *pr + 1)], pr + 1, pn - 1)) {
+				txt[*pr] ^= (1 << i);
+				return 1;
+			}
+		}
+		return 0;
+	}
+	if (crc == 0)
+		return 1;
+	for (i = 0; i < 2 * 8; i++)
+		if (g_synd[i] == crc)
+			return 1;
+	return 0;
+}
+
+static int fixdberr(unsigned char *txt, int len, unsigned short crc)                           /* acars.c:66-90 */
+{
+	int i, j, k;
+	for (i = 0; i < 2 * 8; i++)
+		if (g_synd[i] == crc)
+			return 1;
+	for (k = 0; k < len; k++) {
+		int bo = 8 * (len - k + 1);
+		for (i = 0; i < 8; i++)
+			for (j = 0; j < 8; j++) {
+				if (i == j)
+					continue;
+				if ((crc ^ g_synd[i + bo] ^ g_synd[j + bo]) == 0) {
+					txt[k] ^= (1 << i);
+					txt[k] ^= (1 << j);
+					return 1;
+				}
+			}
+	}
+	return 0;
+}
+
+/* acars.c:123-207: returns 1 and fills *out with what outputmsg() receives (repaired, parity
+ * stripped, err = number of parity errors found), or 0 if the block is dropped. */
+int orc_blk_process(const orc_frame *in, orc_frame *out)
+{
+	int i, pn;
+	unsigned short crc;
+	int pr[MAXPERR];
+
+	if (!g_synd_ready)
+		synd_init();
+	*out = *in;
+	if (out->len < 13)                                      /* acars.c:124 */
+		return 0;
+	out->txt[12] &= (ETX | 0x02);                           /* acars.c:132-133 force STX/ETX */
+	out->txt[12] |= (ETX & 0x02);
+	pn = 0;                                                 /* acars.c:136-144 */
+	for (i = 0; i < out->len; i++) {
+		if ((popcount8(out->txt[i]) & 1) == 0) {
+			if (pn < MAXPERR)
+				pr[pn] = i;
+			pn++;
+		}
+	}
+	if (pn > MAXPERR)                                       /* acars.c:145 */
+		return 0;
+	out->err = pn;
+	crc = 0;                                                /* acars.c:159-165 */
+	for (i = 0; i < out->len; i++)
+		crc = orc_crc_update(crc, out->txt[i]);
+	crc = orc_crc_update(crc, out->crc[0]);
+	crc = orc_crc_update(crc, out->crc[1]);
+	if (pn) {                                               /* acars.c:170-192 */
+		if (fixprerr(out->txt, out->len, crc, pr, pn) == 0)
+			return 0;
+	} else if (crc) {
+		if (fixdberr(out->txt, out->len, crc) == 0)
+			return 0;
+	}
+	pn = 0;                                                 /* acars.c:195-207 */
+	for (i = 0; i < out->len; i++) {
+		if ((popcount8(out->txt[i]) & 1) == 0)
+			pn++;
+		out->txt[i] &= 0x7f;
+	}
+	if (pn)
+		return 0;
+	return 1;
+}

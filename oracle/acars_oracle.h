@@ -96,6 +96,10 @@ void orc_in_callback(orc_chan *chs, int nch, const uint8_t *iq, int nout, int M,
  * -1 = dropped (too short), -2 = crc error with clean parity. */
 int orc_frame_check(const orc_frame *f);
 unsigned short orc_crc_update(unsigned short crc, unsigned char c);   /* syndrom.h:49 */
+/* syndrom.h:52-295 regenerated from its definition (n <= 1936 entries) */
+void orc_syndrome_table(unsigned short *out, int n);
+/* acars.c:123-207 blk_thread body: 1 + *out = the block outputmsg() gets, 0 = dropped */
+int orc_blk_process(const orc_frame *in, orc_frame *out);
 
 #ifdef __cplusplus
 }

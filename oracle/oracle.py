@@ -73,6 +73,9 @@ def lib():
         L.orc_frame_check.restype = C.c_int
         L.orc_crc_update.argtypes = [C.c_ushort, C.c_ubyte]
         L.orc_crc_update.restype = C.c_ushort
+        L.orc_syndrome_table.argtypes = [C.c_void_p, C.c_int]
+        L.orc_blk_process.argtypes = [C.POINTER(OrcFrame), C.POINTER(OrcFrame)]
+        L.orc_blk_process.restype = C.c_int
         _orc = L
     return _orc
 
@@ -145,6 +148,18 @@ def fir_u8(iq, M, wf, nout=None, ntaps=None):
     dm = np.zeros(nout, dtype=np.float32)
     lib().orc_fir_u8(iq.ctypes.data, nout, M, ntaps, wf.ctypes.data, dm.ctypes.data)
     return dm
+
+
+def syndrome_table(n=1936):
+    t = np.zeros(n, dtype=np.uint16)
+    lib().orc_syndrome_table(t.ctypes.data, n)
+    return t
+
+
+def blk_process(frame):
+    """acars.c:123-207 on one raw block: returns the processed OrcFrame or None if dropped."""
+    out = OrcFrame()
+    return out if lib().orc_blk_process(C.byref(frame), C.byref(out)) else None
 
 
 def crc_ccitt(data, crc=0):

@@ -378,6 +378,47 @@ def test_streaming_collect_equals_blocking_drain(D, O, S):
     assert sum(len(v) for v in results[0].values()) >= nch
 
 
+# ------------------------------------------------------------------------------------ block repair on the device
+def test_device_block_repair_matches_oracle_and_golden(D, O, S, testwav, golden):
+    """ACG_F_REPAIR: what drain returns equals what the reference's blk_thread hands to outputmsg():
+    repaired text, parity stripped, err = parity errors found, dropped blocks omitted."""
+    # (1) the reference's own data: the 7 processed blocks of test.wav
+    dec = D.Decoder(4, decim=8, ntaps=8, max_blocks=53, repair=True)
+    x = np.zeros((4, 53 * 1024), dtype=np.float32)
+    x[:, :testwav.shape[0]] = testwav.T
+    dec.demod_msk(x)
+    got = sorted(D.frame_tuple(f) for f in dec.drain_frames())
+    want = sorted(t for t, _ in golden_blocks(golden["file"]["out_blocks"]))
+    assert got == want and len(got) == 7
+    dec.close()
+    # (2) transmissions with injected bit errors: every repair path and every drop path
+    rng = np.random.default_rng(31337)
+    kinds = [None, "p1", "p2", "p3", "db", "crc", "p4", "p1crc"]
+    nch, n = 16, 48 * 1024
+    x = np.zeros((nch, n), dtype=np.float32)
+    for c in range(nch):
+        a, _ = S.channel_audio(rng, n, gap=(1200, 2500), text_len=(15, 50), corrupt=kinds[c % 8:] + kinds[:c % 8])
+        x[c] = S.envelope(a, noise=0.002, rng=rng)
+    dec = D.Decoder(nch, decim=8, ntaps=8, max_blocks=48, repair=True)
+    got = []
+    for k in range(0, n, 16 * 1024):                      # several calls: the repair runs per call
+        dec.demod_msk(x[:, k:k + 16 * 1024])
+        got += [D.frame_tuple(f) for f in dec.drain_frames()]
+    dec.close()
+    want, nraw, nfixed = [], 0, 0
+    for c in range(nch):
+        ch = O.Channel(c, max_frames=512)
+        ch.demod(x[c])
+        for f in ch.frames:
+            nraw += 1
+            o = O.blk_process(f)
+            if o is not None:
+                want.append(O.frame_tuple(o))
+                nfixed += o.err > 0
+    assert sorted(got) == sorted(want)
+    assert nraw > len(want) and nfixed >= 10 and len(want) >= 40, (nraw, len(want), nfixed)
+
+
 # ------------------------------------------------------------------------------------ the legacy call surface
 def test_compat_program_output_is_golden(golden, tmp_path):
     """The reference's UNCHANGED acarsdec.c/acars.c/output.c linked against compat_msk.c

@@ -78,6 +78,56 @@ print(json.dumps(res))
 '''
 
 
+REPAIR_CHILD = r'''
+import sys, json
+import numpy as np
+sys.path.insert(0, %(root)r)
+from oracle import oracle as O
+from acarsdec_amd import synth as S
+seed = int(sys.argv[1])
+rng = np.random.default_rng(seed)
+kinds = [None, "p1", "p2", "p3", "db", "crc", "p4", "p1crc"]
+nch, n = 4, 200000
+ref = O.Ref(); ref.init_file(nch)
+chs = [O.Channel(c, max_frames=512) for c in range(nch)]
+for c in range(nch):
+    a, sent = S.channel_audio(rng, n, gap=(1500, 3000), text_len=(15, 60), corrupt=kinds[c:] + kinds[:c])
+    x = S.envelope(a, noise=0.002, rng=rng)
+    for s in range(0, n, 4096):
+        ref.demod(c, x[s:s+4096]); chs[c].demod(x[s:s+4096])
+ref.drain()
+def tup(f): return [int(f.chn), int(f.len), int(f.err), bytes(f.crc).hex(), bytes(f.txt[:f.len]).hex(), float(f.lvl).hex()]
+raw = [f for c in chs for f in c.frames]
+mine = sorted(tup(o) for o in (O.blk_process(f) for f in raw) if o is not None)
+theirs = sorted(tup(f) for f in ref.out_frames())
+nraw = len(raw)
+print(json.dumps(dict(ok=mine == theirs, nraw=nraw, nout=len(theirs), nmine=len(mine),
+                      repaired=sum(1 for t in theirs if t[2] > 0), raw_equal=sorted(tup(f) for f in raw) == sorted(tup(f) for f in ref.raw_frames()))))
+'''
+
+
+@pytest.mark.parametrize("seed", [5, 6])
+def test_block_repair_identical_to_reference_blk_thread(seed):
+    """acars.c:39-215 (parity/CRC check, fixprerr, fixdberr, parity strip) on transmissions with injected
+    bit errors: what reaches outputmsg() is identical, block for block, drops included."""
+    r = subprocess.run([sys.executable, "-c", REPAIR_CHILD % dict(root=ROOT), str(seed)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["raw_equal"] and res["ok"], res
+    assert res["nraw"] >= 40 and res["nout"] < res["nraw"] and res["repaired"] >= 8, res
+
+
+def test_syndrome_table_regenerated_equals_reference_header():
+    import re
+    path = "/root/reference/syndrom.h"
+    if not os.path.exists(path):
+        pytest.skip("reference tree not present")
+    txt = open(path).read()
+    body = txt[txt.index("static const unsigned short syndrom[]"):]
+    vals = np.array([int(x, 16) for x in re.findall(r"0x[0-9a-fA-F]+", body)], dtype=np.uint16)
+    assert vals.size == 1936 and np.array_equal(vals, O.syndrome_table(1936))
+
+
 def run_child(mode, seed):
     r = subprocess.run([sys.executable, "-c", CHILD % dict(root=ROOT), mode, str(seed)], capture_output=True, text=True,
                        timeout=600)
