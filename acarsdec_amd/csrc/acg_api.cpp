@@ -48,6 +48,7 @@ struct acg_ctx {
     unsigned int frame_cap = 0;
     int last_len = 0;               // samples per channel of the last demod call
     int msk_lpc = 8;                // lanes per channel in the MSK kernel
+    int msk_high_prio = 1;
     bool last_had_demod = false;
 
     float* d_taps = nullptr;
@@ -177,6 +178,8 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
         c->pipe_blocks = std::max(1, std::min(4, (int)(2.0e9 / per_block + 0.5)));
     }
     if (const char* e = std::getenv("ACG_PIPE_BLOCKS")) c->pipe_blocks = std::max(0, std::atoi(e));
+    c->msk_high_prio = cfg->nch <= 2048 ? 1 : 0;
+    if (const char* e = std::getenv("ACG_MSK_PRIO")) c->msk_high_prio = std::atoi(e) ? 1 : 0;
     if (const char* e = std::getenv("ACG_MSK_LPC")) {
         const int v = std::atoi(e);
         if (v == 1 || v == 2 || v == 4 || v == 8) c->msk_lpc = v;
@@ -186,7 +189,21 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
     auto body = [&]() -> int {
         HIPCHK(c, hipSetDevice(cfg->device));
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        HIPCHK(c, hipStreamCreateWithFlags(&c->msk_stream, hipStreamNonBlocking));
+        {
+            // Optionally confine the demodulator to a subset of CUs (ACG_MSK_CUS=n, ACG_MSK_CU_STRIDE=s):
+            // its few long-running high-priority waves then disturb the down-converter on those CUs only.
+            const char* e = std::getenv("ACG_MSK_CUS");
+            const int ncu = e ? std::atoi(e) : 0;
+            if (ncu > 0 && ncu < 256) {
+                const char* es = std::getenv("ACG_MSK_CU_STRIDE");
+                const int stride = es ? std::max(1, std::atoi(es)) : 256 / ncu;
+                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int i = 0, cu = 0; i < ncu && cu < 256; ++i, cu += stride) mask[cu >> 5] |= 1u << (cu & 31);
+                HIPCHK(c, hipExtStreamCreateWithCUMask(&c->msk_stream, 8, mask));
+            } else {
+                HIPCHK(c, hipStreamCreateWithFlags(&c->msk_stream, hipStreamNonBlocking));
+            }
+        }
         HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         HIPCHK(c, hipEventCreateWithFlags(&c->in_ev, hipEventDisableTiming));
         c->fir_done.resize((size_t)cfg->max_blocks);
@@ -371,6 +388,7 @@ static int launch_msk(acg_ctx* c, const float* dm_dev, size_t pitch_floats, int 
     a.nch = g.nch;
     a.len = len;
     a.bit_append = append ? 1 : 0;
+    a.high_prio = c->msk_high_prio;
     a.dm_vec_ok = ((((uintptr_t)dm_dev) & 15) == 0 && (pitch_floats % 4) == 0) ? 1 : 0;
     const bool timing = (g.flags & ACG_F_TIMING) != 0;
     EvPair ev{};

@@ -78,6 +78,7 @@ struct MskArgs {
     int nch;
     int len;                    // samples per channel this launch
     int bit_append;             // 0: bit records start at 0; 1: append after nbits_out[ch] (same call)
+    int high_prio;              // raise wave priority (latency mode)
     int dm_vec_ok;              // dm rows are 16-byte aligned: the window refill may use float4 loads
 };
 

@@ -271,7 +271,9 @@ __global__ __launch_bounds__(ACG_WG_MSK) void msk_demod_kernel(const MskArgs a)
     int pend_blk = 2;
     __syncthreads();
 
-    __builtin_amdgcn_s_setprio(3);        // latency-bound serial chain: win issue arbitration
+    // few channels: this serial chain is the critical path of the whole job -> win issue arbitration;
+    // many channels: the down-converter is, and these waves have slack -> stay at normal priority
+    if (a.high_prio) __builtin_amdgcn_s_setprio(3);
 
     while (__any(n < len)) {
         // ---- window upkeep (rare: once per 32 samples per channel)
