@@ -25,6 +25,23 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 extern __shared__ __attribute__((aligned(16))) unsigned char fir_smem[];
 
+// The run dispenser is an atomic whose result is needed a whole tile later.  Written as a compiler
+// intrinsic it is waited for on the spot (it sits in divergent control flow), which stalls the
+// requesting wave -- and at the next barrier the whole workgroup -- for a full device-scope round
+// trip per run.  As inline asm the compiler does not track it; take_ticket() is the matching wait
+// (vmcnt retires in order, and it is called where no newer load is outstanding).
+__device__ __forceinline__ void request_ticket(unsigned int* counter, unsigned int& ticket)
+{
+    const unsigned int one = 1u;
+    asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(counter), "v"(one) : "memory");
+}
+__device__ __forceinline__ unsigned int take_ticket(unsigned int& ticket)
+{
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket) : : "memory");
+    return ticket;
+}
+
+
 __device__ __forceinline__ float cabs_like_glibc(float re, float im)
 {
     // glibc 2.35 cabsf/hypotf == (float)sqrt((double)x*x + (double)y*y) (checked on 2e8 inputs);
@@ -214,7 +231,7 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_persist_kernel(const FirArg
     };
 
     fetch(ch, t);
-    int pending_next = 0;                 // thread 0: id of the next run (valid one barrier after the request)
+    unsigned int pending_next = 0;        // thread 0: id of the next run (valid one barrier after the request)
     for (long long g = g0;;) {
 #pragma unroll
         for (int i = 0; i < FIR_MAXLD; ++i) {
@@ -229,8 +246,8 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_persist_kernel(const FirArg
         if (DYN) {
             // first tile of a run: ask for the next run; the answer is published at this barrier
             // one tile later and read when the last tile of the run prefetches across the run boundary
-            if (g == g0 && tid == 0) pending_next = (int)atomicAdd(a.work_counter, 1u);
-            if (g == g0 + 1 && tid == 0) *s_next = pending_next;
+            if (g == g0 && tid == 0) request_ticket(a.work_counter, pending_next);
+            if (g == g0 + 1 && tid == 0) *s_next = (int)take_ticket(pending_next);
         }
         __syncthreads();
 
@@ -293,6 +310,124 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_persist_kernel(const FirArg
     }
 }
 
+// LDS-DMA variant (rows that are an odd number of 16-byte slots, e.g. M = 200: no padding needed, so the
+// LDS image of a tile is the linear image of its bytes in HBM).  `global_load_lds_dwordx4 ... nt` moves
+// 1 KiB per wave-instruction straight into LDS: no staging VGPRs, no ds_write pass, one barrier per
+// tile.  Two tile buffers: the DMA of tile t+1 lands while tile t is computed.  Same run dispenser as
+// the register-staged kernel.  LDS: 2 tiles + 2 reduction buffers -> 2 workgroups per CU.
+__global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_dma_kernel(const FirArgs a,
+                                                                 const uint8_t* __restrict__ iq_base,
+                                                                 const float* __restrict__ taps_base,
+                                                                 const int* __restrict__ stream_of,
+                                                                 float* __restrict__ dm_base)
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntile = (a.nwin + ACG_TILE_WIN - 1) / ACG_TILE_WIN;
+    const long long G = (long long)a.nch * ntile;
+    const long long nrun = (G + FIR_RUN - 1) / FIR_RUN;
+    long long g0 = (long long)blockIdx.x * FIR_RUN;
+    long long g1 = g0 + FIR_RUN < G ? g0 + FIR_RUN : G;
+    if (g0 >= g1) return;
+
+    const int cpr = a.cpr;                               // odd
+    const int tile_bytes = ACG_TILE_WIN * a.row_bytes;   // = cpr KiB
+    const int total_chunks = a.nwin * cpr;
+    unsigned char* buf0 = fir_smem;
+    float4* red = (float4*)(fir_smem + 2 * tile_bytes);  // [2][4][64]
+    int* s_next = (int*)(fir_smem + 2 * tile_bytes + 2 * 4 * 64 * sizeof(float4));
+    const int nck = a.ntaps_pad >> 3;
+    const int c0 = nck * wave / 4;
+    const int c1 = nck * (wave + 1) / 4;
+
+    int ch = (int)(g0 / ntile);
+    int t = (int)(g0 - (long long)ch * ntile);
+
+    auto issue = [&](int fch, int ft, int b) {
+        const uint8_t* __restrict__ src = iq_base + (size_t)stream_of[fch] * a.pitch;
+        const int base = ft * ACG_TILE_WIN * cpr;
+        unsigned char* dst = buf0 + b * tile_bytes;
+        for (int q = wave; q < cpr; q += 4) {            // wave-uniform: 1 KiB per instruction
+            int c = base + q * 64 + lane;
+            if (c >= total_chunks) c = total_chunks - 1;  // partial last tile: rows nobody stores
+            // inline asm: as a builtin the compiler orders every later ds_read behind it with vmcnt(0)
+            const unsigned char* gp = src + ((size_t)c << 4);
+            const unsigned int ldst = __builtin_amdgcn_readfirstlane((unsigned int)(uintptr_t)(dst + q * 1024));
+            unsigned int keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(gp), "s"(ldst) : "memory");
+        }
+    };
+
+    issue(ch, t, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    unsigned int pending_next = 0;
+    for (long long g = g0;;) {
+        if (g == g0 && tid == 0) request_ticket(a.work_counter, pending_next);
+        int nch_ = ch, nt_ = t + 1;
+        if (nt_ == ntile) { nt_ = 0; ++nch_; }
+        bool more = g + 1 < g1;
+        long long ng0 = g0, ng1 = g1, ng = g + 1;
+        if (!more) {
+            const long long nr = (g1 - g0 >= 2) ? (long long)*s_next : nrun;
+            if (nr < nrun) {
+                ng0 = nr * FIR_RUN;
+                ng1 = ng0 + FIR_RUN < G ? ng0 + FIR_RUN : G;
+                ng = ng0;
+                nch_ = (int)(ng0 / ntile);
+                nt_ = (int)(ng0 - (long long)nch_ * ntile);
+                more = true;
+            }
+        }
+        if (more) issue(nch_, nt_, cur ^ 1);
+
+        const float* __restrict__ taps = taps_base + (size_t)ch * a.ntaps_pad * 2;
+        f2 accA = {0.f, 0.f};
+        f2 accB = {0.f, 0.f};
+        const unsigned char* rowp = buf0 + cur * tile_bytes + lane * a.row_bytes;
+        for (int c = c0; c < c1; ++c) {
+            const uint4 q = *(const uint4*)(rowp + (c << 4));
+            const float* __restrict__ w = taps + (c << 4);
+            const unsigned int qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned int word = qq[j >> 1];
+                const unsigned int sh = (j & 1) * 16;
+                f2 tt;
+                tt.x = (float)((word >> sh) & 0xffu) - 127.37f;
+                tt.y = (float)((word >> (sh + 8)) & 0xffu) - 127.37f;
+                const f2 wv = {w[2 * j], w[2 * j + 1]};
+                const f2 ws = {w[2 * j + 1], w[2 * j]};
+                accA = __builtin_elementwise_fma(tt, wv, accA);
+                accB = __builtin_elementwise_fma(tt, ws, accB);
+            }
+        }
+        float4* rd = red + cur * 256;
+        rd[wave * 64 + lane] = make_float4(accA.x, accA.y, accB.x, accB.y);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the next tile has landed
+        if (g == g0 && tid == 0) *s_next = (int)take_ticket(pending_next);     // published by the barrier below
+        __syncthreads();
+
+        if (wave == 0) {
+            const float4 r0 = rd[lane], r1 = rd[64 + lane], r2 = rd[128 + lane], r3 = rd[192 + lane];
+            const float Dr = ((r0.x + r1.x) + (r2.x + r3.x)) - ((r0.y + r1.y) + (r2.y + r3.y));
+            const float Di = ((r0.z + r1.z) + (r2.z + r3.z)) + ((r0.w + r1.w) + (r2.w + r3.w));
+            const int m = t * ACG_TILE_WIN + lane;
+            if (m < a.nwin) dm_base[(size_t)ch * a.dm_pitch + m] = cabs_like_glibc(Dr, Di);
+        }
+        if (!more) break;
+        ch = nch_;
+        t = nt_;
+        g = ng;
+        g0 = ng0;
+        g1 = ng1;
+        cur ^= 1;
+    }
+}
+
 // Fallback for decimations whose window is not a whole number of 16-byte chunks (M % 8 != 0):
 // one thread per output, sequential accumulation exactly in the reference's order.
 __global__ void fir_u8_generic_kernel(const FirArgs a, int ntaps)
@@ -334,6 +469,8 @@ extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fir_u8_persist_kernel<true, true>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fir_u8_dma_kernel,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (e != hipSuccess) return (int)e;
         int dev = 0;
         hipGetDevice(&dev);
@@ -346,6 +483,25 @@ extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
         hipLaunchKernelGGL(fir_u8_tile_kernel, dim3(grid), dim3(ACG_WG_FIR), lds, (hipStream_t)stream, *a,
                            a->iq, a->taps, a->stream_of, a->dm);
         return (int)hipGetLastError();
+    }
+    if (variant == 4 && (a->cpr & 1) && a->row_stride == a->row_bytes) {
+        const size_t tile = (size_t)ACG_TILE_WIN * a->row_bytes;
+        const size_t lds2 = 2 * tile + 2 * 4 * 64 * sizeof(float4) + 16;
+        if (lds2 <= 96 * 1024) {
+            int per = (int)((160 * 1024) / lds2);
+            if (per > 4) per = 4;
+            if (const char* v = getenv("ACG_FIR_WG_PER_CU")) per = atoi(v);
+            const long long ntile4 = (a->nwin + ACG_TILE_WIN - 1) / ACG_TILE_WIN;
+            const long long G4 = (long long)a->nch * ntile4;
+            const long long nrun4 = (G4 + FIR_RUN - 1) / FIR_RUN;
+            long long grid4 = (long long)num_cu * per;
+            if (grid4 > nrun4) grid4 = nrun4;
+            hipError_t e = hipMemsetD32Async((hipDeviceptr_t)a->work_counter, (int)grid4, 1, (hipStream_t)stream);
+            if (e != hipSuccess) return (int)e;
+            hipLaunchKernelGGL(fir_u8_dma_kernel, dim3((unsigned int)grid4), dim3(ACG_WG_FIR), lds2, (hipStream_t)stream,
+                               *a, a->iq, a->taps, a->stream_of, a->dm);
+            return (int)hipGetLastError();
+        }
     }
     // resident workgroups: LDS-limited (160 KiB per CU), at most 5 (VGPR budget of 4-wave workgroups)
     int per_cu = (int)((160 * 1024) / lds);
