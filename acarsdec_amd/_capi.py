@@ -9,6 +9,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libacarsdec_amd.so")
 OK, EINVAL, ENOMEM, EHIP, ENODEV, EOVERFLOW, ESTATE = 0, -1, -2, -3, -4, -5, -6
 F_BITLOG, F_TIMING, F_REPAIR = 1, 2, 4
 INTRATE, BLOCK, MAXDECIM, FLEN, TXTMAX = 12500, 1024, 320, 11, 250
+FMT_CS16, FMT_S16_SPLIT, FMT_F32_REAL = 1, 2, 3
 
 
 class Config(C.Structure):
@@ -50,6 +51,9 @@ SYMBOLS = {
     "acg_process_dm_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "acg_fir_only_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "acg_sync": (C.c_int, [C.c_void_p]),
+    "acg_soapy_taps": (C.c_int, [C.c_float, C.c_int, C.c_int, C.c_void_p]),
+    "acg_process_samples_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]),
+    "acg_feed_samples_host": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
     "acg_drain_frames": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.c_int, C.POINTER(C.c_int)]),
     "acg_collect_frames": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Frame), C.c_int, C.POINTER(C.c_int)]),
     "acg_read_bits": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),

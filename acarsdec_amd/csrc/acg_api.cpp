@@ -65,6 +65,8 @@ struct acg_ctx {
     float2* d_bits = nullptr;
     int* d_nbits = nullptr;
     void* d_stage = nullptr;        // staging for *_host entry points
+    int feed_fmt = 0;               // acg_feed_samples_host: format and samples of the incomplete window carried
+    size_t feed_fill = 0;
     size_t stage_bytes = 0;
 
     std::vector<EvPair> fir_ev, msk_ev;
@@ -269,6 +271,7 @@ extern "C" int acg_reset(acg_ctx* ctx)
     HIPCHK(ctx, hipDeviceSynchronize());
     ctx->consumed = 0;
     ctx->call_seq = 0;
+    ctx->feed_fill = 0;
     std::fill(ctx->msk_done_valid.begin(), ctx->msk_done_valid.end(), 0);
     // initMsk (msk.c:34-41): MskPhi = MskClk = MskS = MskDf = idx = 0, inb zeroed;
     // static storage: MskLvlSum = MskBitCount = 0; initAcars (acars.c:230-234): outbits 0, nbits 8, WSYN
@@ -765,6 +768,142 @@ extern "C" int acg_get_timing(acg_ctx* ctx, double* fir_ms, int* fir_launches, d
     int r = sum(ctx->fir_ev, fir_ms, fir_launches);
     if (r != ACG_OK) return r;
     return sum(ctx->msk_ev, msk_ms, msk_launches);
+}
+
+// ------------------------------------------------------------------------------------------
+// The other front ends' sample formats: soapy.c (CS16), sdrplay.c (split int16),
+// air.c (real f32).  Same tile kernel, 4 bytes per input sample.
+static int fmt_geometry(acg_ctx* ctx, int fmt, FirArgs* a, int nwin)
+{
+    const acg_config& g = ctx->cfg;
+    if (fmt < ACG_FMT_CS16 || fmt > ACG_FMT_F32_REAL) return fail(ctx, ACG_EINVAL, "unknown sample format");
+    if (g.decim % (fmt == ACG_FMT_S16_SPLIT ? 8 : 4) || g.decim > 208)
+        return fail(ctx, ACG_EINVAL, "this sample format needs decim % 4 == 0 (8 for split planes) and decim <= 208");
+    std::memset(a, 0, sizeof(*a));
+    a->stream_of = ctx->d_stream_of;
+    a->taps = ctx->d_taps;
+    a->dm = ctx->d_dm;
+    a->dm_pitch = ctx->dm_pitch;
+    a->nch = g.nch;
+    a->decim = g.decim;
+    a->ntaps_pad = ctx->ntaps_pad;
+    a->nwin = nwin;
+    a->row_bytes = 4 * g.decim;
+    a->cpr = a->row_bytes / 16;
+    a->row_stride = (a->cpr & 1) ? a->row_bytes : a->row_bytes + 16;
+    a->cpr_magic = ((1u << 20) + (unsigned int)a->cpr - 1) / (unsigned int)a->cpr;
+    a->nseg = 1;
+    a->out_scale = fmt == ACG_FMT_CS16 ? 1.0f / 32768.0f : fmt == ACG_FMT_S16_SPLIT ? 0.25f : 1.0f;
+    a->work_counter = ctx->d_work;
+    return ACG_OK;
+}
+
+// FIR(fmt) on stream s, then the demodulator on the context's stream; one call = one chunk
+static int run_fmt(acg_ctx* ctx, int fmt, FirArgs* a, hipStream_t s)
+{
+    const int nblk_guard = std::min(ctx->cfg.max_blocks, (a->nwin + ACG_BLOCK - 1) / ACG_BLOCK);
+    for (int j = 0; j < nblk_guard; ++j)
+        if (ctx->msk_done_valid[(size_t)j]) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->msk_done[(size_t)j], 0));
+    const bool timing = (ctx->cfg.flags & ACG_F_TIMING) != 0;
+    EvPair ev{};
+    if (timing) {
+        int r;
+        if ((r = get_event(ctx, &ev.a)) != ACG_OK || (r = get_event(ctx, &ev.b)) != ACG_OK) return r;
+        HIPCHK(ctx, hipEventRecord(ev.a, s));
+    }
+    const int e = acg_launch_fir_fmt(a, fmt, s);
+    if (e != 0) {
+        ctx->err = std::string("FIR launch: ") + hipGetErrorString((hipError_t)e);
+        return ACG_EHIP;
+    }
+    if (timing) {
+        HIPCHK(ctx, hipEventRecord(ev.b, s));
+        ctx->fir_ev.push_back(ev);
+    }
+    HIPCHK(ctx, hipEventRecord(ctx->fir_done[0], s));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->msk_stream, ctx->fir_done[0], 0));
+    int r = launch_msk(ctx, ctx->d_dm, ctx->dm_pitch, a->nwin, ctx->msk_stream, false);
+    if (r != ACG_OK) return r;
+    for (int j = 0; j < nblk_guard; ++j) {
+        HIPCHK(ctx, hipEventRecord(ctx->msk_done[(size_t)j], ctx->msk_stream));
+        ctx->msk_done_valid[(size_t)j] = 1;
+    }
+    ctx->last_len = a->nwin;
+    return end_of_call(ctx);
+}
+
+extern "C" int acg_process_samples_dev(acg_ctx* ctx, int fmt, const void* dev, size_t pitch_bytes, size_t plane_bytes,
+                                       int nblocks, void* hip_stream)
+{
+    if (!ctx || !dev) return ACG_EINVAL;
+    if (nblocks < 1 || nblocks > ctx->cfg.max_blocks) return fail(ctx, ACG_EINVAL, "nblocks out of range");
+    if ((((uintptr_t)dev | pitch_bytes | plane_bytes) & 15)) return fail(ctx, ACG_EINVAL, "base, pitch and plane must be 16-byte aligned");
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    FirArgs a;
+    int r = fmt_geometry(ctx, fmt, &a, nblocks * ACG_BLOCK);
+    if (r != ACG_OK) return r;
+    a.iq = (const uint8_t*)dev;
+    a.pitch = pitch_bytes;
+    a.plane = plane_bytes;
+    return run_fmt(ctx, fmt, &a, hip_stream ? (hipStream_t)hip_stream : ctx->stream);
+}
+
+// Host feed with carry: windows may straddle feeds of any size (soapy.c:232-254, sdrplay.c:215-236,
+// air.c:299-338 carry D / the index across buffers; here the incomplete window's SAMPLES wait at the
+// head of a device staging row -- the sums are then the same sequential windows).
+extern "C" int acg_feed_samples_host(acg_ctx* ctx, int fmt, const void* p0, const void* p1, size_t pitch_samples,
+                                     size_t nsamples)
+{
+    if (!ctx || !p0 || (fmt == ACG_FMT_S16_SPLIT && !p1)) return ACG_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    FirArgs a;
+    int r = fmt_geometry(ctx, fmt, &a, 0);
+    if (r != ACG_OK) return r;
+    if (ctx->feed_fmt != fmt) { ctx->feed_fmt = fmt; ctx->feed_fill = 0; }
+    const acg_config& g = ctx->cfg;
+    const size_t M = (size_t)g.decim;
+    const size_t bps = fmt == ACG_FMT_S16_SPLIT ? 2 : 4;                     // bytes per sample per plane
+    const size_t cap = (size_t)ctx->max_len * M;                              // samples a staging row holds (<= max_len windows per launch)
+    const size_t plane = ((cap * bps) + 15) & ~(size_t)15;
+    const size_t rowb = fmt == ACG_FMT_S16_SPLIT ? 2 * plane : plane;
+    if ((r = ensure_stage(ctx, rowb * (size_t)g.nstreams)) != ACG_OK) return r;
+    hipStream_t s = ctx->stream;
+    size_t done = 0;
+    while (done < nsamples) {
+        const size_t take = std::min(nsamples - done, cap - ctx->feed_fill);
+        unsigned char* base = (unsigned char*)ctx->d_stage;
+        // new samples behind the carried ones
+        HIPCHK(ctx, hipMemcpy2DAsync(base + ctx->feed_fill * bps, rowb, (const unsigned char*)p0 + done * bps,
+                                     (g.nstreams > 1 ? pitch_samples : nsamples) * bps, take * bps, (size_t)g.nstreams,
+                                     hipMemcpyHostToDevice, s));
+        if (fmt == ACG_FMT_S16_SPLIT)
+            HIPCHK(ctx, hipMemcpy2DAsync(base + plane + ctx->feed_fill * bps, rowb, (const unsigned char*)p1 + done * bps,
+                                         (g.nstreams > 1 ? pitch_samples : nsamples) * bps, take * bps, (size_t)g.nstreams,
+                                         hipMemcpyHostToDevice, s));
+        HIPCHK(ctx, hipStreamSynchronize(s));          // the caller's buffers may be reused after return
+        done += take;
+        const size_t have = ctx->feed_fill + take;
+        const size_t nwin = have / M;
+        if (nwin > 0) {
+            a.nwin = (int)nwin;
+            a.iq = base;
+            a.pitch = rowb;
+            a.plane = plane;
+            if ((r = run_fmt(ctx, fmt, &a, s)) != ACG_OK) return r;
+            const size_t left = have - nwin * M;
+            if (left) {                                // < M <= nwin*M samples: source and destination never overlap
+                HIPCHK(ctx, hipMemcpy2DAsync(base, rowb, base + nwin * M * bps, rowb, left * bps, (size_t)g.nstreams,
+                                             hipMemcpyDeviceToDevice, s));
+                if (fmt == ACG_FMT_S16_SPLIT)
+                    HIPCHK(ctx, hipMemcpy2DAsync(base + plane, rowb, base + plane + nwin * M * bps, rowb, left * bps,
+                                                 (size_t)g.nstreams, hipMemcpyDeviceToDevice, s));
+            }
+            ctx->feed_fill = left;
+        } else {
+            ctx->feed_fill = have;
+        }
+    }
+    return ACG_OK;
 }
 
 extern "C" int acg_selftest_sincos(const double* x_host, double* sin_host, double* cos_host, int n)

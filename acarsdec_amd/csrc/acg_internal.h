@@ -60,6 +60,8 @@ struct FirArgs {
     int row_stride;             // LDS row stride in bytes ((row_stride/16) odd)
     int cpr;                    // 16-byte chunks per row = row_bytes/16
     unsigned int cpr_magic;     // ceil(2^20 / cpr): c / cpr == (c * magic) >> 20 for c < 2^11
+    size_t plane;               // FMT_SPLIT: byte distance from a stream's I plane to its Q plane
+    float out_scale;            // power-of-two scale applied to |D| (1, 1/32768 soapy.c:241, 1/4 sdrplay.c:225)
     unsigned int* work_counter; // run dispenser of the dynamically scheduled kernel (one word per launch in flight)
 };
 
@@ -88,6 +90,7 @@ extern "C" {
 // kernel launchers (fir.hip / msk.hip / synth.hip); stream is a hipStream_t
 int acg_launch_fir(const FirArgs* a, void* stream);
 int acg_launch_fir_generic(const FirArgs* a, void* stream);
+int acg_launch_fir_fmt(const FirArgs* a, int fmt, void* stream);     // fmt: 1 CS16, 2 split int16 planes, 3 real f32
 size_t acg_fir_lds_bytes(const FirArgs* a);
 int acg_launch_msk(const MskArgs* a, int lanes_per_channel, void* stream);
 int acg_launch_blk_repair(AcgFrameRec* frames, unsigned int cap, const unsigned int* count, unsigned int* done_upto,

@@ -428,6 +428,200 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_dma_kernel(const FirArgs a,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The other front ends' sample formats: same tile scheme, 4 bytes per input sample.
+//   FMT_CS16   interleaved int16 I,Q        soapy.c:238-241   (x/32768 folded into the output scale)
+//   FMT_SPLIT  int16 I plane + int16 Q plane sdrplay.c:219-223 (cabsf(D)/4 = output scale)
+//   FMT_F32R   real float32 samples          air.c:314-324     (complex tap x real sample)
+// A row (one window) is 4*M bytes in LDS; for FMT_SPLIT it is [I half | Q half].  Static contiguous
+// partition of the (channel, tile) space, non-temporal loads, taps through scalar loads.
+#define FMT_CS16 1
+#define FMT_SPLIT 2
+#define FMT_F32R 3
+#define FMT_MAXLD 14   // 64 rows * 832 B (M = 208) / 16 B / 256 threads
+
+template <int FMT>
+__global__ __launch_bounds__(ACG_WG_FIR) void fir_fmt_kernel(const FirArgs a,
+                                                              const uint8_t* __restrict__ in_base,
+                                                              const float* __restrict__ taps_base,
+                                                              const int* __restrict__ stream_of,
+                                                              float* __restrict__ dm_base)
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntile = (a.nwin + ACG_TILE_WIN - 1) / ACG_TILE_WIN;
+    const long long G = (long long)a.nch * ntile;
+    const long long g0 = G * blockIdx.x / gridDim.x;
+    const long long g1 = G * (blockIdx.x + 1) / gridDim.x;
+    if (g0 >= g1) return;
+
+    const int cpr = a.cpr;                              // 16-byte chunks per LDS row
+    const int half = cpr >> 1;                          // FMT_SPLIT: chunks per plane row
+    const int tile_chunks = ACG_TILE_WIN * cpr;
+    const int pad = a.row_stride - a.row_bytes;
+    const unsigned int magic = a.cpr_magic;
+    unsigned char* tileL = fir_smem;
+    float4* red = (float4*)(fir_smem + ACG_TILE_WIN * a.row_stride);
+    constexpr int SPC = (FMT == FMT_SPLIT) ? 8 : 4;     // samples (taps) per inner step
+    const int nstep = a.ntaps_pad / SPC;
+    const int c0 = nstep * wave / 4;
+    const int c1 = nstep * (wave + 1) / 4;
+    const int nld = (tile_chunks + ACG_WG_FIR - 1) / ACG_WG_FIR;
+
+    int ch = (int)(g0 / ntile);
+    int t = (int)(g0 - (long long)ch * ntile);
+    uint4 stage[FMT_MAXLD];
+
+    auto fetch = [&](int fch, int ft) {
+        const uint8_t* __restrict__ src = in_base + (size_t)stream_of[fch] * a.pitch;
+        typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int i = 0; i < FMT_MAXLD; ++i) {
+            if (i < nld) {
+                const int c = tid + i * ACG_WG_FIR;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (c < tile_chunks) {
+                    const int r = (int)(((unsigned int)c * magic) >> 20);
+                    const int col = c - r * cpr;
+                    const int win = ft * ACG_TILE_WIN + r;
+                    if (win < a.nwin) {
+                        size_t off;
+                        if (FMT == FMT_SPLIT)           // I plane, then Q plane a.plane bytes further
+                            off = (col < half) ? (size_t)win * (a.row_bytes >> 1) + ((size_t)col << 4)
+                                               : a.plane + (size_t)win * (a.row_bytes >> 1) + ((size_t)(col - half) << 4);
+                        else
+                            off = (size_t)win * a.row_bytes + ((size_t)col << 4);
+                        const u4v x = __builtin_nontemporal_load((const u4v*)(src + off));
+                        v = make_uint4(x.x, x.y, x.z, x.w);
+                    }
+                }
+                stage[i] = v;
+            }
+        }
+    };
+
+    fetch(ch, t);
+    for (long long g = g0; g < g1; ++g) {
+#pragma unroll
+        for (int i = 0; i < FMT_MAXLD; ++i) {
+            if (i < nld) {
+                const int c = tid + i * ACG_WG_FIR;
+                if (c < tile_chunks) {
+                    const int r = (int)(((unsigned int)c * magic) >> 20);
+                    *(uint4*)(tileL + (c << 4) + r * pad) = stage[i];
+                }
+            }
+        }
+        __syncthreads();
+        int nch_ = ch, nt_ = t + 1;
+        if (nt_ == ntile) { nt_ = 0; ++nch_; }
+        if (g + 1 < g1) fetch(nch_, nt_);
+
+        const float* __restrict__ taps = taps_base + (size_t)ch * a.ntaps_pad * 2;
+        f2 accA = {0.f, 0.f};       // CS16/SPLIT: (sum r*wr, sum g*wi)   F32R: (sum s*wr, sum s*wi)
+        f2 accB = {0.f, 0.f};       // CS16/SPLIT: (sum r*wi, sum g*wr)
+        const unsigned char* rowp = tileL + lane * a.row_stride;
+        for (int c = c0; c < c1; ++c) {
+            const float* __restrict__ w = taps + c * SPC * 2;                  // wave-uniform
+            if (FMT == FMT_CS16) {
+                const uint4 q = *(const uint4*)(rowp + (c << 4));
+                const unsigned int qq[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f2 tt;
+                    tt.x = (float)(short)(qq[j] & 0xffffu);                    // soapy.c:238
+                    tt.y = (float)((int)qq[j] >> 16);                          // soapy.c:239
+                    const f2 wv = {w[2 * j], w[2 * j + 1]};
+                    const f2 ws = {w[2 * j + 1], w[2 * j]};
+                    accA = __builtin_elementwise_fma(tt, wv, accA);
+                    accB = __builtin_elementwise_fma(tt, ws, accB);
+                }
+            } else if (FMT == FMT_SPLIT) {
+                const uint4 qi = *(const uint4*)(rowp + (c << 4));
+                const uint4 qq_ = *(const uint4*)(rowp + ((c + half) << 4));
+                const unsigned int xi[4] = {qi.x, qi.y, qi.z, qi.w};
+                const unsigned int xq[4] = {qq_.x, qq_.y, qq_.z, qq_.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    f2 tt;
+                    tt.x = (j & 1) ? (float)((int)xi[j >> 1] >> 16) : (float)(short)(xi[j >> 1] & 0xffffu);   // sdrplay.c:219
+                    tt.y = (j & 1) ? (float)((int)xq[j >> 1] >> 16) : (float)(short)(xq[j >> 1] & 0xffffu);   // sdrplay.c:220
+                    const f2 wv = {w[2 * j], w[2 * j + 1]};
+                    const f2 ws = {w[2 * j + 1], w[2 * j]};
+                    accA = __builtin_elementwise_fma(tt, wv, accA);
+                    accB = __builtin_elementwise_fma(tt, ws, accB);
+                }
+            } else {
+                const float4 q = *(const float4*)(rowp + (c << 4));
+                const float sv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f2 tt = {sv[j], sv[j]};                              // air.c:315-316: wf[i] * S
+                    const f2 wv = {w[2 * j], w[2 * j + 1]};
+                    accA = __builtin_elementwise_fma(tt, wv, accA);
+                }
+            }
+        }
+        red[wave * 64 + lane] = make_float4(accA.x, accA.y, accB.x, accB.y);
+        __syncthreads();
+        if (wave == 0) {
+            const float4 r0 = red[lane], r1 = red[64 + lane], r2 = red[128 + lane], r3 = red[192 + lane];
+            float Dr, Di;
+            if (FMT == FMT_F32R) {
+                Dr = (r0.x + r1.x) + (r2.x + r3.x);
+                Di = (r0.y + r1.y) + (r2.y + r3.y);
+            } else {
+                Dr = ((r0.x + r1.x) + (r2.x + r3.x)) - ((r0.y + r1.y) + (r2.y + r3.y));
+                Di = ((r0.z + r1.z) + (r2.z + r3.z)) + ((r0.w + r1.w) + (r2.w + r3.w));
+            }
+            const int m = t * ACG_TILE_WIN + lane;
+            // power-of-two output scale (1/32768 soapy.c:241, 1/4 sdrplay.c:225): exact, commutes with cabsf
+            if (m < a.nwin) dm_base[(size_t)ch * a.dm_pitch + m] = cabs_like_glibc(Dr, Di) * a.out_scale;
+        }
+        ch = nch_;
+        t = nt_;
+    }
+}
+
+extern "C" int acg_launch_fir_fmt(const FirArgs* a, int fmt, void* stream)
+{
+    const size_t lds = (size_t)ACG_TILE_WIN * a->row_stride + 4 * 64 * sizeof(float4);
+    static bool attr_set = false;
+    static int num_cu = 256;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)fir_fmt_kernel<FMT_CS16>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fir_fmt_kernel<FMT_SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fir_fmt_kernel<FMT_F32R>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (e != hipSuccess) return (int)e;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        attr_set = true;
+    }
+    if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 4) per_cu = 4;
+    const long long ntile = (a->nwin + ACG_TILE_WIN - 1) / ACG_TILE_WIN;
+    const long long G = (long long)a->nch * ntile;
+    long long grid = (long long)num_cu * per_cu;
+    if (grid > G) grid = G;
+    switch (fmt) {
+    case FMT_CS16:
+        hipLaunchKernelGGL(fir_fmt_kernel<FMT_CS16>, dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds, (hipStream_t)stream, *a, a->iq, a->taps, a->stream_of, a->dm);
+        break;
+    case FMT_SPLIT:
+        hipLaunchKernelGGL(fir_fmt_kernel<FMT_SPLIT>, dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds, (hipStream_t)stream, *a, a->iq, a->taps, a->stream_of, a->dm);
+        break;
+    case FMT_F32R:
+        hipLaunchKernelGGL(fir_fmt_kernel<FMT_F32R>, dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds, (hipStream_t)stream, *a, a->iq, a->taps, a->stream_of, a->dm);
+        break;
+    default:
+        return (int)hipErrorInvalidValue;
+    }
+    return (int)hipGetLastError();
+}
+
 // Fallback for decimations whose window is not a whole number of 16-byte chunks (M % 8 != 0):
 // one thread per output, sequential accumulation exactly in the reference's order.
 __global__ void fir_u8_generic_kernel(const FirArgs a, int ntaps)
@@ -473,8 +667,8 @@ extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         if (e != hipSuccess) return (int)e;
         int dev = 0;
-        hipGetDevice(&dev);
-        hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev);
         if (const char* v = getenv("ACG_FIR_VARIANT")) variant = atoi(v);
         attr_set = true;
     }

@@ -104,3 +104,19 @@ void acg_host_crc_tables(unsigned short *crc, unsigned short *synd)
 			synd[8 * k + i] = s;
 		}
 }
+
+/* soapy.c:163-166: oscillator[ind] = cexpf(-j*AMFreq*ind)/rateMult with ch->Fr a float (acarsdec.h:70) */
+int acg_soapy_taps(float Fr_hz, int freq_hz, int decim, float *taps_out)
+{
+	int k;
+	float AMFreq;
+	if (!taps_out || decim < 1 || decim > ACG_MAXDECIM)
+		return ACG_EINVAL;
+	AMFreq = (Fr_hz - (float)freq_hz) / (float)(ACG_INTRATE * decim) * 2.0 * M_PI;
+	for (k = 0; k < decim; k++) {
+		const float complex w = cexpf(AMFreq * k * -I) / decim;
+		taps_out[2 * k] = crealf(w);
+		taps_out[2 * k + 1] = cimagf(w);
+	}
+	return ACG_OK;
+}

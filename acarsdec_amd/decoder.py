@@ -34,6 +34,13 @@ def choose_fc(freqs_hz, decim):
     return int(fc), fd
 
 
+def soapy_taps(Fr_hz, freq_hz, decim):
+    """oscillator[] of soapy.c:163-166 as float32 [decim, 2]."""
+    out = np.zeros((decim, 2), dtype=np.float32)
+    _chk(None, K.load().acg_soapy_taps(float(Fr_hz), int(freq_hz), int(decim), out.ctypes.data))
+    return out
+
+
 def parse_freq_mhz(s):
     """rtl.c:245-247: command-line MHz string -> Hz rounded to the 12.5 kHz raster."""
     return (int(1000000 * float(s) + K.INTRATE / 2) // K.INTRATE) * K.INTRATE
@@ -116,6 +123,24 @@ class Decoder:
             _chk(self.ctx, self.L.acg_process_iq_u8_dev(self.ctx, p, pitch, nblocks, stream))
         else:
             _chk(self.ctx, self.L.acg_process_iq_u8_host(self.ctx, p, pitch, nblocks))
+
+    def feed(self, fmt, samples, q_plane=None):
+        """Host samples of any length (the SDR drivers' shape): [nstreams, n] int16 pairs / planes / float32."""
+        if fmt == K.FMT_CS16:
+            a = np.ascontiguousarray(samples, dtype=np.int16).reshape(self.nstreams, -1)
+            n, pitch = a.shape[1] // 2, a.shape[1] // 2
+        elif fmt == K.FMT_S16_SPLIT:
+            a = np.ascontiguousarray(samples, dtype=np.int16).reshape(self.nstreams, -1)
+            q_plane = np.ascontiguousarray(q_plane, dtype=np.int16).reshape(self.nstreams, -1)
+            n, pitch = a.shape[1], a.shape[1]
+        else:
+            a = np.ascontiguousarray(samples, dtype=np.float32).reshape(self.nstreams, -1)
+            n, pitch = a.shape[1], a.shape[1]
+        _chk(self.ctx, self.L.acg_feed_samples_host(self.ctx, fmt, a.ctypes.data,
+                                                     q_plane.ctypes.data if q_plane is not None else None, pitch, n))
+
+    def process_samples(self, fmt, dev_tensor, nblocks, pitch, plane=0, stream=None):
+        _chk(self.ctx, self.L.acg_process_samples_dev(self.ctx, fmt, dev_tensor.data_ptr(), pitch, plane, nblocks, stream))
 
     def fir_only(self, iq_dev, nblocks, pitch, stream=None):
         _chk(self.ctx, self.L.acg_fir_only_dev(self.ctx, iq_dev.data_ptr(), pitch, nblocks, stream))

@@ -178,6 +178,34 @@ def iq_u8_from_envelopes(envs, M, offsets_hz, phases=None, scale=0.25, noise=0.0
     return out
 
 
+def iq_complex_from_envelopes(envs, M, offsets_hz, phases=None, scale=0.25, noise=0.0, rng=None):
+    """The complex baseband of iq_u8_from_envelopes before quantisation (complex128 [nout*M])."""
+    envs = np.atleast_2d(np.asarray(envs, dtype=np.float64))
+    nc, nout = envs.shape
+    offsets_hz = np.asarray(offsets_hz, dtype=np.float64).reshape(nc)
+    phases = np.zeros(nc) if phases is None else np.asarray(phases, dtype=np.float64).reshape(nc)
+    rate = float(INTRATE * M)
+    rng = rng or np.random.default_rng(0)
+    n = np.arange(nout * M, dtype=np.float64)
+    x = np.zeros(nout * M, dtype=np.complex128)
+    for c in range(nc):
+        turns = np.mod(offsets_hz[c] * n / rate, 1.0)
+        x += np.repeat(envs[c], M) * np.exp(1j * (2 * np.pi * turns + phases[c]))
+    x *= scale
+    if noise > 0:
+        x += rng.normal(0, noise, size=x.shape) + 1j * rng.normal(0, noise, size=x.shape)
+    return x
+
+
+def iq_s16_from_envelopes(envs, M, offsets_hz, phases=None, scale=0.25, noise=0.0, rng=None, full_scale=0.9):
+    """CS16 interleaved I,Q (what SoapySDR delivers, soapy.c:181,238-239): int16 = rint(32767*full_scale*x)."""
+    x = iq_complex_from_envelopes(envs, M, offsets_hz, phases, scale, noise, rng)
+    out = np.empty(x.size * 2, dtype=np.int16)
+    out[0::2] = np.clip(np.rint(32767.0 * full_scale * x.real), -32768, 32767).astype(np.int16)
+    out[1::2] = np.clip(np.rint(32767.0 * full_scale * x.imag), -32768, 32767).astype(np.int16)
+    return out
+
+
 def pad_blocks(x, block=1024, fill=0.0):
     """Pad the last axis to a multiple of `block` (rtl.c:49 RTLOUTBUFSZ) with `fill`."""
     x = np.asarray(x)

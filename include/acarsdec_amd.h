@@ -126,6 +126,23 @@ int  acg_fir_only_dev(acg_ctx *ctx, const uint8_t *iq_dev, size_t pitch_bytes, i
 		      void *hip_stream);
 int  acg_sync(acg_ctx *ctx);
 
+/* ---- the other front ends' sample formats ----------------------------------- */
+#define ACG_FMT_CS16       1   /* interleaved int16 I,Q: soapy.c:238-241 (dm = |D| with the /32768 of soapy.c:241) */
+#define ACG_FMT_S16_SPLIT  2   /* int16 I plane + int16 Q plane: sdrplay.c:219-225 (dm = |D|/4) */
+#define ACG_FMT_F32_REAL   3   /* real float32 samples, complex taps: air.c:314-324 */
+/* soapy.c:163-166 oscillator table ([decim][2]); ch->Fr is a float in that front end */
+int  acg_soapy_taps(float Fr_hz, int freq_hz, int decim, float *taps_out);
+/* Window-aligned device input: [nstreams] rows of nblocks*1024*decim samples (4 bytes per sample;
+ * ACG_FMT_S16_SPLIT: I plane at the row start, Q plane plane_bytes further).  decim % 4 == 0
+ * (8 for split planes), decim <= 208.  Same asynchronous contract as acg_process_iq_u8_dev. */
+int  acg_process_samples_dev(acg_ctx *ctx, int fmt, const void *dev, size_t pitch_bytes, size_t plane_bytes,
+			     int nblocks, void *hip_stream);
+/* Host input of ANY length per call, as the SDR drivers deliver it: windows may straddle calls (the
+ * reference carries D / its index across buffers: soapy.c:232-254, sdrplay.c:215-236, air.c:299-338).
+ * p0 = samples (I plane for ACG_FMT_S16_SPLIT), p1 = Q plane or NULL; rows pitch_samples apart. */
+int  acg_feed_samples_host(acg_ctx *ctx, int fmt, const void *p0, const void *p1, size_t pitch_samples,
+			   size_t nsamples);
+
 /* ---- results ------------------------------------------------------------------------------ */
 /* Blocks completed since the last drain/collect, ordered by (chn, end_bit).  Waits for ALL
  * enqueued work of the context. */

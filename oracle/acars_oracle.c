@@ -154,6 +154,49 @@ void orc_fir_u8(const uint8_t *iq, size_t nout, int M, int ntaps, const float *w
 }
 
 /* ------------------------------------------------------------------ */
+/* soapy.c front end (CS16 samples, windows may straddle read buffers)  */
+/* ------------------------------------------------------------------ */
+
+/* soapy.c:163-166.  ch->Fr is a float here (acarsdec.h:70), freq an int, soapyInRate an int. */
+void orc_soapy_taps(float Fr, int freq, int M, float *osc)
+{
+	int soapyInRate = ORC_INTRATE * M;               /* soapy.c:89 */
+	int ind;
+	float AMFreq;
+
+	AMFreq = (Fr - (float)freq) / (float)(soapyInRate) * 2.0 * M_PI;
+	for (ind = 0; ind < M; ind++) {
+		float complex w = cexpf(AMFreq * ind * -I) / M;          /* float complex / int */
+		osc[2 * ind] = crealf(w);
+		osc[2 * ind + 1] = cimagf(w);
+	}
+}
+
+/* soapy.c:232-254 for one channel over a whole stream.  D is carried across read buffers
+ * (ch->D, current_index), so the result does not depend on how the stream was cut into reads:
+ * every window is the same sequential sum.  Per term: float complex product, /32768.0 in
+ * double, added to D in double, narrowed to float complex. */
+void orc_fir_cs16(const int16_t *iq, size_t nout, int M, const float *osc, float *dm)
+{
+	size_t m;
+	for (m = 0; m < nout; m++) {
+		const int16_t *p = iq + 2 * (size_t)M * m;
+		float Dr = 0, Di = 0;
+		int ind;
+		for (ind = 0; ind < M; ind++) {
+			float r = (float)p[2 * ind];                     /* soapy.c:238 */
+			float g = (float)p[2 * ind + 1];                 /* soapy.c:239 */
+			float wr = osc[2 * ind], wi = osc[2 * ind + 1];
+			float pr = r * wr - g * wi;                      /* soapy.c:241 v * oscillator */
+			float pi = r * wi + g * wr;
+			Dr = (float)((double)Dr + (double)pr / 32768.0);
+			Di = (float)((double)Di + (double)pi / 32768.0);
+		}
+		dm[m] = cabsf(Dr + Di * I);                              /* soapy.c:243 */
+	}
+}
+
+/* ------------------------------------------------------------------ */
 /* acars.c framing FSM (only what is reachable from putbit)            */
 /* ------------------------------------------------------------------ */
 

@@ -91,6 +91,10 @@ void orc_fir_u8(const uint8_t *iq, size_t nout, int M, int ntaps,
 void orc_in_callback(orc_chan *chs, int nch, const uint8_t *iq, int nout, int M,
 		     const float *wf /* [nch][M][2] */, float *dm_scratch /* [nch][nout] */);
 
+/* soapy.c:163-166 oscillator table; soapy.c:232-254 CS16 down-converter (whole stream, any read size) */
+void orc_soapy_taps(float Fr, int freq, int M, float *osc);
+void orc_fir_cs16(const int16_t *iq, size_t nout, int M, const float *osc, float *dm);
+
 /* acars.c:123-207 parity + CRC verdict of a queued block (no repair):
  * returns 0 if it would be output with err==0, >0 = number of parity errors,
  * -1 = dropped (too short), -2 = crc error with clean parity. */

@@ -73,6 +73,8 @@ def lib():
         L.orc_frame_check.restype = C.c_int
         L.orc_crc_update.argtypes = [C.c_ushort, C.c_ubyte]
         L.orc_crc_update.restype = C.c_ushort
+        L.orc_soapy_taps.argtypes = [C.c_float, C.c_int, C.c_int, C.c_void_p]
+        L.orc_fir_cs16.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_syndrome_table.argtypes = [C.c_void_p, C.c_int]
         L.orc_blk_process.argtypes = [C.POINTER(OrcFrame), C.POINTER(OrcFrame)]
         L.orc_blk_process.restype = C.c_int
@@ -150,6 +152,22 @@ def fir_u8(iq, M, wf, nout=None, ntaps=None):
     return dm
 
 
+def soapy_taps(Fr, freq, M):
+    osc = np.zeros((M, 2), dtype=np.float32)
+    lib().orc_soapy_taps(float(Fr), int(freq), int(M), osc.ctypes.data)
+    return osc
+
+
+def fir_cs16(iq, M, osc, nout=None):
+    iq = np.ascontiguousarray(iq, dtype=np.int16).reshape(-1)
+    osc = np.ascontiguousarray(osc, dtype=np.float32)
+    if nout is None:
+        nout = iq.size // (2 * M)
+    dm = np.zeros(nout, dtype=np.float32)
+    lib().orc_fir_cs16(iq.ctypes.data, nout, M, osc.ctypes.data, dm.ctypes.data)
+    return dm
+
+
 def syndrome_table(n=1936):
     t = np.zeros(n, dtype=np.uint16)
     lib().orc_syndrome_table(t.ctypes.data, n)
@@ -198,18 +216,29 @@ class Ref:
 
     def __init__(self, variant=""):
         L = C.CDLL(ref_path(variant))
-        L.ref_init_rtl.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_int]
-        L.ref_init_rtl.restype = C.c_long
+        if hasattr(L, 'ref_init_rtl'):
+            L.ref_init_rtl.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_int]
+            L.ref_init_rtl.restype = C.c_long
+            L.ref_in_callback.argtypes = [C.c_void_p, C.c_uint]
+            L.ref_get_wf.argtypes = [C.c_int, C.c_void_p, C.c_int]
+            L.ref_get_wf.restype = C.c_int
         L.ref_init_file.argtypes = [C.c_int]
-        L.ref_in_callback.argtypes = [C.c_void_p, C.c_uint]
         L.ref_demod.argtypes = [C.c_int, C.c_void_p, C.c_int]
-        L.ref_get_wf.argtypes = [C.c_int, C.c_void_p, C.c_int]
-        L.ref_get_wf.restype = C.c_int
         L.ref_get_dm.argtypes = [C.c_int]
         L.ref_get_dm.restype = C.POINTER(C.c_float)
         L.ref_get_state.argtypes = [C.c_int, C.POINTER(RefState)]
         L.ref_raw.restype = C.POINTER(RefFrame)
         L.ref_out.restype = C.POINTER(RefFrame)
+        if hasattr(L, 'ref_init_soapy'):
+            L.ref_init_soapy.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_int]
+            L.ref_init_soapy.restype = C.c_long
+            L.ref_soapy_feed.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
+            L.ref_get_oscillator.argtypes = [C.c_int, C.c_void_p, C.c_int]
+        L.ref_dmlog_enable.argtypes = [C.c_size_t]
+        L.ref_dmlog_count.argtypes = [C.c_int]
+        L.ref_dmlog_count.restype = C.c_size_t
+        L.ref_dmlog.argtypes = [C.c_int]
+        L.ref_dmlog.restype = C.POINTER(C.c_float)
         L.ref_bitlog_enable.argtypes = [C.c_size_t]
         L.ref_bitlog_count.restype = C.c_size_t
         L.ref_bitlog.restype = C.POINTER(RefBit)
@@ -224,6 +253,30 @@ class Ref:
             raise RuntimeError("initRtl failed (%d)" % fc)
         self.M = mult
         return fc
+
+    def init_soapy(self, freqs_mhz, mult):
+        arr = (C.c_char_p * len(freqs_mhz))(*[f.encode() for f in freqs_mhz])
+        fc = self.L.ref_init_soapy(len(freqs_mhz), arr, mult)
+        if fc <= 0:
+            raise RuntimeError("initSoapy failed (%d)" % fc)
+        self.M = mult
+        return fc
+
+    def soapy_feed(self, iq, chunk=0):
+        iq = np.ascontiguousarray(iq, dtype=np.int16).reshape(-1)
+        self.L.ref_soapy_feed(iq.ctypes.data, iq.size // 2, chunk)
+
+    def oscillator(self, n):
+        out = np.zeros((self.M, 2), dtype=np.float32)
+        fr = self.L.ref_get_oscillator(n, out.ctypes.data, self.M)
+        return fr, out
+
+    def dmlog_enable(self, cap):
+        self.L.ref_dmlog_enable(cap)
+
+    def dmlog(self, n):
+        k = self.L.ref_dmlog_count(n)
+        return np.ctypeslib.as_array(self.L.ref_dmlog(n), shape=(k,)).copy() if k else np.zeros(0, np.float32)
 
     def init_file(self, nch):
         if self.L.ref_init_file(nch):

@@ -20,18 +20,33 @@
 #include <setjmp.h>
 #include <math.h>
 #include <complex.h>
+#ifdef WITH_RTL
 #include <rtl-sdr.h>
+#endif
+#ifdef WITH_SOAPY
+#include <SoapySDR/Device.h>
+#endif
 #include "acarsdec.h"
 
-/* ---- globals the reference files expect (acarsdec.c:34-58) ---- */
+/* ---- globals the reference files expect (acarsdec.c:34-75) ---- */
 channel_t channel[MAXNBCHANNELS];
 unsigned int nbch;
 int verbose = 0;
 int signalExit = 0;
+#ifdef WITH_RTL
 int gain = -100;
 int ppm = 0;
 int rtlMult = 160;
+#endif
+#ifdef WITH_SOAPY
+char *antenna = NULL;
+double gain = -10.0;
+int ppm = 0;
+int rateMult = 160;
+int freq = 0;
+#endif
 
+#ifdef WITH_RTL
 /* ---- librtlsdr stand-ins ---- */
 static uint32_t g_center_freq;
 uint32_t rtlsdr_get_device_count(void) { return 1; }
@@ -56,6 +71,7 @@ int rtlsdr_reset_buffer(rtlsdr_dev_t *dev) { (void)dev; return 0; }
 int rtlsdr_read_async(rtlsdr_dev_t *dev, rtlsdr_read_async_cb_t cb, void *ctx, uint32_t n, uint32_t l)
 { (void)dev; (void)cb; (void)ctx; (void)n; (void)l; return 0; }
 int rtlsdr_cancel_async(rtlsdr_dev_t *dev) { (void)dev; return 0; }
+#endif /* WITH_RTL */
 
 /* ---- capture buffers ---- */
 typedef struct {
@@ -145,9 +161,30 @@ void __wrap_decodeAcars(channel_t *ch)
 }
 
 static channel_t *g_cur;
+/* optional log of everything handed to demodMSK (the front end's dm output), per channel */
+static float *g_dmlog[MAXNBCHANNELS];
+static size_t g_dmlog_n[MAXNBCHANNELS], g_dmlog_cap;
+void ref_dmlog_enable(size_t cap_per_channel)
+{
+	int i;
+	for (i = 0; i < MAXNBCHANNELS; i++) {
+		free(g_dmlog[i]);
+		g_dmlog[i] = cap_per_channel ? calloc(cap_per_channel, sizeof(float)) : NULL;
+		g_dmlog_n[i] = 0;
+	}
+	g_dmlog_cap = cap_per_channel;
+}
+size_t ref_dmlog_count(int n) { return g_dmlog_n[n]; }
+const float *ref_dmlog(int n) { return g_dmlog[n]; }
 void __real_demodMSK(channel_t *ch, int len);
 void __wrap_demodMSK(channel_t *ch, int len)
 {
+	if (g_dmlog_cap && ch->chn >= 0 && ch->chn < MAXNBCHANNELS && g_dmlog[ch->chn]) {
+		size_t room = g_dmlog_cap - g_dmlog_n[ch->chn];
+		size_t k = (size_t)len < room ? (size_t)len : room;
+		memcpy(g_dmlog[ch->chn] + g_dmlog_n[ch->chn], ch->dm_buffer, k * sizeof(float));
+		g_dmlog_n[ch->chn] += k;
+	}
 	g_cur = ch;
 	__real_demodMSK(ch, len);
 	g_cur = NULL;
@@ -183,7 +220,9 @@ size_t ref_bitlog_count(void) { return g_nbits; }
 const ref_bit *ref_bitlog(void) { return g_bits; }
 
 /* ---- driver API (ctypes) ---- */
+#ifdef WITH_RTL
 void ref_rtl_in_callback(unsigned char *buf, uint32_t nread);   /* ref_rtl_unit.c */
+#endif
 
 static void common_init(void)
 {
@@ -199,6 +238,7 @@ static void common_init(void)
 	}
 }
 
+#ifdef WITH_RTL
 /* RTL path: freqs are decimal MHz strings exactly as on the reference command line
  * (acarsdec -m mult -r 0 f1 f2 ...).  Returns the centre frequency chosen (rtl.c:268), <0 on error. */
 long ref_init_rtl(int nfreq, const char **freqs, int mult)
@@ -219,6 +259,96 @@ long ref_init_rtl(int nfreq, const char **freqs, int mult)
 	common_init();
 	return (long)g_center_freq;
 }
+void ref_in_callback(unsigned char *buf, unsigned int nread) { ref_rtl_in_callback(buf, nread); }
+int ref_get_wf(int n, float *out, int M)
+{
+	int i;
+	for (i = 0; i < M; i++) {
+		out[2 * i] = crealf(channel[n].wf[i]);
+		out[2 * i + 1] = cimagf(channel[n].wf[i]);
+	}
+	return channel[n].Fr;
+}
+#endif /* WITH_RTL */
+
+#ifdef WITH_SOAPY
+/* ---- SoapySDR stand-ins: set-up calls do nothing, readStream serves the test's samples ---- */
+static const int16_t *g_feed;          /* interleaved I,Q */
+static size_t g_feed_left;             /* complex samples left */
+static size_t g_feed_chunk;            /* complex samples per readStream (0 = whatever is asked for) */
+const char *SoapySDRDevice_lastError(void) { return "stub"; }
+SoapySDRDevice *SoapySDRDevice_makeStrArgs(const char *a) { (void)a; return (SoapySDRDevice *)&g_feed; }
+int SoapySDRDevice_unmake(SoapySDRDevice *d) { (void)d; return 0; }
+int SoapySDRDevice_setGainMode(SoapySDRDevice *d, int dir, size_t c, bool a) { (void)d; (void)dir; (void)c; (void)a; return 0; }
+int SoapySDRDevice_setGain(SoapySDRDevice *d, int dir, size_t c, double v) { (void)d; (void)dir; (void)c; (void)v; return 0; }
+int SoapySDRDevice_setFrequencyCorrection(SoapySDRDevice *d, int dir, size_t c, double v) { (void)d; (void)dir; (void)c; (void)v; return 0; }
+int SoapySDRDevice_setFrequency(SoapySDRDevice *d, int dir, size_t c, double f, const SoapySDRKwargs *a) { (void)d; (void)dir; (void)c; (void)f; (void)a; return 0; }
+int SoapySDRDevice_setSampleRate(SoapySDRDevice *d, int dir, size_t c, double r) { (void)d; (void)dir; (void)c; (void)r; return 0; }
+int SoapySDRDevice_setAntenna(SoapySDRDevice *d, int dir, size_t c, const char *n) { (void)d; (void)dir; (void)c; (void)n; return 0; }
+SoapySDRStream *SoapySDRDevice_setupStream(SoapySDRDevice *d, int dir, const char *f, const size_t *ch, size_t n, const SoapySDRKwargs *a)
+{ (void)d; (void)dir; (void)f; (void)ch; (void)n; (void)a; return (SoapySDRStream *)&g_feed_left; }
+int SoapySDRDevice_closeStream(SoapySDRDevice *d, SoapySDRStream *s) { (void)d; (void)s; return 0; }
+int SoapySDRDevice_activateStream(SoapySDRDevice *d, SoapySDRStream *s, int f, long long t, size_t n) { (void)d; (void)s; (void)f; (void)t; (void)n; return 0; }
+int SoapySDRDevice_deactivateStream(SoapySDRDevice *d, SoapySDRStream *s, int f, long long t) { (void)d; (void)s; (void)f; (void)t; return 0; }
+int SoapySDRDevice_readStream(SoapySDRDevice *d, SoapySDRStream *s, void *const *buffs, size_t numElems, int *flags, long long *timeNs, long timeoutUs)
+{
+	size_t n = numElems;
+	(void)d; (void)s; (void)flags; (void)timeNs; (void)timeoutUs;
+	if (g_feed_chunk && g_feed_chunk < n)
+		n = g_feed_chunk;
+	if (n > g_feed_left)
+		n = g_feed_left;
+	if (n == 0)
+		return 0;                       /* soapy.c:221-227: the reader loop ends */
+	memcpy(buffs[0], g_feed, n * 2 * sizeof(int16_t));
+	g_feed += 2 * n;
+	g_feed_left -= n;
+	return (int)n;
+}
+
+void ref_soapy_run_reader(void);               /* ref_soapy_unit.c */
+
+/* acarsdec -m mult -d <dev> f1 f2 ...  Returns the centre frequency chosen (soapy.c:139-140). */
+long ref_init_soapy(int nfreq, const char **freqs, int mult)
+{
+	char *argv[MAXNBCHANNELS + 3];
+	int i, r;
+	if (nfreq > MAXNBCHANNELS)
+		return -1;
+	rateMult = mult;
+	freq = 0;
+	argv[0] = (char *)"driver=stub";
+	for (i = 0; i < nfreq; i++)
+		argv[1 + i] = (char *)freqs[i];
+	argv[1 + nfreq] = NULL;
+	r = initSoapy(argv, 0);
+	if (r)
+		return -2;
+	common_init();
+	return (long)freq;
+}
+
+/* feed n complex CS16 samples through the reference's reader loop, `chunk` per readStream call */
+void ref_soapy_feed(const int16_t *iq, size_t n, size_t chunk)
+{
+	g_feed = iq;
+	g_feed_left = n;
+	g_feed_chunk = chunk;
+	signalExit = 0;
+	ref_soapy_run_reader();
+	signalExit = 0;
+}
+
+int ref_get_oscillator(int n, float *out, int M)
+{
+	int i;
+	for (i = 0; i < M; i++) {
+		out[2 * i] = crealf(channel[n].oscillator[i]);
+		out[2 * i + 1] = cimagf(channel[n].oscillator[i]);
+	}
+	return (int)channel[n].Fr;
+}
+#endif /* WITH_SOAPY */
 
 /* sound-file path (soundfile.c:30-56): nch channels of 12.5 kHz real samples */
 int ref_init_file(int nch)
@@ -233,23 +363,11 @@ int ref_init_file(int nch)
 	return 0;
 }
 
-void ref_in_callback(unsigned char *buf, unsigned int nread) { ref_rtl_in_callback(buf, nread); }
-
 /* soundfile.c:71-77 for one channel: len <= 4096 */
 void ref_demod(int n, const float *dm, int len)
 {
 	memcpy(channel[n].dm_buffer, dm, sizeof(float) * (size_t)len);
 	demodMSK(&channel[n], len);
-}
-
-int ref_get_wf(int n, float *out, int M)
-{
-	int i;
-	for (i = 0; i < M; i++) {
-		out[2 * i] = crealf(channel[n].wf[i]);
-		out[2 * i + 1] = cimagf(channel[n].wf[i]);
-	}
-	return channel[n].Fr;
 }
 
 const float *ref_get_dm(int n) { return channel[n].dm_buffer; }

@@ -378,6 +378,60 @@ def test_streaming_collect_equals_blocking_drain(D, O, S):
     assert sum(len(v) for v in results[0].values()) >= nch
 
 
+# ------------------------------------------------------------------------------------ other front ends' formats
+@pytest.mark.parametrize("M,feeds", [(160, [1000, 163841 - 1000, 70000, 999999]), (200, [5, 204800, 3 * 204800 + 17, 10 ** 7]), (192, [10 ** 7])])
+def test_cs16_soapy_path_with_carry_matches_oracle(D, O, S, M, feeds):
+    """soapy.c shape: CS16 samples fed in reads of arbitrary size (windows straddle reads).  dm within the
+    stated tolerance, blocks bit-exact, and the result independent of how the stream was cut."""
+    from acarsdec_amd import _capi as K
+    rng = np.random.default_rng(M)
+    nch, nblk = 5, 4
+    nout = nblk * 1024
+    freqs = [131525000, 131725000, 131825000, 131550000, 131450000]
+    fc = D.choose_fc(freqs, M)[0]
+    env = []
+    for c in range(nch):
+        a, _ = S.channel_audio(rng, nout, gap=(400, 900), text_len=(3, 25))
+        env.append(0.5 * (1 + 0.5 * a))
+    iq = S.iq_s16_from_envelopes(np.array(env), M, [f - fc for f in freqs], phases=np.linspace(0, 3, nch), scale=0.15,
+                                 noise=0.01, rng=rng)
+    taps = np.stack([D.soapy_taps(float(f), fc, M) for f in freqs])
+    dec = D.Decoder(nch, decim=M, nstreams=1, max_blocks=nblk)
+    dec.set_taps(taps)
+    got, dms, pos, total = [], [[] for _ in range(nch)], 0, iq.size // 2
+    for n in feeds:
+        n = min(n, total - pos)
+        if n <= 0:
+            break
+        dec.feed(K.FMT_CS16, iq[2 * pos:2 * (pos + n)].reshape(1, -1))
+        pos += n
+        got += [D.frame_tuple(f) for f in dec.drain_frames()]
+    assert pos == total
+    by = blocks_by_channel_tuples(got)
+    nfr = 0
+    for c in range(nch):
+        dm_o = O.fir_cs16(iq, M, O.soapy_taps(float(freqs[c]), fc, M))
+        ch = O.Channel(c)
+        ch.demod(dm_o)
+        assert by.get(c, []) == [O.frame_tuple(f) for f in ch.frames], c
+        nfr += len(ch.frames)
+    assert nfr >= nch - 2
+    dec.close()
+    # window-aligned device path: same blocks, dm within tolerance
+    import torch
+    dec = D.Decoder(nch, decim=M, nstreams=1, max_blocks=nblk)
+    dec.set_taps(taps)
+    d_iq = torch.from_numpy(iq.copy()).cuda()
+    dec.process_samples(K.FMT_CS16, d_iq, nblk, pitch=iq.size * 2)
+    got2 = blocks_by_channel(dec.drain_frames(), D.frame_tuple)
+    for c in range(nch):
+        dm_o = O.fir_cs16(iq, M, O.soapy_taps(float(freqs[c]), fc, M))
+        dm_g = dec.dm(c, nout)
+        assert np.all(np.abs(dm_g - dm_o) <= 1e-5 * np.abs(dm_o) + 1e-6), (c, np.abs(dm_g - dm_o).max())
+        assert got2.get(c, []) == by.get(c, [])
+    dec.close()
+
+
 # ------------------------------------------------------------------------------------ block repair on the device (SURVEY 8f.1)
 def test_device_block_repair_matches_oracle_and_golden(D, O, S, testwav, golden):
     """ACG_F_REPAIR: what drain returns equals what the reference's blk_thread hands to outputmsg():

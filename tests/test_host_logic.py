@@ -52,6 +52,12 @@ def test_rtl_taps_equal_oracle(M):
         assert np.array_equal(D.rtl_taps(fr, fc, M), O.rtl_taps(fr, fc, M))
 
 
+@pytest.mark.parametrize("M", [160, 192, 200])
+def test_soapy_taps_equal_oracle(M):
+    for fr, fc in ((131525000, 131850000), (131825000.0, 131850000), (129125000, 130100000)):
+        assert np.array_equal(D.soapy_taps(fr, fc, M), O.soapy_taps(fr, fc, M))
+
+
 def test_choose_fc_equals_oracle_random_sets():
     rng = np.random.default_rng(0)
     for _ in range(300):

@@ -117,6 +117,62 @@ def test_block_repair_identical_to_reference_blk_thread(seed):
     assert res["nraw"] >= 40 and res["nout"] < res["nraw"] and res["repaired"] >= 8, res
 
 
+SOAPY_CHILD = r'''
+import sys, json
+import numpy as np
+sys.path.insert(0, %(root)r)
+from oracle import oracle as O
+from acarsdec_amd import synth as S
+M, seed, chunk = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+rng = np.random.default_rng(seed)
+ref = O.Ref("_soapy")
+freqs = ["131.525", "131.725", "131.825"]
+fc = ref.init_soapy(freqs, M)
+fr = [int(round(float(f) * 1e6)) for f in freqs]
+res = dict(ok=True, why=[], fc=int(fc))
+if O.choose_fc(fr, M) != fc: res["ok"] = False; res["why"].append("fc")
+nblk = 3
+env = []
+for c in range(3):
+    a, _ = S.channel_audio(rng, nblk * 1024, nframes=1, gap=(300, 600), text_len=(5, 20))
+    env.append(0.5 * (1 + 0.5 * a))
+iq = S.iq_s16_from_envelopes(np.array(env), M, [f - fc for f in fr], phases=[0.2, 1.0, 4.0], noise=0.01, rng=rng)
+ref.dmlog_enable(nblk * 1024)
+ref.soapy_feed(iq, chunk)          # reads of `chunk` samples: windows straddle read buffers (soapy.c:232-254)
+ref.drain()
+chs = [O.Channel(c) for c in range(3)]
+for c in range(3):
+    f, osc = ref.oscillator(c)
+    mine = O.soapy_taps(float(fr[c]), fc, M)
+    if not np.array_equal(osc, mine): res["ok"] = False; res["why"].append("osc%%d" %% c)
+    dm = O.fir_cs16(iq, M, mine)
+    rd = ref.dmlog(c)
+    if not np.array_equal(dm[:rd.size], rd) or rd.size != nblk * 1024: res["ok"] = False; res["why"].append("dm%%d %%d" %% (c, rd.size))
+    for b in range(0, dm.size, 1024): chs[c].demod(dm[b:b+1024])
+    a, b2 = ref.state(c), chs[c].state()
+    for k in a:
+        if not np.array_equal(np.asarray(a[k]), np.asarray(b2[k])): res["ok"] = False; res["why"].append("state %%d %%s" %% (c, k))
+def tup(f): return [int(f.chn), int(f.len), int(f.err), bytes(f.crc).hex(), bytes(f.txt[:f.len]).hex(), float(f.lvl).hex()]
+rf = sorted(tup(f) for f in ref.raw_frames()); of = sorted(tup(f) for c in chs for f in c.frames)
+if rf != of: res["ok"] = False; res["why"].append("frames")
+res["nframes"] = len(rf)
+print(json.dumps(res))
+'''
+
+
+@pytest.mark.parametrize("M,chunk", [(160, 0), (160, 1000), (192, 4097), (200, 777)])
+def test_soapy_front_end_bit_identical_to_reference(M, chunk):
+    """soapy.c (CS16, D carried across read buffers of any size): oscillator table, dm, state, blocks."""
+    if not O.ref_available("_soapy"):
+        pytest.skip("oracle/_ref/libacarsref_soapy.so not built")
+    r = subprocess.run([sys.executable, "-c", SOAPY_CHILD % dict(root=ROOT), str(M), str(M + chunk), str(chunk)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["ok"], res["why"]
+    assert res["nframes"] >= 3
+
+
 def test_syndrome_table_regenerated_equals_reference_header():
     import re
     path = "/root/reference/syndrom.h"
