@@ -206,6 +206,26 @@ def iq_s16_from_envelopes(envs, M, offsets_hz, phases=None, scale=0.25, noise=0.
     return out
 
 
+def real_f32_from_envelopes(envs, M, offsets_hz, phases=None, scale=0.25, noise=0.0, rng=None):
+    """Real float32 samples at INTRATE*M (what an Airspy in FLOAT32_REAL mode delivers, air.c:195,314):
+    carriers at offsets_hz from 0 Hz of the REAL spectrum (air.c tunes so that channels sit around Fs/4)."""
+    envs = np.atleast_2d(np.asarray(envs, dtype=np.float64))
+    nc, nout = envs.shape
+    offsets_hz = np.asarray(offsets_hz, dtype=np.float64).reshape(nc)
+    phases = np.zeros(nc) if phases is None else np.asarray(phases, dtype=np.float64).reshape(nc)
+    rate = float(INTRATE * M)
+    rng = rng or np.random.default_rng(0)
+    n = np.arange(nout * M, dtype=np.float64)
+    x = np.zeros(nout * M)
+    for c in range(nc):
+        turns = np.mod(offsets_hz[c] * n / rate, 1.0)
+        x += np.repeat(envs[c], M) * np.cos(2 * np.pi * turns + phases[c])
+    x *= 2 * scale
+    if noise > 0:
+        x += rng.normal(0, noise, size=x.shape)
+    return x.astype(np.float32)
+
+
 def pad_blocks(x, block=1024, fill=0.0):
     """Pad the last axis to a multiple of `block` (rtl.c:49 RTLOUTBUFSZ) with `fill`."""
     x = np.asarray(x)

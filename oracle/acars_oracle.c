@@ -197,6 +197,92 @@ void orc_fir_cs16(const int16_t *iq, size_t nout, int M, const float *osc, float
 }
 
 /* ------------------------------------------------------------------ */
+/* sdrplay.c front end (split int16 planes, fixed 2.0 Msps)             */
+/* ------------------------------------------------------------------ */
+
+/* sdrplay.c:160-164.  correctionPhase is a DOUBLE here (a float in soapy.c): the phase of tap
+ * `ind` is the double product narrowed by cexpf's float complex parameter. */
+void orc_sdrplay_taps(float Fr, unsigned int Fc, float *osc)
+{
+	const int M = 160;                               /* sdrplay.c:35 SDRPLAY_MULT */
+	int ind;
+	double correctionPhase = (Fr - (float)Fc) / (float)(ORC_INTRATE * M) * 2.0 * M_PI;
+	for (ind = 0; ind < M; ind++) {
+		float complex w = cexpf(correctionPhase * ind * -I) / M;
+		osc[2 * ind] = crealf(w);
+		osc[2 * ind + 1] = cimagf(w);
+	}
+}
+
+/* sdrplay.c:215-236 for one channel over a whole stream (D and the index are carried across
+ * callbacks, so the cut into callbacks does not matter): float complex MAC, dm = cabsf(D)/4. */
+void orc_fir_split16(const int16_t *xi, const int16_t *xq, size_t nout, int M, const float *osc, float *dm)
+{
+	size_t m;
+	for (m = 0; m < nout; m++) {
+		const int16_t *pi_ = xi + (size_t)M * m, *pq = xq + (size_t)M * m;
+		float Dr = 0, Di = 0;
+		int ind;
+		for (ind = 0; ind < M; ind++) {
+			float r = (float)pi_[ind];                       /* sdrplay.c:219 */
+			float g = (float)pq[ind];                        /* sdrplay.c:220 */
+			float wr = osc[2 * ind], wi = osc[2 * ind + 1];
+			float pr = r * wr - g * wi;                      /* sdrplay.c:223 */
+			float pim = r * wi + g * wr;
+			Dr = Dr + pr;
+			Di = Di + pim;
+		}
+		dm[m] = cabsf(Dr + Di * I) / 4;                          /* sdrplay.c:225 */
+	}
+}
+
+/* ------------------------------------------------------------------ */
+/* air.c front end (real float32 samples at Fs/4 offset)                */
+/* ------------------------------------------------------------------ */
+
+/* air.c:40-63 chooseFc without the R820T filter branch (only taken at exactly 5 Msps) */
+unsigned int orc_air_choose_fc(unsigned int minF, unsigned int maxF)
+{
+	return ((maxF + minF) / 2 + 0 + ORC_INTRATE / 2) / ORC_INTRATE * ORC_INTRATE;
+}
+
+/* air.c:278-285.  Fc, ch->Fr are ints, AIRINRATE unsigned: Fc-Fr+AIRINRATE/4 is evaluated in
+ * unsigned arithmetic and converted to double; the phase accumulates in double with wraps. */
+void orc_air_taps(int Fr, int Fc, unsigned int inrate, float *wf)
+{
+	unsigned int M = inrate / ORC_INTRATE;           /* air.c:213 AIRMULT */
+	unsigned int i;
+	double AMFreq, Ph;
+	AMFreq = 2.0 * M_PI * (double)(Fc - Fr + inrate / 4) / (double)(inrate);
+	for (i = 0, Ph = 0; i < M; i++) {
+		float complex w = cexpf(Ph * -I) / M;
+		wf[2 * i] = crealf(w);
+		wf[2 * i + 1] = cimagf(w);
+		Ph += AMFreq;
+		if (Ph > 2.0 * M_PI) Ph -= 2.0 * M_PI;
+		if (Ph < -2.0 * M_PI) Ph += 2.0 * M_PI;
+	}
+}
+
+/* air.c:299-338 for one channel over a whole stream (ch->D and `ind` carry partial windows
+ * across transfers): D += wf[i]*S, complex tap times real sample, float. */
+void orc_fir_f32r(const float *x, size_t nout, int M, const float *wf, float *dm)
+{
+	size_t m;
+	for (m = 0; m < nout; m++) {
+		const float *p = x + (size_t)M * m;
+		float Dr = 0, Di = 0;
+		int i;
+		for (i = 0; i < M; i++) {
+			float S = p[i];
+			Dr = Dr + wf[2 * i] * S;                         /* air.c:315-316 */
+			Di = Di + wf[2 * i + 1] * S;
+		}
+		dm[m] = cabsf(Dr + Di * I);                              /* air.c:318 */
+	}
+}
+
+/* ------------------------------------------------------------------ */
 /* acars.c framing FSM (only what is reachable from putbit)            */
 /* ------------------------------------------------------------------ */
 

@@ -95,6 +95,13 @@ void orc_in_callback(orc_chan *chs, int nch, const uint8_t *iq, int nout, int M,
 void orc_soapy_taps(float Fr, int freq, int M, float *osc);
 void orc_fir_cs16(const int16_t *iq, size_t nout, int M, const float *osc, float *dm);
 
+/* sdrplay.c:160-164 / 215-236 (fixed rateMult 160) ; air.c:40-63, 278-285, 299-338 */
+void orc_sdrplay_taps(float Fr, unsigned int Fc, float *osc);
+void orc_fir_split16(const int16_t *xi, const int16_t *xq, size_t nout, int M, const float *osc, float *dm);
+unsigned int orc_air_choose_fc(unsigned int minF, unsigned int maxF);
+void orc_air_taps(int Fr, int Fc, unsigned int inrate, float *wf);
+void orc_fir_f32r(const float *x, size_t nout, int M, const float *wf, float *dm);
+
 /* acars.c:123-207 parity + CRC verdict of a queued block (no repair):
  * returns 0 if it would be output with err==0, >0 = number of parity errors,
  * -1 = dropped (too short), -2 = crc error with clean parity. */

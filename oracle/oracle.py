@@ -75,6 +75,12 @@ def lib():
         L.orc_crc_update.restype = C.c_ushort
         L.orc_soapy_taps.argtypes = [C.c_float, C.c_int, C.c_int, C.c_void_p]
         L.orc_fir_cs16.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_sdrplay_taps.argtypes = [C.c_float, C.c_uint, C.c_void_p]
+        L.orc_fir_split16.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_air_choose_fc.argtypes = [C.c_uint, C.c_uint]
+        L.orc_air_choose_fc.restype = C.c_uint
+        L.orc_air_taps.argtypes = [C.c_int, C.c_int, C.c_uint, C.c_void_p]
+        L.orc_fir_f32r.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_syndrome_table.argtypes = [C.c_void_p, C.c_int]
         L.orc_blk_process.argtypes = [C.POINTER(OrcFrame), C.POINTER(OrcFrame)]
         L.orc_blk_process.restype = C.c_int
@@ -168,6 +174,43 @@ def fir_cs16(iq, M, osc, nout=None):
     return dm
 
 
+def sdrplay_taps(Fr, Fc):
+    osc = np.zeros((160, 2), dtype=np.float32)
+    lib().orc_sdrplay_taps(float(Fr), int(Fc), osc.ctypes.data)
+    return osc
+
+
+def fir_split16(xi, xq, M, osc, nout=None):
+    xi = np.ascontiguousarray(xi, dtype=np.int16).reshape(-1)
+    xq = np.ascontiguousarray(xq, dtype=np.int16).reshape(-1)
+    osc = np.ascontiguousarray(osc, dtype=np.float32)
+    if nout is None:
+        nout = xi.size // M
+    dm = np.zeros(nout, dtype=np.float32)
+    lib().orc_fir_split16(xi.ctypes.data, xq.ctypes.data, nout, M, osc.ctypes.data, dm.ctypes.data)
+    return dm
+
+
+def air_choose_fc(freqs_hz):
+    return lib().orc_air_choose_fc(int(min(freqs_hz)), int(max(freqs_hz)))
+
+
+def air_taps(Fr, Fc, inrate):
+    wf = np.zeros((inrate // INTRATE, 2), dtype=np.float32)
+    lib().orc_air_taps(int(Fr), int(Fc), int(inrate), wf.ctypes.data)
+    return wf
+
+
+def fir_f32r(x, M, wf, nout=None):
+    x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+    wf = np.ascontiguousarray(wf, dtype=np.float32)
+    if nout is None:
+        nout = x.size // M
+    dm = np.zeros(nout, dtype=np.float32)
+    lib().orc_fir_f32r(x.ctypes.data, nout, M, wf.ctypes.data, dm.ctypes.data)
+    return dm
+
+
 def syndrome_table(n=1936):
     t = np.zeros(n, dtype=np.uint16)
     lib().orc_syndrome_table(t.ctypes.data, n)
@@ -234,6 +277,17 @@ class Ref:
             L.ref_init_soapy.restype = C.c_long
             L.ref_soapy_feed.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
             L.ref_get_oscillator.argtypes = [C.c_int, C.c_void_p, C.c_int]
+        if hasattr(L, 'ref_init_sdrplay'):
+            L.ref_init_sdrplay.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
+            L.ref_init_sdrplay.restype = C.c_long
+            L.ref_sdrplay_feed.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
+            L.ref_get_oscillator.argtypes = [C.c_int, C.c_void_p, C.c_int]
+        if hasattr(L, 'ref_init_air'):
+            L.ref_init_air.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_uint]
+            L.ref_init_air.restype = C.c_long
+            L.ref_air_feed.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
+            L.ref_get_wf.argtypes = [C.c_int, C.c_void_p, C.c_int]
+            L.ref_get_wf.restype = C.c_int
         L.ref_dmlog_enable.argtypes = [C.c_size_t]
         L.ref_dmlog_count.argtypes = [C.c_int]
         L.ref_dmlog_count.restype = C.c_size_t
@@ -270,6 +324,31 @@ class Ref:
         out = np.zeros((self.M, 2), dtype=np.float32)
         fr = self.L.ref_get_oscillator(n, out.ctypes.data, self.M)
         return fr, out
+
+    def init_sdrplay(self, freqs_mhz):
+        arr = (C.c_char_p * len(freqs_mhz))(*[f.encode() for f in freqs_mhz])
+        fc = self.L.ref_init_sdrplay(len(freqs_mhz), arr)
+        if fc <= 0:
+            raise RuntimeError("initSdrplay failed (%d)" % fc)
+        self.M = 160
+        return fc
+
+    def sdrplay_feed(self, xi, xq, chunk=0):
+        xi = np.ascontiguousarray(xi, dtype=np.int16).reshape(-1)
+        xq = np.ascontiguousarray(xq, dtype=np.int16).reshape(-1)
+        self.L.ref_sdrplay_feed(xi.ctypes.data, xq.ctypes.data, xi.size, chunk)
+
+    def init_air(self, freqs_mhz, rate):
+        arr = (C.c_char_p * len(freqs_mhz))(*[f.encode() for f in freqs_mhz])
+        fc = self.L.ref_init_air(len(freqs_mhz), arr, rate)
+        if fc <= 0:
+            raise RuntimeError("initAirspy failed (%d)" % fc)
+        self.M = rate // INTRATE
+        return fc
+
+    def air_feed(self, x, chunk=0):
+        x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1)
+        self.L.ref_air_feed(x.ctypes.data, x.size, chunk)
 
     def dmlog_enable(self, cap):
         self.L.ref_dmlog_enable(cap)

@@ -26,6 +26,12 @@
 #ifdef WITH_SOAPY
 #include <SoapySDR/Device.h>
 #endif
+#ifdef WITH_SDRPLAY
+#include <mirsdrapi-rsp.h>
+#endif
+#ifdef WITH_AIR
+#include <libairspy/airspy.h>
+#endif
 #include "acarsdec.h"
 
 /* ---- globals the reference files expect (acarsdec.c:34-75) ---- */
@@ -44,6 +50,15 @@ double gain = -10.0;
 int ppm = 0;
 int rateMult = 160;
 int freq = 0;
+#endif
+#ifdef WITH_SDRPLAY
+int lnaState = 2;
+int GRdB = 20;
+int ppm = 0;
+int gain = 0;
+#endif
+#ifdef WITH_AIR
+int gain = 18;
 #endif
 
 #ifdef WITH_RTL
@@ -349,6 +364,136 @@ int ref_get_oscillator(int n, float *out, int M)
 	return (int)channel[n].Fr;
 }
 #endif /* WITH_SOAPY */
+
+#ifdef WITH_SDRPLAY
+/* ---- SDRplay API stand-ins ---- */
+mir_sdr_ErrT mir_sdr_ApiVersion(float *v) { *v = MIR_SDR_API_VERSION; return mir_sdr_Success; }
+mir_sdr_ErrT mir_sdr_GetDevices(mir_sdr_DeviceT *d, unsigned int *n, unsigned int m)
+{ (void)m; d[0].SerNo = (char *)"0"; d[0].DevNm = (char *)"stub"; d[0].hwVer = 1; d[0].devAvail = 1; *n = 1; return mir_sdr_Success; }
+mir_sdr_ErrT mir_sdr_SetDeviceIdx(unsigned int i) { (void)i; return mir_sdr_Success; }
+mir_sdr_ErrT mir_sdr_ReleaseDeviceIdx(void) { return mir_sdr_Success; }
+mir_sdr_ErrT mir_sdr_StreamInit(int *g, double fs, double rf, mir_sdr_Bw_MHzT bw, mir_sdr_If_kHzT i, int l, int *gs, mir_sdr_SetGrModeT m,
+				int *spp, mir_sdr_StreamCallback_t s, mir_sdr_GainChangeCallback_t c, void *x)
+{ (void)g; (void)fs; (void)rf; (void)bw; (void)i; (void)l; (void)gs; (void)m; (void)spp; (void)s; (void)c; (void)x; return mir_sdr_Success; }
+mir_sdr_ErrT mir_sdr_AgcControl(mir_sdr_AgcControlT e, int a, int b, unsigned int c, unsigned int d, int f, int g)
+{ (void)e; (void)a; (void)b; (void)c; (void)d; (void)f; (void)g; return mir_sdr_Success; }
+mir_sdr_ErrT mir_sdr_SetPpm(double p) { (void)p; return mir_sdr_Success; }
+mir_sdr_ErrT mir_sdr_SetDcMode(int a, int b) { (void)a; (void)b; return mir_sdr_Success; }
+mir_sdr_ErrT mir_sdr_SetDcTrackTime(int t) { (void)t; return mir_sdr_Success; }
+mir_sdr_ErrT mir_sdr_DCoffsetIQimbalanceControl(unsigned int a, unsigned int b) { (void)a; (void)b; return mir_sdr_Success; }
+
+int initSdrplay(char **argv, int optind);
+void ref_sdrplay_callback(int16_t *xi, int16_t *xq, uint32_t n);     /* ref_sdrplay_unit.c */
+unsigned int ref_sdrplay_fc(void);
+
+long ref_init_sdrplay(int nfreq, const char **freqs)
+{
+	char *argv[MAXNBCHANNELS + 2];
+	int i, r;
+	if (nfreq > MAXNBCHANNELS)
+		return -1;
+	for (i = 0; i < nfreq; i++)
+		argv[i] = (char *)freqs[i];
+	argv[nfreq] = NULL;
+	r = initSdrplay(argv, 0);
+	if (r)
+		return -2;
+	common_init();
+	return (long)ref_sdrplay_fc();
+}
+
+/* n samples per plane, delivered in callbacks of `chunk` samples (sdrplay.c:202-237 carries D) */
+void ref_sdrplay_feed(const int16_t *xi, const int16_t *xq, size_t n, size_t chunk)
+{
+	size_t pos = 0;
+	if (!chunk)
+		chunk = n;
+	while (pos < n) {
+		size_t k = n - pos < chunk ? n - pos : chunk;
+		ref_sdrplay_callback((int16_t *)xi + pos, (int16_t *)xq + pos, (uint32_t)k);
+		pos += k;
+	}
+}
+
+int ref_get_oscillator(int n, float *out, int M)
+{
+	int i;
+	for (i = 0; i < M; i++) {
+		out[2 * i] = crealf(channel[n].oscillator[i]);
+		out[2 * i + 1] = cimagf(channel[n].oscillator[i]);
+	}
+	return (int)channel[n].Fr;
+}
+#endif /* WITH_SDRPLAY */
+
+#ifdef WITH_AIR
+/* ---- libairspy stand-ins: one device, one sample rate (set by the test before init) ---- */
+static uint32_t g_air_rate = 2500000;
+static uint32_t g_air_freq;
+int airspy_list_devices(uint64_t *serials, int count) { if (serials && count > 0) serials[0] = 0x1234; return 1; }
+int airspy_open_sn(struct airspy_device **d, uint64_t sn) { (void)sn; *d = (struct airspy_device *)&g_air_rate; return AIRSPY_SUCCESS; }
+int airspy_open(struct airspy_device **d) { *d = (struct airspy_device *)&g_air_rate; return AIRSPY_SUCCESS; }
+int airspy_close(struct airspy_device *d) { (void)d; return AIRSPY_SUCCESS; }
+int airspy_exit(void) { return AIRSPY_SUCCESS; }
+const char *airspy_error_name(int e) { (void)e; return "stub"; }
+int airspy_set_sample_type(struct airspy_device *d, enum airspy_sample_type t) { (void)d; (void)t; return AIRSPY_SUCCESS; }
+int airspy_get_samplerates(struct airspy_device *d, uint32_t *b, const uint32_t len)
+{ (void)d; if (len == 0) *b = 1; else b[0] = g_air_rate; return AIRSPY_SUCCESS; }
+int airspy_set_samplerate(struct airspy_device *d, uint32_t s) { (void)d; (void)s; return AIRSPY_SUCCESS; }
+int airspy_set_packing(struct airspy_device *d, uint8_t v) { (void)d; (void)v; return AIRSPY_SUCCESS; }
+int airspy_set_linearity_gain(struct airspy_device *d, uint8_t v) { (void)d; (void)v; return AIRSPY_SUCCESS; }
+int airspy_set_vga_gain(struct airspy_device *d, uint8_t v) { (void)d; (void)v; return AIRSPY_SUCCESS; }
+int airspy_set_freq(struct airspy_device *d, const uint32_t f) { (void)d; g_air_freq = f; return AIRSPY_SUCCESS; }
+int airspy_r820t_write(struct airspy_device *d, uint8_t r, uint8_t v) { (void)d; (void)r; (void)v; return AIRSPY_SUCCESS; }
+int airspy_start_rx(struct airspy_device *d, airspy_sample_block_cb_fn cb, void *c) { (void)d; (void)cb; (void)c; return AIRSPY_SUCCESS; }
+int airspy_is_streaming(struct airspy_device *d) { (void)d; return 0; }
+
+int ref_air_callback(float *samples, int count);                   /* ref_air_unit.c */
+unsigned int ref_air_mult(void);
+
+/* acarsdec -s <dev> f1 f2 ... with a stub Airspy offering `rate` samples/s.  Returns Fc (air.c:246). */
+long ref_init_air(int nfreq, const char **freqs, unsigned int rate)
+{
+	char *argv[MAXNBCHANNELS + 3];
+	int i, r;
+	if (nfreq > MAXNBCHANNELS)
+		return -1;
+	g_air_rate = rate;
+	argv[0] = (char *)"0";
+	for (i = 0; i < nfreq; i++)
+		argv[1 + i] = (char *)freqs[i];
+	argv[1 + nfreq] = NULL;
+	nbch = 0;
+	r = initAirspy(argv, 0);
+	if (r)
+		return -2;
+	common_init();
+	return (long)g_air_freq;
+}
+
+void ref_air_feed(const float *x, size_t n, size_t chunk)
+{
+	size_t pos = 0;
+	if (!chunk)
+		chunk = n;
+	while (pos < n) {
+		size_t k = n - pos < chunk ? n - pos : chunk;
+		ref_air_callback((float *)x + pos, (int)k);
+		pos += k;
+	}
+}
+
+int ref_get_wf(int n, float *out, int M)
+{
+	int i;
+	for (i = 0; i < M; i++) {
+		out[2 * i] = crealf(channel[n].wf[i]);
+		out[2 * i + 1] = cimagf(channel[n].wf[i]);
+	}
+	return channel[n].Fr;
+}
+unsigned int ref_air_get_mult(void) { return ref_air_mult(); }
+#endif /* WITH_AIR */
 
 /* sound-file path (soundfile.c:30-56): nch channels of 12.5 kHz real samples */
 int ref_init_file(int nch)

@@ -173,6 +173,81 @@ def test_soapy_front_end_bit_identical_to_reference(M, chunk):
     assert res["nframes"] >= 3
 
 
+FE_CHILD = r'''
+import sys, json
+import numpy as np
+sys.path.insert(0, %(root)r)
+from oracle import oracle as O
+from acarsdec_amd import synth as S
+kind, seed, chunk = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+rng = np.random.default_rng(seed)
+freqs = ["131.525", "131.725", "131.825"]
+fr = [int(round(float(f) * 1e6)) for f in freqs]
+res = dict(ok=True, why=[])
+nblk = 3
+env = []
+for c in range(3):
+    a, _ = S.channel_audio(rng, nblk * 1024, nframes=1, gap=(300, 600), text_len=(5, 20))
+    env.append(0.5 * (1 + 0.5 * a))
+if kind == "sdrplay":
+    ref = O.Ref("_sdrplay"); M = 160
+    fc = ref.init_sdrplay(freqs)
+    if O.choose_fc(fr, M) != fc: res["ok"] = False; res["why"].append("fc %%d" %% fc)
+    iq = S.iq_s16_from_envelopes(np.array(env), M, [f - fc for f in fr], phases=[0.2, 1.0, 4.0], noise=0.01, rng=rng, full_scale=0.05)
+    xi, xq = iq[0::2].copy(), iq[1::2].copy()
+    ref.dmlog_enable(nblk * 1024)
+    ref.sdrplay_feed(xi, xq, chunk)
+    taps = [O.sdrplay_taps(float(fr[c]), fc) for c in range(3)]
+    dms = [O.fir_split16(xi, xq, M, taps[c]) for c in range(3)]
+    gettaps = lambda c: ref.L.ref_get_oscillator
+    step = 512
+else:
+    ref = O.Ref("_air"); rate = 2500000; M = rate // 12500
+    fc = ref.init_air(freqs, rate)
+    if O.air_choose_fc(fr) != fc: res["ok"] = False; res["why"].append("fc %%d" %% fc)
+    # air.c mixes with Fc - Fr + Fs/4: a channel at Fr sits at that frequency of the real spectrum
+    x = S.real_f32_from_envelopes(np.array(env), M, [fc - f + rate / 4 for f in fr], phases=[0.2, 1.0, 4.0], noise=0.01, rng=rng)
+    ref.dmlog_enable(nblk * 1024 + 8)
+    ref.air_feed(x, chunk)
+    taps = [O.air_taps(fr[c], fc, rate) for c in range(3)]
+    dms = [O.fir_f32r(x, M, taps[c]) for c in range(3)]
+    step = None
+ref.drain()
+import ctypes as C
+chs = [O.Channel(c) for c in range(3)]
+for c in range(3):
+    out = np.zeros((M, 2), dtype=np.float32)
+    (ref.L.ref_get_oscillator if kind == "sdrplay" else ref.L.ref_get_wf)(c, out.ctypes.data, M)
+    if not np.array_equal(out, taps[c]): res["ok"] = False; res["why"].append("taps%%d" %% c)
+    rd = ref.dmlog(c)
+    dm = dms[c]
+    if rd.size == 0 or not np.array_equal(dm[:rd.size], rd): res["ok"] = False; res["why"].append("dm%%d %%d" %% (c, rd.size))
+    chs[c].demod(dm[:rd.size])
+    a, b2 = ref.state(c), chs[c].state()
+    for k in a:
+        if not np.array_equal(np.asarray(a[k]), np.asarray(b2[k])): res["ok"] = False; res["why"].append("state %%d %%s" %% (c, k))
+def tup(f): return [int(f.chn), int(f.len), int(f.err), bytes(f.crc).hex(), bytes(f.txt[:f.len]).hex(), float(f.lvl).hex()]
+rf = sorted(tup(f) for f in ref.raw_frames()); of = sorted(tup(f) for c in chs for f in c.frames)
+if rf != of: res["ok"] = False; res["why"].append("frames %%d %%d" %% (len(rf), len(of)))
+res["nframes"] = len(rf)
+print(json.dumps(res))
+'''
+
+
+@pytest.mark.parametrize("kind,chunk", [("sdrplay", 0), ("sdrplay", 504), ("sdrplay", 1001), ("air", 32768), ("air", 65536), ("air", 1000)])
+def test_sdrplay_and_airspy_front_ends_bit_identical_to_reference(kind, chunk):
+    """sdrplay.c (split int16 planes, cabsf(D)/4) and air.c (real float32, complex taps): taps, centre
+    frequency, dm, demodulator state and blocks, with the stream cut into callbacks of any size."""
+    if not O.ref_available("_" + kind):
+        pytest.skip("oracle/_ref/libacarsref_%s.so not built" % kind)
+    r = subprocess.run([sys.executable, "-c", FE_CHILD % dict(root=ROOT), kind, str(7 + chunk), str(chunk)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["ok"], res["why"]
+    assert res["nframes"] >= 2
+
+
 def test_syndrome_table_regenerated_equals_reference_header():
     import re
     path = "/root/reference/syndrom.h"
