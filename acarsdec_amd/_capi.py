@@ -52,6 +52,9 @@ SYMBOLS = {
     "acg_fir_only_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "acg_sync": (C.c_int, [C.c_void_p]),
     "acg_soapy_taps": (C.c_int, [C.c_float, C.c_int, C.c_int, C.c_void_p]),
+    "acg_sdrplay_taps": (C.c_int, [C.c_float, C.c_uint, C.c_void_p]),
+    "acg_airspy_choose_fc": (C.c_uint, [C.c_uint, C.c_uint]),
+    "acg_airspy_taps": (C.c_int, [C.c_int, C.c_int, C.c_uint, C.c_void_p]),
     "acg_process_samples_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]),
     "acg_feed_samples_host": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
     "acg_drain_frames": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.c_int, C.POINTER(C.c_int)]),

@@ -120,3 +120,47 @@ int acg_soapy_taps(float Fr_hz, int freq_hz, int decim, float *taps_out)
 	}
 	return ACG_OK;
 }
+
+/* sdrplay.c:160-164 (fixed SDRPLAY_MULT = 160; the phase is a double there, unlike soapy.c) */
+int acg_sdrplay_taps(float Fr_hz, unsigned int Fc_hz, float *taps_out)
+{
+	const int decim = 160;
+	int k;
+	double phase;
+	if (!taps_out)
+		return ACG_EINVAL;
+	phase = (Fr_hz - (float)Fc_hz) / (float)(ACG_INTRATE * decim) * 2.0 * M_PI;
+	for (k = 0; k < decim; k++) {
+		const float complex w = cexpf(phase * k * -I) / decim;
+		taps_out[2 * k] = crealf(w);
+		taps_out[2 * k + 1] = cimagf(w);
+	}
+	return ACG_OK;
+}
+
+/* air.c:62: centre frequency without the R820T IF-filter branch (taken only at exactly 5 Msps) */
+unsigned int acg_airspy_choose_fc(unsigned int minF_hz, unsigned int maxF_hz)
+{
+	return ((maxF_hz + minF_hz) / 2 + ACG_INTRATE / 2) / ACG_INTRATE * ACG_INTRATE;
+}
+
+/* air.c:278-285: channels are mixed down from around Fs/4 of the real spectrum; the phase
+ * accumulates in double with wraps; Fc - Fr + Fs/4 is evaluated in unsigned arithmetic */
+int acg_airspy_taps(int Fr_hz, int Fc_hz, unsigned int inrate, float *taps_out)
+{
+	const unsigned int decim = inrate / ACG_INTRATE;
+	unsigned int i;
+	double AMFreq, Ph;
+	if (!taps_out || decim < 1 || decim * ACG_INTRATE != inrate)
+		return ACG_EINVAL;
+	AMFreq = 2.0 * M_PI * (double)(Fc_hz - Fr_hz + inrate / 4) / (double)(inrate);
+	for (i = 0, Ph = 0; i < decim; i++) {
+		const float complex w = cexpf(Ph * -I) / decim;
+		taps_out[2 * i] = crealf(w);
+		taps_out[2 * i + 1] = cimagf(w);
+		Ph += AMFreq;
+		if (Ph > 2.0 * M_PI) Ph -= 2.0 * M_PI;
+		if (Ph < -2.0 * M_PI) Ph += 2.0 * M_PI;
+	}
+	return ACG_OK;
+}

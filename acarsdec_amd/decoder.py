@@ -41,6 +41,22 @@ def soapy_taps(Fr_hz, freq_hz, decim):
     return out
 
 
+def sdrplay_taps(Fr_hz, Fc_hz):
+    out = np.zeros((160, 2), dtype=np.float32)
+    _chk(None, K.load().acg_sdrplay_taps(float(Fr_hz), int(Fc_hz), out.ctypes.data))
+    return out
+
+
+def airspy_taps(Fr_hz, Fc_hz, inrate):
+    out = np.zeros((inrate // K.INTRATE, 2), dtype=np.float32)
+    _chk(None, K.load().acg_airspy_taps(int(Fr_hz), int(Fc_hz), int(inrate), out.ctypes.data))
+    return out
+
+
+def airspy_choose_fc(freqs_hz):
+    return int(K.load().acg_airspy_choose_fc(int(min(freqs_hz)), int(max(freqs_hz))))
+
+
 def parse_freq_mhz(s):
     """rtl.c:245-247: command-line MHz string -> Hz rounded to the 12.5 kHz raster."""
     return (int(1000000 * float(s) + K.INTRATE / 2) // K.INTRATE) * K.INTRATE

@@ -132,6 +132,11 @@ int  acg_sync(acg_ctx *ctx);
 #define ACG_FMT_F32_REAL   3   /* real float32 samples, complex taps: air.c:314-324 */
 /* soapy.c:163-166 oscillator table ([decim][2]); ch->Fr is a float in that front end */
 int  acg_soapy_taps(float Fr_hz, int freq_hz, int decim, float *taps_out);
+/* sdrplay.c:160-164 (fixed rate multiplier 160) */
+int  acg_sdrplay_taps(float Fr_hz, unsigned int Fc_hz, float *taps_out);
+/* air.c:62 centre frequency (no IF-filter branch) and air.c:278-285 taps; inrate = 12500*decim */
+unsigned int acg_airspy_choose_fc(unsigned int minF_hz, unsigned int maxF_hz);
+int  acg_airspy_taps(int Fr_hz, int Fc_hz, unsigned int inrate, float *taps_out);
 /* Window-aligned device input: [nstreams] rows of nblocks*1024*decim samples (4 bytes per sample;
  * ACG_FMT_S16_SPLIT: I plane at the row start, Q plane plane_bytes further).  decim % 4 == 0
  * (8 for split planes), decim <= 208.  Same asynchronous contract as acg_process_iq_u8_dev. */

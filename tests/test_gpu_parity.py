@@ -432,6 +432,89 @@ def test_cs16_soapy_path_with_carry_matches_oracle(D, O, S, M, feeds):
     dec.close()
 
 
+def test_split16_sdrplay_and_f32_airspy_paths_match_oracle(D, O, S):
+    """sdrplay.c (two int16 planes, |D|/4) and air.c (real float32 around Fs/4): arbitrary callback sizes
+    with carry, then the window-aligned device path; dm within tolerance, blocks bit-exact."""
+    import torch
+    from acarsdec_amd import _capi as K
+    rng = np.random.default_rng(2718)
+    nch, nblk = 4, 4
+    nout = nblk * 1024
+    freqs = [131525000, 131725000, 131825000, 131550000]
+    env = []
+    for c in range(nch):
+        a, _ = S.channel_audio(rng, nout, gap=(400, 900), text_len=(3, 25))
+        env.append(0.5 * (1 + 0.5 * a))
+    env = np.array(env)
+    # ---- sdrplay
+    M = 160
+    fc = D.choose_fc(freqs, M)[0]
+    iq = S.iq_s16_from_envelopes(env, M, [f - fc for f in freqs], phases=np.linspace(0, 3, nch), scale=0.15, noise=0.01,
+                                 rng=rng, full_scale=0.06)
+    xi, xq = iq[0::2].copy(), iq[1::2].copy()
+    taps = np.stack([D.sdrplay_taps(float(f), fc) for f in freqs])
+    want = {}
+    for c in range(nch):
+        ch = O.Channel(c)
+        ch.demod(O.fir_split16(xi, xq, M, O.sdrplay_taps(float(freqs[c]), fc)))
+        want[c] = [O.frame_tuple(f) for f in ch.frames]
+    assert sum(len(v) for v in want.values()) >= nch - 1
+    dec = D.Decoder(nch, decim=M, nstreams=1, max_blocks=nblk)
+    dec.set_taps(taps)
+    got, pos = [], 0
+    for n in (504, 100000, 3, 10 ** 7):
+        n = min(n, xi.size - pos)
+        dec.feed(K.FMT_S16_SPLIT, xi[pos:pos + n].reshape(1, -1), xq[pos:pos + n].reshape(1, -1))
+        pos += n
+        got += [D.frame_tuple(f) for f in dec.drain_frames()]
+    assert blocks_by_channel_tuples(got) == {c: v for c, v in want.items() if v}
+    dec.close()
+    dec = D.Decoder(nch, decim=M, nstreams=1, max_blocks=nblk)
+    dec.set_taps(taps)
+    planes = torch.from_numpy(np.concatenate([xi, xq])).cuda()
+    dec.process_samples(K.FMT_S16_SPLIT, planes, nblk, pitch=planes.numel() * 2, plane=xi.size * 2)
+    assert blocks_by_channel(dec.drain_frames(), D.frame_tuple) == {c: v for c, v in want.items() if v}
+    for c in range(nch):
+        dm_o = O.fir_split16(xi, xq, M, O.sdrplay_taps(float(freqs[c]), fc))
+        dm_g = dec.dm(c, nout)
+        assert np.all(np.abs(dm_g - dm_o) <= 1e-5 * np.abs(dm_o) + 1e-6 * np.abs(dm_o).max())
+    dec.close()
+    # ---- airspy at 2.5 Msps real
+    rate = 2500000
+    M = rate // 12500
+    fc = D.airspy_choose_fc(freqs)
+    assert fc == O.air_choose_fc(freqs)
+    x = S.real_f32_from_envelopes(env, M, [fc - f + rate / 4 for f in freqs], phases=np.linspace(0, 3, nch), scale=0.15,
+                                  noise=0.01, rng=rng)
+    taps = np.stack([D.airspy_taps(f, fc, rate) for f in freqs])
+    want = {}
+    for c in range(nch):
+        ch = O.Channel(c)
+        ch.demod(O.fir_f32r(x, M, O.air_taps(freqs[c], fc, rate)))
+        want[c] = [O.frame_tuple(f) for f in ch.frames]
+    assert sum(len(v) for v in want.values()) >= nch - 1
+    dec = D.Decoder(nch, decim=M, nstreams=1, max_blocks=nblk)
+    dec.set_taps(taps)
+    got, pos = [], 0
+    for n in (65536, 1000, 300001, 10 ** 7):
+        n = min(n, x.size - pos)
+        dec.feed(K.FMT_F32_REAL, x[pos:pos + n].reshape(1, -1))
+        pos += n
+        got += [D.frame_tuple(f) for f in dec.drain_frames()]
+    assert blocks_by_channel_tuples(got) == {c: v for c, v in want.items() if v}
+    dec.close()
+    dec = D.Decoder(nch, decim=M, nstreams=1, max_blocks=nblk)
+    dec.set_taps(taps)
+    dx = torch.from_numpy(x).cuda()
+    dec.process_samples(K.FMT_F32_REAL, dx, nblk, pitch=x.size * 4)
+    assert blocks_by_channel(dec.drain_frames(), D.frame_tuple) == {c: v for c, v in want.items() if v}
+    for c in range(nch):
+        dm_o = O.fir_f32r(x, M, O.air_taps(freqs[c], fc, rate))
+        dm_g = dec.dm(c, nout)
+        assert np.all(np.abs(dm_g - dm_o) <= 1e-5 * np.abs(dm_o) + 1e-6)
+    dec.close()
+
+
 # ------------------------------------------------------------------------------------ block repair on the device (SURVEY 8f.1)
 def test_device_block_repair_matches_oracle_and_golden(D, O, S, testwav, golden):
     """ACG_F_REPAIR: what drain returns equals what the reference's blk_thread hands to outputmsg():

@@ -58,6 +58,15 @@ def test_soapy_taps_equal_oracle(M):
         assert np.array_equal(D.soapy_taps(fr, fc, M), O.soapy_taps(fr, fc, M))
 
 
+def test_sdrplay_and_airspy_taps_equal_oracle():
+    for fr, fc in ((131525000, 131850000), (131825000, 131850000), (129125000, 130100000)):
+        assert np.array_equal(D.sdrplay_taps(fr, fc), O.sdrplay_taps(fr, fc))
+    for rate in (2500000, 2000000):
+        for fr, fc in ((131525000, 131675000), (131825000, 131675000), (131725000, 131725000)):
+            assert np.array_equal(D.airspy_taps(fr, fc, rate), O.air_taps(fr, fc, rate))
+    assert D.airspy_choose_fc([131525000, 131825000]) == O.air_choose_fc([131525000, 131825000]) == 131675000
+
+
 def test_choose_fc_equals_oracle_random_sets():
     rng = np.random.default_rng(0)
     for _ in range(300):
