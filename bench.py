@@ -114,6 +114,8 @@ def main():
     ap.add_argument("--blocks", type=int, default=None, help="1024-output callbacks per channel per step")
     ap.add_argument("--check-channels", type=int, default=24, help="channels of rank 0 verified against the oracle")
     ap.add_argument("--random-bytes", action="store_true", help="uniform random input bytes instead of ACARS traffic")
+    ap.add_argument("--format", choices=["u8", "cs16", "split16", "f32"], default="u8",
+                    help="input sample format: u8 = rtl.c (headline); cs16 = soapy.c, split16 = sdrplay.c, f32 = air.c (SURVEY 8f.2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-child", nargs=4, default=None)
     args = ap.parse_args()
@@ -171,9 +173,18 @@ def main():
         taps[c] = tap_cache[o]
 
     # ---- inputs, resident in HBM: distinct bytes per channel, working set >> 256 MiB Infinity Cache
-    row = nblk * 1024 * M * 2
+    fmt = {"u8": 0, "cs16": K.FMT_CS16, "split16": K.FMT_S16_SPLIT, "f32": K.FMT_F32_REAL}[args.format]
+    bps = 2 if fmt == 0 else 4
+    row = nblk * 1024 * M * bps
     iq = torch.empty((nch, row), dtype=torch.uint8, device=dev)
-    if args.random_bytes:
+    if fmt == K.FMT_F32_REAL:
+        iq.view(torch.float32).normal_(0.0, 0.1)
+        data_desc = "gaussian float32 samples (format throughput run; parity of this format is covered by tests/)"
+    elif fmt != 0:
+        assert L.acg_fill_random_u8_dev(iq.data_ptr(), row, nch, row, 0xACA25 + rank, None) == 0
+        iq.view(torch.int16).bitwise_and_(0x0FFF)
+        data_desc = "uniform random int16 samples (format throughput run; parity of this format is covered by tests/)"
+    elif args.random_bytes:
         assert L.acg_fill_random_u8_dev(iq.data_ptr(), row, nch, row, 0xACA25 + rank, None) == 0
         data_desc = "uniform random bytes"
     else:
@@ -203,7 +214,10 @@ def main():
     def step(lag=1):
         """one pass of the hot path; decoded blocks are delivered to the host one call behind
         (streaming double buffering: the newest call keeps the GPU busy while the host collects)"""
-        dec.in_callback(iq, nblocks=nblk, pitch=row, stream=stream)
+        if fmt == 0:
+            dec.in_callback(iq, nblocks=nblk, pitch=row, stream=stream)
+        else:
+            dec.process_samples(fmt, iq, nblk, pitch=row, plane=row // 2 if fmt == K.FMT_S16_SPLIT else 0, stream=stream)
         return dec.collect_frames_raw(lag, maxfr)
 
     def barrier():
@@ -217,7 +231,7 @@ def main():
     n_first, fbuf = step(lag=0)
     first = [K.Frame.from_buffer_copy(fbuf[i]) for i in range(n_first)]
     parity = None
-    if rank == 0:
+    if rank == 0 and fmt == 0:
         from oracle import oracle as O
         ncheck = min(args.check_channels, nch)
         got = {}
@@ -272,7 +286,7 @@ def main():
         # 4 B per 12.5 kHz output written, taps (8 B each) read once per launch.  A step is split
         # into `lps` pipelined FIR launches (chunks of the step's callbacks).
         lps = max(1, round(tim["fir_launches"] / args.steps))
-        fir_bytes = nch * (nblk / lps) * 1024 * (2 * M + 4) + nch * ntaps * 8
+        fir_bytes = nch * (nblk / lps) * 1024 * (bps * M + 4) + nch * ntaps * 8
         fir_avg_ms = tim["fir_ms"] / max(1, tim["fir_launches"])
         msk_avg_ms = tim["msk_ms"] / max(1, tim["msk_launches"])
         achieved = fir_bytes / (fir_avg_ms * 1e-3) / 1e9
@@ -300,14 +314,15 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic: " + data_desc,
-            "config": {"workload": "BASELINE configs[%s]: %d channels/GPU x %.1f Msps u8 IQ, one stream per channel, rtlMult=%d, ntaps=%d, "
-                                   "%d callbacks (%.3f s of signal) per step; FIR decimate + MSK demod + framing, blocks delivered to the host (one call behind)"
-                                   % ({"throughput": "2", "stress": "4", "shard2048": "3"}[args.config], nch, 12500 * M / 1e6, M, ntaps, nblk, nblk * 0.08192),
-                       "channels_per_gpu": nch, "decim": M, "ntaps": ntaps, "blocks_per_step": nblk,
+            "config": {"workload": ("BASELINE configs[%s]: %d channels/GPU x %.1f Msps FORMAT_TAG input, one stream per channel, rtlMult=%d, ntaps=%d, "
+                                    "%d callbacks (%.3f s of signal) per step; FIR decimate + MSK demod + framing, blocks delivered to the host (one call behind)"
+                                    % ({"throughput": "2", "stress": "4", "shard2048": "3"}[args.config], nch, 12500 * M / 1e6, M, ntaps, nblk, nblk * 0.08192)).replace(
+                                        "FORMAT_TAG", {"u8": "u8 IQ", "cs16": "CS16 IQ", "split16": "split int16 I/Q", "f32": "real f32"}[args.format]),
+                       "input_format": args.format, "channels_per_gpu": nch, "decim": M, "ntaps": ntaps, "blocks_per_step": nblk,
                        "realtime_channels_equiv": int(value / (12500 * M / 1e6)),
                        "arithmetic": "u8 in, f32 down-converter and matched filter, f64 VCO/PLL/normalisation (as the reference)",
                        "preset": args.config, "channels_total": nch_total, "blocks_decoded_timed": int(nfr_total)},
-            "roofline": {"bound": "hbm", "kernel": "fir_u8_tile_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "fir_u8_persist_kernel" if fmt == 0 else "fir_fmt_kernel<%s>" % args.format, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "bytes_per_launch": int(fir_bytes), "avg_launch_ms": round(fir_avg_ms, 4), "launches_per_step": lps,
                          "frac_of_measured_copy_ceiling_6290": round(achieved / 6290.0, 4),
