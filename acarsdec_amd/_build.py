@@ -81,9 +81,29 @@ def build_demo(force=False):
     return DEMO
 
 
+DEMO_RTL = os.path.join(LIBDIR, "acarsdec_gpu_rtl")
+
+
+def build_demo_rtl(force=False):
+    """Reference acarsdec.c + rtl.c + acars.c + output.c ... UNCHANGED, with compat_msk.c instead of msk.c
+    and a file-playing librtlsdr stand-in that hands the buffers to acarsdec_amd_in_callback()."""
+    if not os.path.exists(os.path.join(REF, "rtl.c")):
+        return DEMO_RTL if os.path.exists(DEMO_RTL) else None
+    build_lib()
+    demo_dir = os.path.join(CSRC, "demo")
+    ref_units = ["acarsdec.c", "acars.c", "rtl.c", "output.c", "label.c", "cJSON.c", "netout.c", "fileout.c"]
+    mine = [os.path.join(CSRC, "compat_msk.c"), os.path.join(demo_dir, "demo_rtlsdr_file.c")]
+    srcs = [os.path.join(REF, u) for u in ref_units] + mine
+    if force or _newer(srcs + [LIB], DEMO_RTL):
+        _run(["gcc", "-O2", "-w", "-DWITH_RTL", "-DUSE_AMD_IN_CALLBACK", "-I" + REF, "-I" + INC, "-I" + demo_dir] + srcs +
+             ["-o", DEMO_RTL, "-L" + LIBDIR, "-lacarsdec_amd", "-Wl,-rpath,$ORIGIN", "-lm", "-lpthread"])
+    return DEMO_RTL
+
+
 def build_all(force=False):
     lib = build_lib(force)
     demo = build_demo(force)
+    build_demo_rtl(force)
     return lib, demo
 
 

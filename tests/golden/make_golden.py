@@ -117,6 +117,26 @@ def main():
                     recs.append(d)
             prog["o4"]["records"] = recs
     gold["program"] = prog
+    # the rtl.c path of the whole program: reference acarsdec.c + rtl.c + msk.c ... fed by the file-playing
+    # librtlsdr stand-in (acarsdec_amd/csrc/demo) with the same synthetic I/Q plus 4 blocks of bare carrier
+    import re
+    import tempfile
+    rate, pcm = O.read_wav_pcm16(WAV)
+    x = O.wav_to_float(pcm)
+    fr = [int(round(float(f) * 1e6)) for f in RTL_FREQS]
+    fc = gold["rtl"]["Fc"]
+    env = S.pad_blocks(0.5 + 0.5 * x.T.astype(np.float64), 1024, 0.5)
+    env = np.concatenate([env, np.full((4, 4096), 0.5)], axis=1)
+    iq = S.iq_u8_from_envelopes(env, RTL_M, [f - fc for f in fr], phases=RTL_PHASES)
+    with tempfile.NamedTemporaryFile(suffix=".iq", delete=False) as f:
+        f.write(iq.tobytes())
+        path = f.name
+    args = ["-o", "1", "-r", "0"] + RTL_FREQS
+    r = subprocess.run([os.path.join(ROOT, "oracle", "_ref", "acarsdec_cpu_rtl")] + args,
+                       env=dict(os.environ, ACARSDEC_IQ_FILE=path), capture_output=True)
+    os.unlink(path)
+    gold["program_rtl"] = dict(args=args, tail_blocks=4, iq_sha256=hashlib.sha256(iq.tobytes()).hexdigest(),
+                               stdout_no_timestamps=re.sub(r"\d\d/\d\d/\d{4} \d\d:\d\d:\d\d\.\d{3} ", "", r.stdout.decode("latin-1")))
     with open(os.path.join(HERE, "testwav_golden.json"), "w") as f:
         json.dump(gold, f, indent=1)
     print("wrote fixtures:", sorted(os.listdir(HERE)))

@@ -588,6 +588,30 @@ def test_compat_program_output_is_golden(golden, tmp_path):
     assert recs == golden["program"]["o4"]["records"]
 
 
+def test_compat_rtl_program_output_is_golden(golden, testwav, S, tmp_path):
+    """The rtl.c path end to end: the reference's UNCHANGED acarsdec.c + rtl.c + acars.c + output.c, compat_msk.c
+    instead of msk.c, and a file-playing dongle that hands every buffer to acarsdec_amd_in_callback()
+    (= the one-line change at rtl.c:364): `acarsdec -o 1 -r 0 f1 f2 f3 f4` prints what the CPU reference prints."""
+    import hashlib
+    import re
+    exe = os.path.join(ROOT, "acarsdec_amd", "lib", "acarsdec_gpu_rtl")
+    if not os.path.exists(exe):
+        pytest.skip("demo binary not built (needs the reference tree at build time)")
+    g, pr = golden["rtl"], golden["program_rtl"]
+    fr = [int(round(float(f) * 1e6)) for f in g["freqs"]]
+    env = S.pad_blocks(0.5 + 0.5 * testwav.T.astype(np.float64), 1024, 0.5)
+    env = np.concatenate([env, np.full((4, 1024 * pr["tail_blocks"]), 0.5)], axis=1)
+    iq = S.iq_u8_from_envelopes(env, g["M"], [f - g["Fc"] for f in fr], phases=g["phases"])
+    if hashlib.sha256(iq.tobytes()).hexdigest() != pr["iq_sha256"]:
+        pytest.skip("numpy produced different synthetic IQ bytes than when the fixture was made")
+    path = tmp_path / "t.iq"
+    path.write_bytes(iq.tobytes())
+    r = subprocess.run([exe] + pr["args"], env=dict(os.environ, ACARSDEC_IQ_FILE=str(path)), capture_output=True, timeout=300)
+    out = re.sub(r"\d\d/\d\d/\d{4} \d\d:\d\d:\d\d\.\d{3} ", "", r.stdout.decode("latin-1"))
+    assert out == pr["stdout_no_timestamps"], out + r.stderr.decode("latin-1")[-800:]
+    assert out.count("\n") == 7
+
+
 def test_replay_sink_matches_device_blocks(D, O, testwav):
     """acg_replay_bits hands every bit to a putbit()-shaped sink; feeding an oracle FSM from it
     yields the same blocks the device assembled."""
