@@ -147,6 +147,15 @@ __device__ __forceinline__ void decode_acars(Lane& L, const MskArgs& a, int ch, 
 // Sun Microsystems 1993, freely distributable; < 1 ulp).  The reference calls glibc's cexp (also
 // < 1 ulp, different algorithm): results agree to the last bit except in rare last-place cases,
 // and only the float-rounded product in*cos / in*sin is kept (msk.c:90).
+// acc*z + C with the constant as an SGPR operand: one v_fma_f64.  (Left to the compiler, every Horner
+// step becomes v_mov_b64 + v_fmac_f64 because the constant has to be copied into the accumulator.)
+__device__ __forceinline__ double fma_zc(double acc, double z, double c)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(acc), "v"(z), "s"(c));
+    return r;
+}
+
 __device__ __forceinline__ void sincos_2pi(double x, double* sn, double* cs)
 {
     const double kd = __builtin_rint(x * 6.36619772367581382433e-01);           // x * 2/pi
@@ -158,21 +167,21 @@ __device__ __forceinline__ void sincos_2pi(double x, double* sn, double* cs)
     const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
                  S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
                  S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-    double ps = __builtin_fma(z, S6, S5);
-    ps = __builtin_fma(z, ps, S4);
-    ps = __builtin_fma(z, ps, S3);
-    ps = __builtin_fma(z, ps, S2);
+    double ps = fma_zc(S6, z, S5);
+    ps = fma_zc(ps, z, S4);
+    ps = fma_zc(ps, z, S3);
+    ps = fma_zc(ps, z, S2);
     const double v = z * r;
-    const double s = __builtin_fma(v, __builtin_fma(z, ps, S1), r);
+    const double s = __builtin_fma(v, fma_zc(ps, z, S1), r);
     // cos kernel
     const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
                  C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
                  C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
-    double pc = __builtin_fma(z, C6, C5);
-    pc = __builtin_fma(z, pc, C4);
-    pc = __builtin_fma(z, pc, C3);
-    pc = __builtin_fma(z, pc, C2);
-    pc = __builtin_fma(z, pc, C1);
+    double pc = fma_zc(C6, z, C5);
+    pc = fma_zc(pc, z, C4);
+    pc = fma_zc(pc, z, C3);
+    pc = fma_zc(pc, z, C2);
+    pc = fma_zc(pc, z, C1);
     const double hz = 0.5 * z;
     const double w = 1.0 - hz;
     const double c = w + (((1.0 - w) - hz) + z * (z * pc));
@@ -299,7 +308,7 @@ __global__ __launch_bounds__(ACG_WG_MSK) void msk_demod_kernel(const MskArgs a)
         // sample from within +-s/2 of zero to 3pi/2 - s/2), so the first four steps neither fire
         // nor hit the end of the buffer.  With s > 0 the clock is monotonic, so "none of the first
         // four fired" is decided by the fourth value alone.  Same operations, same order, fewer
-        // predicated instructions; anything unusual takes the general loop below.
+        // predicated instructions; anything unusual takes the one-sample pass below.
         double p4 = p;
         float c4 = L.clk;
         double pq[4];
@@ -311,8 +320,7 @@ __global__ __launch_bounds__(ACG_WG_MSK) void msk_demod_kernel(const MskArgs a)
             pq[u] = p4;
         }
         const bool quick = (s > 0) && !((double)c4 >= thr) && (n + 4 <= len);
-        if (__all(quick || n >= len)) {
-            if (n < len) {
+        if (n < len && quick) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     if ((u % LPC) == g) myp[u / LPC] = pq[u];
@@ -333,22 +341,18 @@ __global__ __launch_bounds__(ACG_WG_MSK) void msk_demod_kernel(const MskArgs a)
                     }
                     if ((u % LPC) == g) myp[u / LPC] = pn;
                 }
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < 6; ++u) {
-                const bool go = !fired && (n + u < len);
-                double pn = p + s;                                         // msk.c:82-83
-                if (pn >= K_TWOPI) pn -= K_TWOPI;
-                const float cn = (float)((double)L.clk + s);               // msk.c:95
-                if (go) {
-                    p = pn;
-                    L.clk = cn;
-                    cnt = u + 1;
-                    fired = (double)cn >= thr;
-                }
-                if ((u % LPC) == g) myp[u / LPC] = pn;
-            }
+        } else if (n < len) {
+            // anything unusual (buffer tail, a clock that is not where a locked loop keeps it): THIS channel
+            // advances one sample in this pass (its bit period is then simply spread over several passes)
+            // while the others do their normal period; it is back in step as soon as its bit fires
+            double pn = p + s;                                             // msk.c:82-83
+            if (pn >= K_TWOPI) pn -= K_TWOPI;
+            const float cn = (float)((double)L.clk + s);                   // msk.c:95
+            p = pn;
+            L.clk = cn;
+            cnt = 1;
+            fired = (double)cn >= thr;
+            if (g == 0) myp[0] = pn;
         }
         // ---- B: mixer for the cnt samples, spread over the group's lanes (msk.c:86-91)
 #pragma unroll
@@ -406,17 +410,15 @@ __global__ __launch_bounds__(ACG_WG_MSK) void msk_demod_kernel(const MskArgs a)
             vi = (float)((double)vi / d);
             L.lvlsum += (double)(lvl * lvl / 4);
             L.bitcount++;
-            // decision + phase detector, msk.c:115-121
-            float vo;
-            double dphi;
-            if (L.S & 1) {
-                vo = vi;
-                dphi = (vo >= 0) ? -(double)vr : (double)vr;
-            } else {
-                vo = vr;
-                dphi = (vo >= 0) ? (double)vi : -(double)vi;
-            }
-            const float sv = (L.S & 2) ? -vo : vo;                         // msk.c:122-126
+            // decision + phase detector, msk.c:115-121, as sign-bit arithmetic (exact: only signs move):
+            //   odd  S: vo = Im v, dphi = (vo >= 0) ? -Re v :  Re v
+            //   even S: vo = Re v, dphi = (vo >= 0) ?  Im v : -Im v
+            const bool odd = (L.S & 1) != 0;
+            const float vo = odd ? vi : vr;
+            const float ot = odd ? vr : vi;
+            const unsigned int flip = ((vo >= 0) == odd) ? 0x80000000u : 0u;
+            const double dphi = (double)__uint_as_float(__float_as_uint(ot) ^ flip);
+            const float sv = __uint_as_float(__float_as_uint(vo) ^ ((L.S & 2u) << 30));   // msk.c:122-126
             if (bits && nb < a.bit_cap) bits[nb] = make_float2(sv, lvl);
             ++nb;
             // putbit, msk.c:53-63
