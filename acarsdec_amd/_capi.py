@@ -9,6 +9,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libacarsdec_amd.so")
 OK, EINVAL, ENOMEM, EHIP, ENODEV, EOVERFLOW, ESTATE = 0, -1, -2, -3, -4, -5, -6
 F_BITLOG, F_TIMING, F_REPAIR = 1, 2, 4
 INTRATE, BLOCK, MAXDECIM, FLEN, TXTMAX = 12500, 1024, 320, 11, 250
+MAXDECIM_SAMPLES = 1024
 FMT_CS16, FMT_S16_SPLIT, FMT_F32_REAL = 1, 2, 3
 
 

@@ -154,7 +154,7 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
     if (!out || !cfg) return ACG_EINVAL;
     *out = nullptr;
     if (cfg->nch < 1 || cfg->nstreams < 1 || cfg->nstreams > cfg->nch || cfg->decim < 1 ||
-        cfg->decim > ACG_MAXDECIM || cfg->ntaps < 1 || cfg->ntaps > cfg->decim || cfg->max_blocks < 1)
+        cfg->decim > ACG_MAXDECIM_SAMPLES || cfg->ntaps < 1 || cfg->ntaps > cfg->decim || cfg->max_blocks < 1)
         return ACG_EINVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || cfg->device < 0 || cfg->device >= ndev)
@@ -418,6 +418,7 @@ static int check_iq_args(acg_ctx* ctx, const void* p, size_t pitch, int nblocks)
 {
     if (!ctx || !p) return ACG_EINVAL;
     if (nblocks < 1 || nblocks > ctx->cfg.max_blocks) return fail(ctx, ACG_EINVAL, "nblocks out of range");
+    if (ctx->cfg.decim > ACG_MAXDECIM) return fail(ctx, ACG_EINVAL, "u8 I/Q path: decim above RTLMULTMAX (rtl.c:39)");
     const size_t row = (size_t)nblocks * ACG_BLOCK * ctx->cfg.decim * 2;
     if (ctx->cfg.nstreams > 1 && pitch < row) return fail(ctx, ACG_EINVAL, "pitch smaller than a row");
     return ACG_OK;
@@ -777,8 +778,8 @@ static int fmt_geometry(acg_ctx* ctx, int fmt, FirArgs* a, int nwin)
 {
     const acg_config& g = ctx->cfg;
     if (fmt < ACG_FMT_CS16 || fmt > ACG_FMT_F32_REAL) return fail(ctx, ACG_EINVAL, "unknown sample format");
-    if (g.decim % (fmt == ACG_FMT_S16_SPLIT ? 8 : 4) || g.decim > 208)
-        return fail(ctx, ACG_EINVAL, "this sample format needs decim % 4 == 0 (8 for split planes) and decim <= 208");
+    if (g.decim % (fmt == ACG_FMT_S16_SPLIT ? 8 : 4) || (fmt == ACG_FMT_S16_SPLIT && g.decim > 208))
+        return fail(ctx, ACG_EINVAL, "this sample format needs decim % 4 == 0 (split planes: % 8 and <= 208)");
     std::memset(a, 0, sizeof(*a));
     a->stream_of = ctx->d_stream_of;
     a->taps = ctx->d_taps;
@@ -789,8 +790,10 @@ static int fmt_geometry(acg_ctx* ctx, int fmt, FirArgs* a, int nwin)
     a->ntaps_pad = ctx->ntaps_pad;
     a->nwin = nwin;
     a->row_bytes = 4 * g.decim;
-    a->cpr = a->row_bytes / 16;
-    a->row_stride = (a->cpr & 1) ? a->row_bytes : a->row_bytes + 16;
+    a->cpr_total = a->row_bytes / 16;
+    a->kseg = (a->cpr_total + 51) / 52;                 // LDS slice <= 52 chunks per window (Airspy: 480 -> 3 x 40, 800 -> 4 x 50)
+    a->cpr = (a->cpr_total + a->kseg - 1) / a->kseg;
+    a->row_stride = 16 * ((a->cpr & 1) ? a->cpr : a->cpr + 1);
     a->cpr_magic = ((1u << 20) + (unsigned int)a->cpr - 1) / (unsigned int)a->cpr;
     a->nseg = 1;
     a->out_scale = fmt == ACG_FMT_CS16 ? 1.0f / 32768.0f : fmt == ACG_FMT_S16_SPLIT ? 0.25f : 1.0f;
@@ -798,37 +801,53 @@ static int fmt_geometry(acg_ctx* ctx, int fmt, FirArgs* a, int nwin)
     return ACG_OK;
 }
 
-// FIR(fmt) on stream s, then the demodulator on the context's stream; one call = one chunk
+// Same software pipeline as acg_process_iq_u8_dev: down-converter chunks on stream s, demodulator
+// chunks in order on the context's stream, per-block guards on the dm buffer.
 static int run_fmt(acg_ctx* ctx, int fmt, FirArgs* a, hipStream_t s)
 {
-    const int nblk_guard = std::min(ctx->cfg.max_blocks, (a->nwin + ACG_BLOCK - 1) / ACG_BLOCK);
-    for (int j = 0; j < nblk_guard; ++j)
-        if (ctx->msk_done_valid[(size_t)j]) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->msk_done[(size_t)j], 0));
+    const int nwin = a->nwin;
+    const uint8_t* iq0 = a->iq;
+    const size_t win_bytes = (size_t)(fmt == ACG_FMT_S16_SPLIT ? a->row_bytes / 2 : a->row_bytes);
+    int cb = ctx->pipe_blocks > 0 ? (ctx->pipe_blocks + 1) / 2 : ctx->cfg.max_blocks;   // 4-byte samples: half the callbacks per ~2 GB
+    const int cw = cb * ACG_BLOCK;
     const bool timing = (ctx->cfg.flags & ACG_F_TIMING) != 0;
-    EvPair ev{};
-    if (timing) {
-        int r;
-        if ((r = get_event(ctx, &ev.a)) != ACG_OK || (r = get_event(ctx, &ev.b)) != ACG_OK) return r;
-        HIPCHK(ctx, hipEventRecord(ev.a, s));
+    int k = 0;
+    for (int w0 = 0; w0 < nwin; w0 += cw, ++k) {
+        const int nw = std::min(cw, nwin - w0);
+        const int j0 = w0 / ACG_BLOCK;
+        const int j1 = std::min(ctx->cfg.max_blocks, (w0 + nw + ACG_BLOCK - 1) / ACG_BLOCK);
+        for (int j = j0; j < j1; ++j)
+            if (ctx->msk_done_valid[(size_t)j]) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->msk_done[(size_t)j], 0));
+        a->iq = iq0 + (size_t)w0 * win_bytes;
+        a->dm = ctx->d_dm + w0;
+        a->nwin = nw;
+        EvPair ev{};
+        if (timing) {
+            int r;
+            if ((r = get_event(ctx, &ev.a)) != ACG_OK || (r = get_event(ctx, &ev.b)) != ACG_OK) return r;
+            HIPCHK(ctx, hipEventRecord(ev.a, s));
+        }
+        const int e = acg_launch_fir_fmt(a, fmt, s);
+        if (e != 0) {
+            ctx->err = std::string("FIR launch: ") + hipGetErrorString((hipError_t)e);
+            return ACG_EHIP;
+        }
+        if (timing) {
+            HIPCHK(ctx, hipEventRecord(ev.b, s));
+            ctx->fir_ev.push_back(ev);
+        }
+        HIPCHK(ctx, hipEventRecord(ctx->fir_done[(size_t)k], s));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->msk_stream, ctx->fir_done[(size_t)k], 0));
+        int r = launch_msk(ctx, ctx->d_dm + w0, ctx->dm_pitch, nw, ctx->msk_stream, w0 > 0);
+        if (r != ACG_OK) return r;
+        for (int j = j0; j < j1; ++j) {
+            HIPCHK(ctx, hipEventRecord(ctx->msk_done[(size_t)j], ctx->msk_stream));
+            ctx->msk_done_valid[(size_t)j] = 1;
+        }
     }
-    const int e = acg_launch_fir_fmt(a, fmt, s);
-    if (e != 0) {
-        ctx->err = std::string("FIR launch: ") + hipGetErrorString((hipError_t)e);
-        return ACG_EHIP;
-    }
-    if (timing) {
-        HIPCHK(ctx, hipEventRecord(ev.b, s));
-        ctx->fir_ev.push_back(ev);
-    }
-    HIPCHK(ctx, hipEventRecord(ctx->fir_done[0], s));
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->msk_stream, ctx->fir_done[0], 0));
-    int r = launch_msk(ctx, ctx->d_dm, ctx->dm_pitch, a->nwin, ctx->msk_stream, false);
-    if (r != ACG_OK) return r;
-    for (int j = 0; j < nblk_guard; ++j) {
-        HIPCHK(ctx, hipEventRecord(ctx->msk_done[(size_t)j], ctx->msk_stream));
-        ctx->msk_done_valid[(size_t)j] = 1;
-    }
-    ctx->last_len = a->nwin;
+    a->iq = iq0;
+    a->nwin = nwin;
+    ctx->last_len = nwin;
     return end_of_call(ctx);
 }
 

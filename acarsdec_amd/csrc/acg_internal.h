@@ -61,6 +61,8 @@ struct FirArgs {
     int cpr;                    // 16-byte chunks per row = row_bytes/16
     unsigned int cpr_magic;     // ceil(2^20 / cpr): c / cpr == (c * magic) >> 20 for c < 2^11
     size_t plane;               // FMT_SPLIT: byte distance from a stream's I plane to its Q plane
+    int kseg;                   // format kernels: column segments per window (long windows pass through LDS in kseg slices)
+    int cpr_total;              // format kernels: 16-byte chunks per whole window (cpr = chunks per slice)
     float out_scale;            // power-of-two scale applied to |D| (1, 1/32768 soapy.c:241, 1/4 sdrplay.c:225)
     unsigned int* work_counter; // run dispenser of the dynamically scheduled kernel (one word per launch in flight)
 };

@@ -433,12 +433,13 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_dma_kernel(const FirArgs a,
 //   FMT_CS16   interleaved int16 I,Q        soapy.c:238-241   (x/32768 folded into the output scale)
 //   FMT_SPLIT  int16 I plane + int16 Q plane sdrplay.c:219-223 (cabsf(D)/4 = output scale)
 //   FMT_F32R   real float32 samples          air.c:314-324     (complex tap x real sample)
-// A row (one window) is 4*M bytes in LDS; for FMT_SPLIT it is [I half | Q half].  Static contiguous
-// partition of the (channel, tile) space, non-temporal loads, taps through scalar loads.
+// A row (one window) is 4*M bytes in LDS; for FMT_SPLIT it is [I half | Q half]; windows longer than
+// 52 chunks go through LDS in column slices.  Static contiguous partition of the (channel, tile)
+// space, non-temporal loads, taps through scalar loads.
 #define FMT_CS16 1
 #define FMT_SPLIT 2
 #define FMT_F32R 3
-#define FMT_MAXLD 14   // 64 rows * 832 B (M = 208) / 16 B / 256 threads
+#define FMT_MAXLD 14   // 64 rows * 52 chunks (one slice) / 256 threads
 
 template <int FMT>
 __global__ __launch_bounds__(ACG_WG_FIR) void fir_fmt_kernel(const FirArgs a,
@@ -456,26 +457,29 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_fmt_kernel(const FirArgs a,
     const long long g1 = G * (blockIdx.x + 1) / gridDim.x;
     if (g0 >= g1) return;
 
-    const int cpr = a.cpr;                              // 16-byte chunks per LDS row
-    const int half = cpr >> 1;                          // FMT_SPLIT: chunks per plane row
+    // A window longer than 52 chunks (Airspy: 480 / 800 samples) passes through LDS in K column
+    // slices of cpr chunks; the partial sums stay in registers across the slices of one tile.
+    const int K = a.kseg;
+    const int cpr = a.cpr;                              // 16-byte chunks per LDS row (one slice)
+    const int half = cpr >> 1;                          // FMT_SPLIT: chunks per plane row (K == 1)
     const int tile_chunks = ACG_TILE_WIN * cpr;
-    const int pad = a.row_stride - a.row_bytes;
+    const int pad = a.row_stride - (cpr << 4);
     const unsigned int magic = a.cpr_magic;
     unsigned char* tileL = fir_smem;
     float4* red = (float4*)(fir_smem + ACG_TILE_WIN * a.row_stride);
     constexpr int SPC = (FMT == FMT_SPLIT) ? 8 : 4;     // samples (taps) per inner step
-    const int nstep = a.ntaps_pad / SPC;
-    const int c0 = nstep * wave / 4;
-    const int c1 = nstep * (wave + 1) / 4;
+    const int nstep_total = a.ntaps_pad / SPC;
     const int nld = (tile_chunks + ACG_WG_FIR - 1) / ACG_WG_FIR;
 
     int ch = (int)(g0 / ntile);
     int t = (int)(g0 - (long long)ch * ntile);
+    int k = 0;
     uint4 stage[FMT_MAXLD];
 
-    auto fetch = [&](int fch, int ft) {
+    auto fetch = [&](int fch, int ft, int fk) {
         const uint8_t* __restrict__ src = in_base + (size_t)stream_of[fch] * a.pitch;
         typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+        const int col0 = fk * cpr;
 #pragma unroll
         for (int i = 0; i < FMT_MAXLD; ++i) {
             if (i < nld) {
@@ -485,13 +489,13 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_fmt_kernel(const FirArgs a,
                     const int r = (int)(((unsigned int)c * magic) >> 20);
                     const int col = c - r * cpr;
                     const int win = ft * ACG_TILE_WIN + r;
-                    if (win < a.nwin) {
+                    if (win < a.nwin && col0 + col < a.cpr_total) {
                         size_t off;
                         if (FMT == FMT_SPLIT)           // I plane, then Q plane a.plane bytes further
                             off = (col < half) ? (size_t)win * (a.row_bytes >> 1) + ((size_t)col << 4)
                                                : a.plane + (size_t)win * (a.row_bytes >> 1) + ((size_t)(col - half) << 4);
                         else
-                            off = (size_t)win * a.row_bytes + ((size_t)col << 4);
+                            off = (size_t)win * a.row_bytes + ((size_t)(col0 + col) << 4);
                         const u4v x = __builtin_nontemporal_load((const u4v*)(src + off));
                         v = make_uint4(x.x, x.y, x.z, x.w);
                     }
@@ -501,8 +505,11 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_fmt_kernel(const FirArgs a,
         }
     };
 
-    fetch(ch, t);
-    for (long long g = g0; g < g1; ++g) {
+    f2 accA = {0.f, 0.f};       // CS16/SPLIT: (sum r*wr, sum g*wi)   F32R: (sum s*wr, sum s*wi)
+    f2 accB = {0.f, 0.f};       // CS16/SPLIT: (sum r*wi, sum g*wr)
+    const long long u1 = (g1 - g0) * K;
+    fetch(ch, t, 0);
+    for (long long u = 0; u < u1; ++u) {
 #pragma unroll
         for (int i = 0; i < FMT_MAXLD; ++i) {
             if (i < nld) {
@@ -514,13 +521,18 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_fmt_kernel(const FirArgs a,
             }
         }
         __syncthreads();
-        int nch_ = ch, nt_ = t + 1;
-        if (nt_ == ntile) { nt_ = 0; ++nch_; }
-        if (g + 1 < g1) fetch(nch_, nt_);
+        int nch_ = ch, nt_ = t, nk_ = k + 1;
+        if (nk_ == K) {
+            nk_ = 0;
+            if (++nt_ == ntile) { nt_ = 0; ++nch_; }
+        }
+        if (u + 1 < u1) fetch(nch_, nt_, nk_);
 
-        const float* __restrict__ taps = taps_base + (size_t)ch * a.ntaps_pad * 2;
-        f2 accA = {0.f, 0.f};       // CS16/SPLIT: (sum r*wr, sum g*wi)   F32R: (sum s*wr, sum s*wi)
-        f2 accB = {0.f, 0.f};       // CS16/SPLIT: (sum r*wi, sum g*wr)
+        // this slice's inner steps, split over the 4 waves
+        const int nstep = (FMT == FMT_SPLIT) ? nstep_total : max(0, min(cpr, nstep_total - k * cpr));
+        const int c0 = nstep * wave / 4;
+        const int c1 = nstep * (wave + 1) / 4;
+        const float* __restrict__ taps = taps_base + (size_t)ch * a.ntaps_pad * 2 + (size_t)k * cpr * SPC * 2;
         const unsigned char* rowp = tileL + lane * a.row_stride;
         for (int c = c0; c < c1; ++c) {
             const float* __restrict__ w = taps + c * SPC * 2;                  // wave-uniform
@@ -563,24 +575,31 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_fmt_kernel(const FirArgs a,
                 }
             }
         }
-        red[wave * 64 + lane] = make_float4(accA.x, accA.y, accB.x, accB.y);
-        __syncthreads();
-        if (wave == 0) {
-            const float4 r0 = red[lane], r1 = red[64 + lane], r2 = red[128 + lane], r3 = red[192 + lane];
-            float Dr, Di;
-            if (FMT == FMT_F32R) {
-                Dr = (r0.x + r1.x) + (r2.x + r3.x);
-                Di = (r0.y + r1.y) + (r2.y + r3.y);
-            } else {
-                Dr = ((r0.x + r1.x) + (r2.x + r3.x)) - ((r0.y + r1.y) + (r2.y + r3.y));
-                Di = ((r0.z + r1.z) + (r2.z + r3.z)) + ((r0.w + r1.w) + (r2.w + r3.w));
+        if (nk_ == 0) {                                 // last slice of this tile: reduce the 4 waves, emit |D|
+            red[wave * 64 + lane] = make_float4(accA.x, accA.y, accB.x, accB.y);
+            accA = {0.f, 0.f};
+            accB = {0.f, 0.f};
+            __syncthreads();
+            if (wave == 0) {
+                const float4 r0 = red[lane], r1 = red[64 + lane], r2 = red[128 + lane], r3 = red[192 + lane];
+                float Dr, Di;
+                if (FMT == FMT_F32R) {
+                    Dr = (r0.x + r1.x) + (r2.x + r3.x);
+                    Di = (r0.y + r1.y) + (r2.y + r3.y);
+                } else {
+                    Dr = ((r0.x + r1.x) + (r2.x + r3.x)) - ((r0.y + r1.y) + (r2.y + r3.y));
+                    Di = ((r0.z + r1.z) + (r2.z + r3.z)) + ((r0.w + r1.w) + (r2.w + r3.w));
+                }
+                const int m = t * ACG_TILE_WIN + lane;
+                // power-of-two output scale (1/32768 soapy.c:241, 1/4 sdrplay.c:225): exact, commutes with cabsf
+                if (m < a.nwin) dm_base[(size_t)ch * a.dm_pitch + m] = cabs_like_glibc(Dr, Di) * a.out_scale;
             }
-            const int m = t * ACG_TILE_WIN + lane;
-            // power-of-two output scale (1/32768 soapy.c:241, 1/4 sdrplay.c:225): exact, commutes with cabsf
-            if (m < a.nwin) dm_base[(size_t)ch * a.dm_pitch + m] = cabs_like_glibc(Dr, Di) * a.out_scale;
+        } else {
+            __syncthreads();                            // the slice in LDS is overwritten next round
         }
         ch = nch_;
         t = nt_;
+        k = nk_;
     }
 }
 

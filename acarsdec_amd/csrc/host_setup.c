@@ -110,7 +110,7 @@ int acg_soapy_taps(float Fr_hz, int freq_hz, int decim, float *taps_out)
 {
 	int k;
 	float AMFreq;
-	if (!taps_out || decim < 1 || decim > ACG_MAXDECIM)
+	if (!taps_out || decim < 1 || decim > ACG_MAXDECIM_SAMPLES)
 		return ACG_EINVAL;
 	AMFreq = (Fr_hz - (float)freq_hz) / (float)(ACG_INTRATE * decim) * 2.0 * M_PI;
 	for (k = 0; k < decim; k++) {
@@ -151,7 +151,7 @@ int acg_airspy_taps(int Fr_hz, int Fc_hz, unsigned int inrate, float *taps_out)
 	const unsigned int decim = inrate / ACG_INTRATE;
 	unsigned int i;
 	double AMFreq, Ph;
-	if (!taps_out || decim < 1 || decim * ACG_INTRATE != inrate)
+	if (!taps_out || decim < 1 || decim > ACG_MAXDECIM_SAMPLES || decim * ACG_INTRATE != inrate)
 		return ACG_EINVAL;
 	AMFreq = 2.0 * M_PI * (double)(Fc_hz - Fr_hz + inrate / 4) / (double)(inrate);
 	for (i = 0, Ph = 0; i < decim; i++) {

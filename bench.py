@@ -169,7 +169,10 @@ def main():
     for c in range(nch):
         o = int(offs[c])
         if o not in tap_cache:
-            tap_cache[o] = (D.rtl_taps(fc + o, fc, M)[:ntaps] * win[:, None]).astype(np.float32)
+            # the front end's own tap builder (rtl.c:283-286 / soapy.c:163-166 / air.c:278-285)
+            base = (D.rtl_taps(fc + o, fc, M) if args.format == "u8" else
+                    D.airspy_taps(fc - o, fc, M * 12500) if args.format == "f32" else D.soapy_taps(fc + o, fc, M))
+            tap_cache[o] = (base[:ntaps] * win[:, None]).astype(np.float32)
         taps[c] = tap_cache[o]
 
     # ---- inputs, resident in HBM: distinct bytes per channel, working set >> 256 MiB Infinity Cache

@@ -37,7 +37,8 @@ extern "C" {
 
 #define ACG_INTRATE     12500     /* acarsdec.h:31 */
 #define ACG_BLOCK       1024      /* rtl.c:49 RTLOUTBUFSZ: outputs per reference callback */
-#define ACG_MAXDECIM    320       /* rtl.c:39 RTLMULTMAX */
+#define ACG_MAXDECIM    320       /* rtl.c:39 RTLMULTMAX: limit of the u8 I/Q path */
+#define ACG_MAXDECIM_SAMPLES 1024 /* limit of the acg_*_samples_* formats (air.c:213: 10 Msps -> 800) */
 #define ACG_FLEN        11        /* msk.c:25 */
 #define ACG_TXTMAX      250       /* acarsdec.h:55 */
 
@@ -139,7 +140,8 @@ unsigned int acg_airspy_choose_fc(unsigned int minF_hz, unsigned int maxF_hz);
 int  acg_airspy_taps(int Fr_hz, int Fc_hz, unsigned int inrate, float *taps_out);
 /* Window-aligned device input: [nstreams] rows of nblocks*1024*decim samples (4 bytes per sample;
  * ACG_FMT_S16_SPLIT: I plane at the row start, Q plane plane_bytes further).  decim % 4 == 0
- * (8 for split planes), decim <= 208.  Same asynchronous contract as acg_process_iq_u8_dev. */
+ * and decim <= ACG_MAXDECIM_SAMPLES (split planes: decim % 8 == 0, decim <= 208).  Same asynchronous
+ * contract and FIR/demodulator stream pipeline as acg_process_iq_u8_dev. */
 int  acg_process_samples_dev(acg_ctx *ctx, int fmt, const void *dev, size_t pitch_bytes, size_t plane_bytes,
 			     int nblocks, void *hip_stream);
 /* Host input of ANY length per call, as the SDR drivers deliver it: windows may straddle calls (the

@@ -379,7 +379,8 @@ def test_streaming_collect_equals_blocking_drain(D, O, S):
 
 
 # ------------------------------------------------------------------------------------ other front ends' formats
-@pytest.mark.parametrize("M,feeds", [(160, [1000, 163841 - 1000, 70000, 999999]), (200, [5, 204800, 3 * 204800 + 17, 10 ** 7]), (192, [10 ** 7])])
+@pytest.mark.parametrize("M,feeds", [(160, [1000, 163841 - 1000, 70000, 999999]), (200, [5, 204800, 3 * 204800 + 17, 10 ** 7]), (192, [10 ** 7]),
+                                      (400, [123457, 10 ** 7])])
 def test_cs16_soapy_path_with_carry_matches_oracle(D, O, S, M, feeds):
     """soapy.c shape: CS16 samples fed in reads of arbitrary size (windows straddle reads).  dm within the
     stated tolerance, blocks bit-exact, and the result independent of how the stream was cut."""
@@ -432,8 +433,8 @@ def test_cs16_soapy_path_with_carry_matches_oracle(D, O, S, M, feeds):
     dec.close()
 
 
-def test_split16_sdrplay_and_f32_airspy_paths_match_oracle(D, O, S):
-    """sdrplay.c (two int16 planes, |D|/4) and air.c (real float32 around Fs/4): arbitrary callback sizes
+def test_split16_sdrplay_path_matches_oracle(D, O, S):
+    """sdrplay.c (two int16 planes, |D|/4): arbitrary callback sizes
     with carry, then the window-aligned device path; dm within tolerance, blocks bit-exact."""
     import torch
     from acarsdec_amd import _capi as K
@@ -479,8 +480,24 @@ def test_split16_sdrplay_and_f32_airspy_paths_match_oracle(D, O, S):
         dm_g = dec.dm(c, nout)
         assert np.all(np.abs(dm_g - dm_o) <= 1e-5 * np.abs(dm_o) + 1e-6 * np.abs(dm_o).max())
     dec.close()
-    # ---- airspy at 2.5 Msps real
-    rate = 2500000
+
+
+@pytest.mark.parametrize("rate", [2500000, 6000000, 10000000])
+def test_f32_airspy_path_matches_oracle(D, O, S, rate):
+    """air.c (real float32 around Fs/4) at the rates Airspy devices offer (R2: 10 and 2.5 Msps, Mini:
+    6 Msps -> windows of 800 / 200 / 480 samples; the long ones pass through LDS in column slices):
+    arbitrary callback sizes with carry, then the window-aligned device path."""
+    import torch
+    from acarsdec_amd import _capi as K
+    rng = np.random.default_rng(2718 + rate // 100000)
+    nch, nblk = 4, 4
+    nout = nblk * 1024
+    freqs = [131525000, 131725000, 131825000, 131550000]
+    env = []
+    for c in range(nch):
+        a, _ = S.channel_audio(rng, nout, gap=(400, 900), text_len=(3, 25))
+        env.append(0.5 * (1 + 0.5 * a))
+    env = np.array(env)
     M = rate // 12500
     fc = D.airspy_choose_fc(freqs)
     assert fc == O.air_choose_fc(freqs)

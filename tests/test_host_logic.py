@@ -40,7 +40,7 @@ def test_no_gpu_means_loud_failure_not_fallback():
 def test_create_rejects_bad_configs():
     L = K.load()
     ctx = C.c_void_p()
-    for cfg in (K.Config(0, 0, 1, 160, 160, 1, 0), K.Config(0, 4, 5, 160, 160, 1, 0), K.Config(0, 4, 4, 321, 321, 1, 0),
+    for cfg in (K.Config(0, 0, 1, 160, 160, 1, 0), K.Config(0, 4, 5, 160, 160, 1, 0), K.Config(0, 4, 4, 1025, 1025, 1, 0),
                 K.Config(0, 4, 4, 160, 161, 1, 0), K.Config(0, 4, 4, 160, 160, 0, 0)):
         assert L.acg_create(C.byref(ctx), C.byref(cfg)) == K.EINVAL
     assert L.acg_create(None, None) == K.EINVAL
@@ -52,7 +52,7 @@ def test_rtl_taps_equal_oracle(M):
         assert np.array_equal(D.rtl_taps(fr, fc, M), O.rtl_taps(fr, fc, M))
 
 
-@pytest.mark.parametrize("M", [160, 192, 200])
+@pytest.mark.parametrize("M", [160, 192, 200, 400])
 def test_soapy_taps_equal_oracle(M):
     for fr, fc in ((131525000, 131850000), (131825000.0, 131850000), (129125000, 130100000)):
         assert np.array_equal(D.soapy_taps(fr, fc, M), O.soapy_taps(fr, fc, M))
@@ -61,7 +61,7 @@ def test_soapy_taps_equal_oracle(M):
 def test_sdrplay_and_airspy_taps_equal_oracle():
     for fr, fc in ((131525000, 131850000), (131825000, 131850000), (129125000, 130100000)):
         assert np.array_equal(D.sdrplay_taps(fr, fc), O.sdrplay_taps(fr, fc))
-    for rate in (2500000, 2000000):
+    for rate in (2500000, 2000000, 6000000, 10000000):
         for fr, fc in ((131525000, 131675000), (131825000, 131675000), (131725000, 131725000)):
             assert np.array_equal(D.airspy_taps(fr, fc, rate), O.air_taps(fr, fc, rate))
     assert D.airspy_choose_fc([131525000, 131825000]) == O.air_choose_fc([131525000, 131825000]) == 131675000

@@ -202,7 +202,7 @@ if kind == "sdrplay":
     gettaps = lambda c: ref.L.ref_get_oscillator
     step = 512
 else:
-    ref = O.Ref("_air"); rate = 2500000; M = rate // 12500
+    ref = O.Ref("_air"); rate = int(sys.argv[4]); M = rate // 12500
     fc = ref.init_air(freqs, rate)
     if O.air_choose_fc(fr) != fc: res["ok"] = False; res["why"].append("fc %%d" %% fc)
     # air.c mixes with Fc - Fr + Fs/4: a channel at Fr sits at that frequency of the real spectrum
@@ -234,13 +234,16 @@ print(json.dumps(res))
 '''
 
 
-@pytest.mark.parametrize("kind,chunk", [("sdrplay", 0), ("sdrplay", 504), ("sdrplay", 1001), ("air", 32768), ("air", 65536), ("air", 1000)])
-def test_sdrplay_and_airspy_front_ends_bit_identical_to_reference(kind, chunk):
+@pytest.mark.parametrize("kind,chunk,rate", [("sdrplay", 0, 0), ("sdrplay", 504, 0), ("sdrplay", 1001, 0),
+                                             ("air", 32768, 2500000), ("air", 65536, 2500000), ("air", 1000, 2500000),
+                                             ("air", 65536, 6000000), ("air", 40000, 10000000)])
+def test_sdrplay_and_airspy_front_ends_bit_identical_to_reference(kind, chunk, rate):
     """sdrplay.c (split int16 planes, cabsf(D)/4) and air.c (real float32, complex taps): taps, centre
-    frequency, dm, demodulator state and blocks, with the stream cut into callbacks of any size."""
+    frequency, dm, demodulator state and blocks, with the stream cut into callbacks of any size; Airspy
+    at the rates its devices offer (air.c:211-214: R2 10 / 2.5 Msps, Mini 6 Msps -> 800 / 200 / 480 taps)."""
     if not O.ref_available("_" + kind):
         pytest.skip("oracle/_ref/libacarsref_%s.so not built" % kind)
-    r = subprocess.run([sys.executable, "-c", FE_CHILD % dict(root=ROOT), kind, str(7 + chunk), str(chunk)],
+    r = subprocess.run([sys.executable, "-c", FE_CHILD % dict(root=ROOT), kind, str(7 + chunk), str(chunk), str(rate)],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     res = json.loads(r.stdout.strip().splitlines()[-1])
