@@ -53,6 +53,11 @@ struct acg_ctx {
 
     float* d_taps = nullptr;
     int* d_stream_of = nullptr;
+    int4* d_groups = nullptr;       // shared-stream down-converter: <= 8 channels of one stream per group
+    int* d_group_ch = nullptr;
+    int ngroups = 0;                // 0: every stream feeds one channel (plain kernel)
+    float* d_gtaps = nullptr;       // taps regrouped for the shared-stream kernel (lazily rebuilt)
+    bool gtaps_dirty = true;
     float* d_dm = nullptr;
     AcgChan* d_st = nullptr;
     float* d_h = nullptr;
@@ -124,7 +129,7 @@ extern "C" int acg_device_count(void)
 static void free_all(acg_ctx* c)
 {
     if (!c) return;
-    hipFree(c->d_taps); hipFree(c->d_stream_of); hipFree(c->d_dm); hipFree(c->d_st);
+    hipFree(c->d_taps); hipFree(c->d_stream_of); hipFree(c->d_groups); hipFree(c->d_group_ch); hipFree(c->d_gtaps); hipFree(c->d_dm); hipFree(c->d_st);
     hipFree(c->d_h); hipFree(c->d_txt); hipFree(c->d_frames); hipFree(c->d_frame_count);
     hipFree(c->d_bits); hipFree(c->d_nbits); hipFree(c->d_stage); hipFree(c->d_work); hipFree(c->d_crctab); hipFree(c->d_rep_upto);
     for (auto& p : c->fir_ev) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
@@ -147,6 +152,35 @@ extern "C" void acg_destroy(acg_ctx* ctx)
     hipDeviceSynchronize();
     free_all(ctx);
     delete ctx;
+}
+
+// Channel -> stream map, plus its inverse for the shared-stream down-converter: channels ordered by
+// stream and cut into groups of <= 8 channels of one stream (rtl.c's shape: one dongle, several channels).
+static int upload_stream_map(acg_ctx* c, const int* so)
+{
+    const int nch = c->cfg.nch, ns = c->cfg.nstreams;
+    HIPCHK(c, hipMemcpy(c->d_stream_of, so, (size_t)nch * sizeof(int), hipMemcpyHostToDevice));
+    std::vector<int> cnt((size_t)ns + 1, 0), ord((size_t)nch);
+    for (int i = 0; i < nch; ++i) cnt[(size_t)so[i] + 1]++;
+    bool shared = false;
+    for (int s = 0; s < ns; ++s) {
+        shared |= cnt[(size_t)s + 1] > 1;
+        cnt[(size_t)s + 1] += cnt[(size_t)s];
+    }
+    c->ngroups = 0;
+    c->gtaps_dirty = true;
+    if (!shared || !c->tile_path) return ACG_OK;
+    std::vector<int> fill(cnt.begin(), cnt.end() - 1);
+    for (int i = 0; i < nch; ++i) ord[(size_t)fill[(size_t)so[i]]++] = i;          // stable: ascending channel id per stream
+    std::vector<int4> groups;
+    for (int s = 0; s < ns; ++s)
+        for (int f = cnt[(size_t)s]; f < cnt[(size_t)s + 1]; f += 8)
+            groups.push_back(make_int4(s, f, std::min(8, cnt[(size_t)s + 1] - f), 0));
+    HIPCHK(c, hipMemcpy(c->d_group_ch, ord.data(), (size_t)nch * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_groups, groups.data(), groups.size() * sizeof(int4), hipMemcpyHostToDevice));
+    c->ngroups = (int)groups.size();
+    if (const char* e = std::getenv("ACG_FIR_SHARED")) if (!std::atoi(e)) c->ngroups = 0;
+    return ACG_OK;
 }
 
 extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
@@ -245,10 +279,12 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
         float h[136] = {0};
         acg_host_msk_h(h);                               // msk.c:44-48
         HIPCHK(c, hipMemcpy(c->d_h, h, sizeof(h), hipMemcpyHostToDevice));
+        HIPCHK(c, hipMalloc(&c->d_groups, nch * sizeof(int4)));
+        HIPCHK(c, hipMalloc(&c->d_group_ch, nch * sizeof(int)));
+        HIPCHK(c, hipMalloc(&c->d_gtaps, nch * (size_t)c->ntaps_pad * 2 * sizeof(float)));
         std::vector<int> so(nch);
         for (size_t i = 0; i < nch; ++i) so[i] = (int)(i % (size_t)cfg->nstreams);
-        HIPCHK(c, hipMemcpy(c->d_stream_of, so.data(), nch * sizeof(int), hipMemcpyHostToDevice));
-        return ACG_OK;
+        return upload_stream_map(c, so.data());
     };
     rc = body();
     if (rc == ACG_OK) rc = acg_reset(c);
@@ -294,9 +330,10 @@ extern "C" int acg_set_taps(acg_ctx* ctx, int ch0, int n, const float* taps)
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
     const size_t src_pitch = (size_t)ctx->cfg.ntaps * 2 * sizeof(float);
     const size_t dst_pitch = (size_t)ctx->ntaps_pad * 2 * sizeof(float);
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipDeviceSynchronize());                 // down-converter launches run on the callers' streams
     HIPCHK(ctx, hipMemcpy2D(ctx->d_taps + (size_t)ch0 * ctx->ntaps_pad * 2, dst_pitch, taps, src_pitch,
                             src_pitch, (size_t)n, hipMemcpyHostToDevice));
+    ctx->gtaps_dirty = true;
     return ACG_OK;
 }
 
@@ -307,10 +344,8 @@ extern "C" int acg_set_channel_streams(acg_ctx* ctx, const int* stream_of_channe
         if (stream_of_channel[i] < 0 || stream_of_channel[i] >= ctx->cfg.nstreams)
             return fail(ctx, ACG_EINVAL, "stream index out of range");
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    HIPCHK(ctx, hipMemcpy(ctx->d_stream_of, stream_of_channel, (size_t)ctx->cfg.nch * sizeof(int),
-                          hipMemcpyHostToDevice));
-    return ACG_OK;
+    HIPCHK(ctx, hipDeviceSynchronize());
+    return upload_stream_map(ctx, stream_of_channel);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -357,7 +392,18 @@ static int launch_fir(acg_ctx* c, const uint8_t* iq_dev, size_t pitch, int nbloc
         int nseg = (4096 + g.nch - 1) / g.nch;          // aim at >= ~4096 workgroups
         nseg = std::max(1, std::min(nseg, ntile));
         a.nseg = nseg;
-        e = acg_launch_fir(&a, s);
+        a.groups = c->d_groups;
+        a.group_ch = c->d_group_ch;
+        a.ngroups = c->ngroups;
+        a.gtaps = c->d_gtaps;
+        if (c->ngroups > 0 && c->gtaps_dirty) {          // taps or the stream map changed (both synchronise the device)
+            if ((e = acg_launch_regroup_taps(&a, s)) != 0) {
+                c->err = std::string("tap regroup launch: ") + hipGetErrorString((hipError_t)e);
+                return ACG_EHIP;
+            }
+            c->gtaps_dirty = false;
+        }
+        e = c->ngroups > 0 ? acg_launch_fir_shared(&a, s) : acg_launch_fir(&a, s);
     } else {
         a.nseg = 1;
         e = acg_launch_fir_generic(&a, s);

@@ -61,6 +61,10 @@ struct FirArgs {
     int cpr;                    // 16-byte chunks per row = row_bytes/16
     unsigned int cpr_magic;     // ceil(2^20 / cpr): c / cpr == (c * magic) >> 20 for c < 2^11
     size_t plane;               // FMT_SPLIT: byte distance from a stream's I plane to its Q plane
+    const int4* groups;         // shared-stream kernel: {stream, first index into group_ch, channel count (<= 8), 0}
+    const int* group_ch;        // shared-stream kernel: channel ids ordered by stream
+    int ngroups;
+    const float* gtaps;         // shared-stream kernel: taps regrouped [group][step][channel][16]
     int kseg;                   // format kernels: column segments per window (long windows pass through LDS in kseg slices)
     int cpr_total;              // format kernels: 16-byte chunks per whole window (cpr = chunks per slice)
     float out_scale;            // power-of-two scale applied to |D| (1, 1/32768 soapy.c:241, 1/4 sdrplay.c:225)
@@ -92,6 +96,8 @@ extern "C" {
 // kernel launchers (fir.hip / msk.hip / synth.hip); stream is a hipStream_t
 int acg_launch_fir(const FirArgs* a, void* stream);
 int acg_launch_fir_generic(const FirArgs* a, void* stream);
+int acg_launch_fir_shared(const FirArgs* a, void* stream);
+int acg_launch_regroup_taps(const FirArgs* a, void* stream);          // channels grouped by stream (a->groups)
 int acg_launch_fir_fmt(const FirArgs* a, int fmt, void* stream);     // fmt: 1 CS16, 2 split int16 planes, 3 real f32
 size_t acg_fir_lds_bytes(const FirArgs* a);
 int acg_launch_msk(const MskArgs* a, int lanes_per_channel, void* stream);

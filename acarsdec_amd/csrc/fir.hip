@@ -16,6 +16,7 @@
 //     consecutive floats of dm.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "acg_internal.h"
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -303,6 +304,191 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_persist_kernel(const FirArg
         }
         if (!more) break;
         ch = nch_;
+        t = nt_;
+        g = ng;
+        g0 = ng0;
+        g1 = ng1;
+    }
+}
+
+// Shared-stream variant -- rtl.c's own shape: one dongle's stream feeds several channels (up to 16,
+// acarsdec.h:30).  A work unit is (group of <= FIR_KC channels of ONE stream, tile): the tile is loaded
+// and converted u8 -> f32 once and every channel of the group takes its taps to the same registers.
+// Per 8 complex samples: 1 ds_read_b128 + 24 conversion ops shared, 16 v_pk_fma_f32 per channel, so the
+// kernel is VALU-bound at (2 + 3/K) lane-ops per channel-sample instead of HBM/fabric-bound at 5.
+// The arithmetic per channel (tap split over the 4 waves, reduction order) is that of
+// fir_u8_persist_kernel: both give bit-identical dm.  Partial sums meet in LDS four channels at a
+// time; wave w finishes channel 4r + w.  Dynamic run dispenser as above.
+// Taps come from a regrouped copy of the tap table, [group][8-sample step][channel of the group][16 floats]
+// (regroup_taps_kernel), so that one scalar base + immediate offsets reaches all channels of a step.
+#define FIR_KC 8
+__global__ void regroup_taps_kernel(const float* __restrict__ taps, float* __restrict__ gtaps,
+                                    const int4* __restrict__ groups, const int* __restrict__ group_ch, int ntaps_pad)
+{
+    const int4 gi = groups[blockIdx.x];
+    const int kc = gi.z;
+    const int n = kc * ntaps_pad * 2;
+    float* out = gtaps + (size_t)gi.y * ntaps_pad * 2;
+    for (int idx = threadIdx.x; idx < n; idx += blockDim.x) {
+        const int e = idx & 15;
+        const int q = idx >> 4;
+        const int c = q / kc;
+        const int k = q - c * kc;
+        out[idx] = taps[(size_t)group_ch[gi.y + k] * ntaps_pad * 2 + (c << 4) + e];
+    }
+}
+
+__global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_shared_kernel(const FirArgs a,
+                                                                    const uint8_t* __restrict__ iq_base,
+                                                                    const float* __restrict__ taps_base,
+                                                                    const int4* __restrict__ groups,
+                                                                    const int* __restrict__ group_ch,
+                                                                    float* __restrict__ dm_base)
+{
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntile = (a.nwin + ACG_TILE_WIN - 1) / ACG_TILE_WIN;
+    const long long G = (long long)a.ngroups * ntile;
+    const long long nrun = (G + FIR_RUN - 1) / FIR_RUN;
+    long long g0 = (long long)blockIdx.x * FIR_RUN;
+    long long g1 = g0 + FIR_RUN < G ? g0 + FIR_RUN : G;
+    if (g0 >= g1) return;
+    int* s_next = (int*)(fir_smem + ACG_TILE_WIN * a.row_stride + 16 * 64 * sizeof(float4));
+
+    const int cpr = a.cpr;
+    const int tile_chunks = ACG_TILE_WIN * cpr;
+    const int total_chunks = a.nwin * cpr;
+    const int pad = a.row_stride - a.row_bytes;
+    const unsigned int magic = a.cpr_magic;
+    unsigned char* tileL = fir_smem;
+    float4* red = (float4*)(fir_smem + ACG_TILE_WIN * a.row_stride);      // [4 channels][4 waves][64]
+    const int nck = a.ntaps_pad >> 3;
+    const int c0 = nck * wave / 4;
+    const int c1 = nck * (wave + 1) / 4;
+    const int nld = (tile_chunks + ACG_WG_FIR - 1) / ACG_WG_FIR;
+
+    int grp = (int)(g0 / ntile);
+    int t = (int)(g0 - (long long)grp * ntile);
+    uint4 stage[FIR_MAXLD];
+
+    auto fetch = [&](int fgrp, int ft) {
+        const uint8_t* __restrict__ src = iq_base + (size_t)groups[fgrp].x * a.pitch;
+        const int base = ft * tile_chunks;
+        typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int i = 0; i < FIR_MAXLD; ++i) {
+            if (i < nld) {
+                const int c = tid + i * ACG_WG_FIR;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (c < tile_chunks && base + c < total_chunks) {
+                    const u4v x = __builtin_nontemporal_load((const u4v*)(src + ((size_t)(base + c) << 4)));
+                    v = make_uint4(x.x, x.y, x.z, x.w);
+                }
+                stage[i] = v;
+            }
+        }
+    };
+
+    fetch(grp, t);
+    unsigned int pending_next = 0;
+    for (long long g = g0;;) {
+#pragma unroll
+        for (int i = 0; i < FIR_MAXLD; ++i) {
+            if (i < nld) {
+                const int c = tid + i * ACG_WG_FIR;
+                if (c < tile_chunks) {
+                    const int r = (int)(((unsigned int)c * magic) >> 20);
+                    *(uint4*)(tileL + (c << 4) + r * pad) = stage[i];
+                }
+            }
+        }
+        if (g == g0 && tid == 0) request_ticket(a.work_counter, pending_next);
+        if (g == g0 + 1 && tid == 0) *s_next = (int)take_ticket(pending_next);
+        __syncthreads();
+
+        int ngrp = grp, nt_ = t + 1;
+        if (nt_ == ntile) { nt_ = 0; ++ngrp; }
+        bool more = g + 1 < g1;
+        long long ng0 = g0, ng1 = g1, ng = g + 1;
+        if (!more) {
+            const long long nr = (g1 - g0 >= 2) ? (long long)*s_next : nrun;
+            if (nr < nrun) {
+                ng0 = nr * FIR_RUN;
+                ng1 = ng0 + FIR_RUN < G ? ng0 + FIR_RUN : G;
+                ng = ng0;
+                ngrp = (int)(ng0 / ntile);
+                nt_ = (int)(ng0 - (long long)ngrp * ntile);
+                more = true;
+            }
+        }
+        if (more) fetch(ngrp, nt_);
+
+        const int4 gi = groups[grp];                                        // wave-uniform
+        const int kc = gi.z;
+        const float* __restrict__ gt = taps_base + (size_t)gi.y * a.ntaps_pad * 2;
+        f2 accA[FIR_KC], accB[FIR_KC];
+#pragma unroll
+        for (int k = 0; k < FIR_KC; ++k) {
+            accA[k] = {0.f, 0.f};
+            accB[k] = {0.f, 0.f};
+        }
+        const unsigned char* rowp = tileL + lane * a.row_stride;
+        auto taps_pass = [&](auto full) {
+            constexpr bool FULL = decltype(full)::value;
+            const int kcc = FULL ? FIR_KC : kc;
+            for (int c = c0; c < c1; ++c) {
+                const float* __restrict__ wc = gt + (size_t)(c * kcc) * 16;
+                const uint4 q = *(const uint4*)(rowp + (c << 4));
+                const unsigned int qq[4] = {q.x, q.y, q.z, q.w};
+                f2 x[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const unsigned int word = qq[j >> 1];
+                    const unsigned int sh = (j & 1) * 16;
+                    x[j].x = (float)((word >> sh) & 0xffu) - 127.37f;
+                    x[j].y = (float)((word >> (sh + 8)) & 0xffu) - 127.37f;
+                }
+#pragma unroll
+                for (int k = 0; k < FIR_KC; ++k) {
+                    if (FULL || k < kc) {
+                        const float* __restrict__ w = wc + k * 16;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const f2 wv = {w[2 * j], w[2 * j + 1]};
+                            const f2 ws = {w[2 * j + 1], w[2 * j]};
+                            accA[k] = __builtin_elementwise_fma(x[j], wv, accA[k]);
+                            accB[k] = __builtin_elementwise_fma(x[j], ws, accB[k]);
+                        }
+                    }
+                }
+            }
+        };
+        if (kc == FIR_KC) taps_pass(std::true_type{});
+        else taps_pass(std::false_type{});
+
+        const int m = t * ACG_TILE_WIN + lane;
+#pragma unroll
+        for (int r = 0; r < FIR_KC / 4; ++r) {
+            if (4 * r < kc) {                                               // uniform
+                if (r > 0) __syncthreads();                                 // round r-1's reads are done
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    red[(kk * 4 + wave) * 64 + lane] = make_float4(accA[4 * r + kk].x, accA[4 * r + kk].y,
+                                                                   accB[4 * r + kk].x, accB[4 * r + kk].y);
+                __syncthreads();
+                if (4 * r + wave < kc) {
+                    const float4* rr = red + (wave * 4) * 64 + lane;
+                    const float4 r0 = rr[0], r1 = rr[64], r2 = rr[128], r3 = rr[192];
+                    const float Dr = ((r0.x + r1.x) + (r2.x + r3.x)) - ((r0.y + r1.y) + (r2.y + r3.y));
+                    const float Di = ((r0.z + r1.z) + (r2.z + r3.z)) + ((r0.w + r1.w) + (r2.w + r3.w));
+                    const int mych = group_ch[gi.y + 4 * r + wave];          // wave-uniform
+                    if (m < a.nwin) dm_base[(size_t)mych * a.dm_pitch + m] = cabs_like_glibc(Dr, Di);
+                }
+            }
+        }
+        if (!more) break;
+        grp = ngrp;
         t = nt_;
         g = ng;
         g0 = ng0;
@@ -741,6 +927,43 @@ extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
         hipLaunchKernelGGL((fir_u8_persist_kernel<true, true>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds,
                            (hipStream_t)stream, *a, a->iq, a->taps, a->stream_of, a->dm);
     }
+    return (int)hipGetLastError();
+}
+
+extern "C" int acg_launch_fir_shared(const FirArgs* a, void* stream)
+{
+    const size_t lds = (size_t)ACG_TILE_WIN * a->row_stride + 16 * 64 * sizeof(float4) + 16;
+    static bool attr_set = false;
+    static int num_cu = 256;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)fir_u8_shared_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (e != hipSuccess) return (int)e;
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        attr_set = true;
+    }
+    if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 4) per_cu = 4;
+    if (per_cu < 1) per_cu = 1;
+    if (const char* v = getenv("ACG_FIR_WG_PER_CU")) per_cu = atoi(v);
+    const long long ntile = (a->nwin + ACG_TILE_WIN - 1) / ACG_TILE_WIN;
+    const long long G = (long long)a->ngroups * ntile;
+    const long long nrun = (G + FIR_RUN - 1) / FIR_RUN;
+    long long grid = (long long)num_cu * per_cu;
+    if (grid > nrun) grid = nrun;
+    hipError_t e = hipMemsetD32Async((hipDeviceptr_t)a->work_counter, (int)grid, 1, (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(fir_u8_shared_kernel, dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds, (hipStream_t)stream, *a,
+                       a->iq, a->gtaps, a->groups, a->group_ch, a->dm);
+    return (int)hipGetLastError();
+}
+
+extern "C" int acg_launch_regroup_taps(const FirArgs* a, void* stream)
+{
+    hipLaunchKernelGGL(regroup_taps_kernel, dim3((unsigned int)a->ngroups), dim3(256), 0, (hipStream_t)stream, a->taps,
+                       (float*)a->gtaps, a->groups, a->group_ch, a->ntaps_pad);
     return (int)hipGetLastError();
 }
 

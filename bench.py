@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--random-bytes", action="store_true", help="uniform random input bytes instead of ACARS traffic")
     ap.add_argument("--format", choices=["u8", "cs16", "split16", "f32"], default="u8",
                     help="input sample format: u8 = rtl.c (headline); cs16 = soapy.c, split16 = sdrplay.c, f32 = air.c (SURVEY 8f.2)")
+    ap.add_argument("--share", type=int, default=1,
+                    help="channels per input stream (rtl.c's own shape: one dongle feeds up to 16 channels); >1 = shared-stream "
+                         "mode, VALU-bound, reported separately and never as the roofline figure (SURVEY 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-child", nargs=4, default=None)
     args = ap.parse_args()
@@ -179,7 +182,12 @@ def main():
     fmt = {"u8": 0, "cs16": K.FMT_CS16, "split16": K.FMT_S16_SPLIT, "f32": K.FMT_F32_REAL}[args.format]
     bps = 2 if fmt == 0 else 4
     row = nblk * 1024 * M * bps
-    iq = torch.empty((nch, row), dtype=torch.uint8, device=dev)
+    share = max(1, args.share)
+    if share > 1:
+        assert fmt == 0 and nch % share == 0, "--share needs the u8 format and a channel count divisible by it"
+        args.random_bytes = True
+    nstreams = nch // share
+    iq = torch.empty((nstreams, row), dtype=torch.uint8, device=dev)
     if fmt == K.FMT_F32_REAL:
         iq.view(torch.float32).normal_(0.0, 0.1)
         data_desc = "gaussian float32 samples (format throughput run; parity of this format is covered by tests/)"
@@ -188,7 +196,7 @@ def main():
         iq.view(torch.int16).bitwise_and_(0x0FFF)
         data_desc = "uniform random int16 samples (format throughput run; parity of this format is covered by tests/)"
     elif args.random_bytes:
-        assert L.acg_fill_random_u8_dev(iq.data_ptr(), row, nch, row, 0xACA25 + rank, None) == 0
+        assert L.acg_fill_random_u8_dev(iq.data_ptr(), row, nstreams, row, 0xACA25 + rank, None) == 0
         data_desc = "uniform random bytes"
     else:
         # a pool of ACARS/MSK audio tracks (SURVEY App. C.2 modulator), every channel = one track on its
@@ -208,8 +216,10 @@ def main():
         data_desc = "ACARS/MSK traffic on every channel (%d-track pool, AM depth 0.5, AWGN sigma 0.05, device-side up-converter)" % NPOOL
     torch.cuda.synchronize()
 
-    dec = D.Decoder(nch, decim=M, ntaps=ntaps, max_blocks=nblk, device=local, bitlog=True, timing=True)
+    dec = D.Decoder(nch, decim=M, ntaps=ntaps, nstreams=nstreams, max_blocks=nblk, device=local, bitlog=True, timing=True)
     dec.set_taps(taps)
+    if share > 1:
+        dec.set_channel_streams(np.arange(nch) // share)
     stream = torch.cuda.current_stream().cuda_stream
 
     maxfr = max(8192, 8 * nch)
@@ -241,10 +251,10 @@ def main():
         for f in first:
             got.setdefault(int(f.chn), []).append(D.frame_tuple(f))
         ok, nblocks = True, 0
-        host_rows = iq[:ncheck].cpu().numpy()
+        host_rows = iq[:(ncheck + share - 1) // share].cpu().numpy()
         for c in range(ncheck):
             ch = O.Channel(c)
-            ch.demod(O.fir_u8(host_rows[c], M, taps[c], ntaps=ntaps))
+            ch.demod(O.fir_u8(host_rows[c // share], M, taps[c], ntaps=ntaps))
             want = [O.frame_tuple(f) for f in ch.frames]
             nblocks += len(want)
             ok &= got.get(c, []) == want
@@ -289,7 +299,8 @@ def main():
         # 4 B per 12.5 kHz output written, taps (8 B each) read once per launch.  A step is split
         # into `lps` pipelined FIR launches (chunks of the step's callbacks).
         lps = max(1, round(tim["fir_launches"] / args.steps))
-        fir_bytes = nch * (nblk / lps) * 1024 * (bps * M + 4) + nch * ntaps * 8
+        # (shared-stream mode: each stream's bytes count once)
+        fir_bytes = (nstreams * (nblk / lps) * 1024 * bps * M + nch * (nblk / lps) * 1024 * 4) + nch * ntaps * 8
         fir_avg_ms = tim["fir_ms"] / max(1, tim["fir_launches"])
         msk_avg_ms = tim["msk_ms"] / max(1, tim["msk_launches"])
         achieved = fir_bytes / (fir_avg_ms * 1e-3) / 1e9
@@ -325,7 +336,7 @@ def main():
                        "realtime_channels_equiv": int(value / (12500 * M / 1e6)),
                        "arithmetic": "u8 in, f32 down-converter and matched filter, f64 VCO/PLL/normalisation (as the reference)",
                        "preset": args.config, "channels_total": nch_total, "blocks_decoded_timed": int(nfr_total)},
-            "roofline": {"bound": "hbm", "kernel": "fir_u8_persist_kernel" if fmt == 0 else "fir_fmt_kernel<%s>" % args.format, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": ("fir_u8_shared_kernel" if share > 1 else "fir_u8_persist_kernel") if fmt == 0 else "fir_fmt_kernel<%s>" % args.format, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "bytes_per_launch": int(fir_bytes), "avg_launch_ms": round(fir_avg_ms, 4), "launches_per_step": lps,
                          "frac_of_measured_copy_ceiling_6290": round(achieved / 6290.0, 4),
@@ -334,6 +345,16 @@ def main():
                         "note": "FIR chunks (own stream) overlap the MSK chunks of the previous chunk; per-step sums of event-timed launches"},
             "parity": parity,
         }
+        if share > 1:
+            out["config"]["channels_per_stream"] = share
+            out["roofline"]["note"] = ("shared-stream mode: %d channels reuse each stream's bytes, the down-converter is VALU-bound "
+                                       "(8*K flop per 2 B); achieved counts each stream once and is NOT the HBM roofline figure" % share)
+            # VALU lane-ops of the shared-stream kernel: per 8 complex samples 24 shared conversion ops + 16 packed
+            # FMAs per channel of the group (groups of <= 8); peak = 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz
+            keff = min(share, 8)
+            ops = nch * nblk * 1024 * M * (2.0 + 3.0 / keff) * args.steps / (tim["fir_ms"] * 1e-3)
+            out["valu"] = {"kernel": "fir_u8_shared_kernel", "lane_ops_per_s": round(ops, 0), "peak": 256 * 4 * 16 * 2.4e9,
+                           "frac": round(ops / (256 * 4 * 16 * 2.4e9), 4), "lane_ops_per_channel_sample": round(2.0 + 3.0 / keff, 3)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = run_cpu_baseline(M)
             out["cpu_baseline"]["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)

@@ -108,6 +108,44 @@ def test_fir_shared_stream_and_stream_map(D, O):
     dec.close()
 
 
+@pytest.mark.parametrize("M", [200, 160, 192])
+def test_fir_shared_stream_kernel_ragged_groups(D, O, M, monkeypatch):
+    """the shared-stream down-converter (one tile load + one u8->f32 conversion for all channels of a
+    stream, groups of <= 8): streams feeding 1, 3, 8, 11 and 16 channels in scrambled channel order;
+    dm within tolerance of the oracle AND bit-identical to the one-channel-per-unit kernel."""
+    rng = np.random.default_rng(77 + M)
+    sizes = [1, 3, 8, 11, 16, 1]
+    smap = np.repeat(np.arange(len(sizes)), sizes)
+    rng.shuffle(smap)
+    nch, nblk = int(smap.size), 2
+    nout = nblk * 1024
+    iq = rng.integers(0, 256, size=(len(sizes), nout * M * 2), dtype=np.uint8)
+    taps = np.stack([O.rtl_taps(131000000 + 25000 * int(rng.integers(-40, 41)), 131000000, M) for c in range(nch)])
+
+    def run():
+        dec = D.Decoder(nch, decim=M, nstreams=len(sizes), max_blocks=nblk)
+        dec.set_taps(taps)
+        dec.set_channel_streams(smap)
+        dec.in_callback(iq)
+        out = np.stack([dec.dm(c, nout) for c in range(nch)])
+        # taps changed after the first call: the regrouped tap table must follow
+        dec.set_taps(taps[::-1].copy())
+        dec.in_callback(iq)
+        out2 = np.stack([dec.dm(c, nout) for c in range(nch)])
+        dec.close()
+        return out, out2
+
+    shared, shared2 = run()
+    monkeypatch.setenv("ACG_FIR_SHARED", "0")
+    plain, plain2 = run()
+    assert np.array_equal(shared, plain) and np.array_equal(shared2, plain2)
+    for c in range(nch):
+        want = O.fir_u8(iq[smap[c]], M, taps[c], nout=nout)
+        assert np.all(np.abs(shared[c] - want) <= 1e-5 * np.abs(want) + 1e-6), c
+        want2 = O.fir_u8(iq[smap[c]], M, taps[nch - 1 - c], nout=nout)
+        assert np.all(np.abs(shared2[c] - want2) <= 1e-5 * np.abs(want2) + 1e-6), c
+
+
 # ------------------------------------------------------------------------------------ MSK stage on test.wav
 def run_wav(D, x, chunk):
     nch = x.shape[1]
