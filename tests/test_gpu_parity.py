@@ -10,6 +10,7 @@ Stated tolerances:
     bits because `o=(int)(12*(MskClk/s+0.5))`, msk.c:103, truncates);
   * level: within 0.05 dB.
 """
+import ctypes as C
 import os
 import subprocess
 
@@ -144,6 +145,43 @@ def test_fir_shared_stream_kernel_ragged_groups(D, O, M, monkeypatch):
         assert np.all(np.abs(shared[c] - want) <= 1e-5 * np.abs(want) + 1e-6), c
         want2 = O.fir_u8(iq[smap[c]], M, taps[nch - 1 - c], nout=nout)
         assert np.all(np.abs(shared2[c] - want2) <= 1e-5 * np.abs(want2) + 1e-6), c
+
+
+# ------------------------------------------------------------------------------------ error behaviour of the ABI
+def test_abi_rejects_misuse_loudly(D):
+    """bad arguments and call-sequence errors come back as codes with a message, never as silent no-ops:
+    the reference's conventions are 0 = OK / non-zero = fail (acarsdec.c:456-459)."""
+    import torch
+    from acarsdec_amd import _capi as K
+    L = K.load()
+    M = 160
+    dec = D.Decoder(2, decim=M, max_blocks=2, bitlog=False)
+    iq = torch.zeros((2, 2 * 1024 * M * 2 + 64), dtype=torch.uint8, device="cuda")
+    assert L.acg_process_iq_u8_dev(dec.ctx, iq.data_ptr(), iq.stride(0), 3, None) == K.EINVAL      # > max_blocks
+    assert b"nblocks" in L.acg_last_error(dec.ctx)
+    assert L.acg_process_iq_u8_dev(dec.ctx, iq.data_ptr() + 4, iq.stride(0), 1, None) == K.EINVAL  # misaligned base
+    assert L.acg_process_iq_u8_dev(dec.ctx, iq.data_ptr(), 1024 * M * 2 - 16, 1, None) == K.EINVAL  # pitch < row
+    assert L.acg_process_iq_u8_dev(dec.ctx, None, iq.stride(0), 1, None) == K.EINVAL
+    assert L.acg_set_channel_streams(dec.ctx, (C.c_int * 2)(0, 2)) == K.EINVAL                    # stream out of range
+    with pytest.raises(K.AcgError) as e:
+        dec.bits(0)                                                        # context has no bit log
+    assert e.value.code == K.ESTATE
+    assert L.acg_process_samples_dev(dec.ctx, 9, iq.data_ptr(), iq.stride(0), 0, 1, None) == K.EINVAL   # unknown format
+    # the context still works after the rejected calls
+    dec.in_callback(iq[:, : 1024 * M * 2].contiguous())
+    assert dec.drain_frames() == []
+    dec.close()
+    # u8 path above RTLMULTMAX, split planes above their limit
+    dec = D.Decoder(1, decim=400, max_blocks=1)
+    big = torch.zeros(1024 * 400 * 4, dtype=torch.uint8, device="cuda")
+    assert L.acg_process_iq_u8_dev(dec.ctx, big.data_ptr(), big.numel(), 1, None) == K.EINVAL
+    assert L.acg_process_samples_dev(dec.ctx, K.FMT_S16_SPLIT, big.data_ptr(), big.numel(), big.numel() // 2, 1, None) == K.EINVAL
+    assert L.acg_process_samples_dev(dec.ctx, K.FMT_CS16, big.data_ptr(), big.numel(), 0, 1, None) == K.OK
+    dec.close()
+    # queue smaller than the result: EOVERFLOW, truncated, not corrupted
+    fr = (K.Frame * 1)()
+    n = C.c_int(0)
+    assert L.acg_drain_frames(None, fr, 1, C.byref(n)) == K.EINVAL
 
 
 # ------------------------------------------------------------------------------------ MSK stage on test.wav
