@@ -31,6 +31,8 @@ struct acg_ctx {
     hipStream_t copy_stream = nullptr;  // result copies that must not queue behind running kernels
     hipEvent_t in_ev = nullptr;
     std::vector<hipEvent_t> fir_done;   // per chunk slot: FIR of the slot finished (recorded on the caller's stream)
+    hipEvent_t msk_go = nullptr;        // the demodulator stream has reached the launch of the newest chunk
+    bool msk_go_valid = false;
     std::vector<hipEvent_t> msk_done;   // per chunk slot: MSK has consumed the slot's dm (recorded on msk_stream)
     std::vector<char> msk_done_valid;
     int pipe_blocks = 1;            // 1024-output blocks per pipelined chunk (0 = no pipelining)
@@ -136,6 +138,7 @@ static void free_all(acg_ctx* c)
     for (auto& p : c->msk_ev) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : c->ev_pool) hipEventDestroy(e);
     for (auto e : c->fir_done) hipEventDestroy(e);
+    if (c->msk_go) hipEventDestroy(c->msk_go);
     for (auto e : c->msk_done) hipEventDestroy(e);
     for (auto e : c->call_done) if (e) hipEventDestroy(e);
     if (c->h_call_count) hipHostFree(c->h_call_count);
@@ -246,6 +249,7 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
         c->msk_done.resize((size_t)cfg->max_blocks);
         c->msk_done_valid.assign((size_t)cfg->max_blocks, 0);
         for (auto& e : c->fir_done) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->msk_go, hipEventDisableTiming));
         for (auto& e : c->msk_done) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto& e : c->call_done) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIPCHK(c, hipHostMalloc((void**)&c->h_call_count, sizeof(unsigned int) * acg_ctx::NCALL, hipHostMallocDefault));
@@ -265,7 +269,8 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
         if (cfg->flags & ACG_F_BITLOG)
             HIPCHK(c, hipMalloc(&c->d_bits, nch * (size_t)c->bit_cap * sizeof(float2)));
         HIPCHK(c, hipMalloc(&c->d_nbits, nch * sizeof(int)));
-        HIPCHK(c, hipMalloc(&c->d_work, sizeof(unsigned int) * (size_t)(cfg->max_blocks + 1)));
+        HIPCHK(c, hipMalloc(&c->d_work, sizeof(unsigned int) * 2 * (size_t)(cfg->max_blocks + 1)));
+        HIPCHK(c, hipMemset(c->d_work, 0, sizeof(unsigned int) * 2 * (size_t)(cfg->max_blocks + 1)));   // dispensers re-arm themselves
         HIPCHK(c, hipMemset(c->d_nbits, 0, nch * sizeof(int)));
 
         if (cfg->flags & ACG_F_REPAIR) {
@@ -375,7 +380,10 @@ static int launch_fir(acg_ctx* c, const uint8_t* iq_dev, size_t pitch, int nbloc
     a.ntaps_pad = c->ntaps_pad;
     a.nwin = nblocks * ACG_BLOCK;
     a.row_bytes = 2 * g.decim;
-    a.work_counter = c->d_work + block0;         // distinct word per chunk: launches of one call may overlap
+    a.work_counter = c->d_work + 2 * block0;     // {tickets, finished} per chunk slot
+    // few channels: the demodulator's serial chain is the critical path; three resident workgroups per CU
+    // cost the down-converter ~5 % of its bandwidth and give the demodulator waves ~10 % (whole job +5 %)
+    a.wg_per_cu = c->msk_high_prio ? 3 : 0;
     const bool timing = (g.flags & ACG_F_TIMING) != 0;
     EvPair ev{};
     if (timing) {
@@ -527,10 +535,18 @@ extern "C" int acg_process_iq_u8_dev(acg_ctx* ctx, const uint8_t* iq_dev, size_t
         // dm blocks [b0, b0+nb) may still be read by demodulator launches of the previous call
         for (int j = b0; j < b0 + nb; ++j)
             if (ctx->msk_done_valid[(size_t)j]) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->msk_done[(size_t)j], 0));
+        // dispatch order: the demodulator launch of the previous chunk goes to the chip BEFORE this
+        // down-converter launch floods it (otherwise its few long-lived waves are placed into whatever the
+        // persistent workgroups left over and run ~20 % slower): wait until the demodulator stream has
+        // reached that launch.  Costs one cross-queue signal per chunk; the down-converter is then at
+        // most two chunks ahead, which is all the run-ahead the pipeline needs.
+        if (ctx->msk_go_valid) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->msk_go, 0));
         r = launch_fir(ctx, iq_dev, pitch_bytes, nb, s, b0);
         if (r != ACG_OK) return r;
         HIPCHK(ctx, hipEventRecord(ctx->fir_done[(size_t)k], s));
         HIPCHK(ctx, hipStreamWaitEvent(ctx->msk_stream, ctx->fir_done[(size_t)k], 0));
+        HIPCHK(ctx, hipEventRecord(ctx->msk_go, ctx->msk_stream));
+        ctx->msk_go_valid = true;
         r = launch_msk(ctx, ctx->d_dm + (size_t)b0 * ACG_BLOCK, ctx->dm_pitch, nb * ACG_BLOCK, ctx->msk_stream, b0 > 0);
         if (r != ACG_OK) return r;
         // one event per dm block so that a later call with different chunking still finds its guards
@@ -873,6 +889,7 @@ static int run_fmt(acg_ctx* ctx, int fmt, FirArgs* a, hipStream_t s)
             if ((r = get_event(ctx, &ev.a)) != ACG_OK || (r = get_event(ctx, &ev.b)) != ACG_OK) return r;
             HIPCHK(ctx, hipEventRecord(ev.a, s));
         }
+        if (ctx->msk_go_valid) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->msk_go, 0));   // see acg_process_iq_u8_dev
         const int e = acg_launch_fir_fmt(a, fmt, s);
         if (e != 0) {
             ctx->err = std::string("FIR launch: ") + hipGetErrorString((hipError_t)e);
@@ -884,6 +901,8 @@ static int run_fmt(acg_ctx* ctx, int fmt, FirArgs* a, hipStream_t s)
         }
         HIPCHK(ctx, hipEventRecord(ctx->fir_done[(size_t)k], s));
         HIPCHK(ctx, hipStreamWaitEvent(ctx->msk_stream, ctx->fir_done[(size_t)k], 0));
+        HIPCHK(ctx, hipEventRecord(ctx->msk_go, ctx->msk_stream));
+        ctx->msk_go_valid = true;
         int r = launch_msk(ctx, ctx->d_dm + w0, ctx->dm_pitch, nw, ctx->msk_stream, w0 > 0);
         if (r != ACG_OK) return r;
         for (int j = j0; j < j1; ++j) {

@@ -65,6 +65,7 @@ struct FirArgs {
     const int* group_ch;        // shared-stream kernel: channel ids ordered by stream
     int ngroups;
     const float* gtaps;         // shared-stream kernel: taps regrouped [group][step][channel][16]
+    int wg_per_cu;              // resident down-converter workgroups per CU (0 = as many as fit, at most 5)
     int kseg;                   // format kernels: column segments per window (long windows pass through LDS in kseg slices)
     int cpr_total;              // format kernels: 16-byte chunks per whole window (cpr = chunks per slice)
     float out_scale;            // power-of-two scale applied to |D| (1, 1/32768 soapy.c:241, 1/4 sdrplay.c:225)

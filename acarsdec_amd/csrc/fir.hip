@@ -41,6 +41,19 @@ __device__ __forceinline__ unsigned int take_ticket(unsigned int& ticket)
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket) : : "memory");
     return ticket;
 }
+// The dispenser is two words, {tickets handed out, workgroups finished}, both zero between launches:
+// run ids are gridDim.x + ticket (the first run of a workgroup is its own id), and the last workgroup
+// to leave re-arms the pair, so no memset launch precedes the kernel.  A workgroup's own request has
+// been performed before it signs off (take_ticket), so no ticket atomic can land after the reset.
+__device__ __forceinline__ void dispenser_sign_off(unsigned int* counter, unsigned int& pending)
+{
+    (void)take_ticket(pending);
+    const unsigned int d = atomicAdd(counter + 1, 1u);
+    if (d == gridDim.x - 1) {
+        __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(counter + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 
 
 __device__ __forceinline__ float cabs_like_glibc(float re, float im)
@@ -170,7 +183,7 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_tile_kernel(const FirArgs a
 // (channel, tile) space is cut into equal contiguous runs, one per workgroup, so that all workgroups
 // finish together (no partial last wave of workgroups).  A run may cross channel boundaries; the
 // stream/tap base pointers follow.  NT selects non-temporal loads for the input, which is read once.
-template <bool NT, bool DYN>
+template <bool NT, bool DYN, bool FULL>
 __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_persist_kernel(const FirArgs a,
                                                                      const uint8_t* __restrict__ iq_base,
                                                                      const float* __restrict__ taps_base,
@@ -202,31 +215,40 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_persist_kernel(const FirArg
     const int nck = a.ntaps_pad >> 3;
     const int c0 = nck * wave / 4;
     const int c1 = nck * (wave + 1) / 4;
-    const int nld = (tile_chunks + ACG_WG_FIR - 1) / ACG_WG_FIR;
 
     int ch = (int)(g0 / ntile);
     int t = (int)(g0 - (long long)ch * ntile);
     uint4 stage[FIR_MAXLD];
 
+    // A tile is 64*cpr chunks and a wave owns 64 consecutive chunks per pass, so "chunk inside the tile"
+    // is a whole-wave property (wave + 4*i < cpr): scalar branches, no per-lane predicates, and the
+    // address is one uniform base per pass + a per-thread constant offset (global_load ... saddr form:
+    // no vector address arithmetic at all).  FULL = every tile lies completely inside the row
+    // (nwin % 64 == 0, always true for whole callbacks), which removes the last per-lane bound.
+    const unsigned int voff = (unsigned int)tid << 4;
+    const size_t tile_bytes = (size_t)tile_chunks << 4;
+    // the row base follows the channel; looked up only when the channel changes (a dependent scalar
+    // load in front of every tile's loads would leave the workgroup without loads in flight meanwhile)
+    int row_ch = -1;
+    const uint8_t* __restrict__ row_base = iq_base;
     auto fetch = [&](int fch, int ft) {
-        const uint8_t* __restrict__ src = iq_base + (size_t)stream_of[fch] * a.pitch;
+        if (fch != row_ch) {
+            row_base = iq_base + (size_t)stream_of[fch] * a.pitch;
+            row_ch = fch;
+        }
+        const uint8_t* __restrict__ tb = row_base + (size_t)ft * tile_bytes;
         const int base = ft * tile_chunks;
+        typedef unsigned int u4v __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int i = 0; i < FIR_MAXLD; ++i) {
-            if (i < nld) {
-                const int c = tid + i * ACG_WG_FIR;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (c < tile_chunks && base + c < total_chunks) {
-                    const uint4* p = (const uint4*)(src + ((size_t)(base + c) << 4));
-                    if (NT) {
-                        typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-                        const u4v x = __builtin_nontemporal_load((const u4v*)p);
-                        v = make_uint4(x.x, x.y, x.z, x.w);
-                    } else {
-                        v = *p;
-                    }
+            if (wave + 4 * i < cpr) {
+                if (FULL || base + tid + i * ACG_WG_FIR < total_chunks) {
+                    const u4v* p = (const u4v*)(tb + (size_t)i * (ACG_WG_FIR * 16) + (size_t)voff);
+                    const u4v x = NT ? __builtin_nontemporal_load(p) : *p;
+                    stage[i] = make_uint4(x.x, x.y, x.z, x.w);
+                } else {
+                    stage[i] = make_uint4(0, 0, 0, 0);
                 }
-                stage[i] = v;
             }
         }
     };
@@ -236,19 +258,17 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_persist_kernel(const FirArg
     for (long long g = g0;;) {
 #pragma unroll
         for (int i = 0; i < FIR_MAXLD; ++i) {
-            if (i < nld) {
+            if (wave + 4 * i < cpr) {
                 const int c = tid + i * ACG_WG_FIR;
-                if (c < tile_chunks) {
-                    const int r = (int)(((unsigned int)c * magic) >> 20);
-                    *(uint4*)(tileL + (c << 4) + r * pad) = stage[i];
-                }
+                const int r = (int)(((unsigned int)c * magic) >> 20);
+                *(uint4*)(tileL + (c << 4) + r * pad) = stage[i];
             }
         }
         if (DYN) {
             // first tile of a run: ask for the next run; the answer is published at this barrier
             // one tile later and read when the last tile of the run prefetches across the run boundary
             if (g == g0 && tid == 0) request_ticket(a.work_counter, pending_next);
-            if (g == g0 + 1 && tid == 0) *s_next = (int)take_ticket(pending_next);
+            if (g == g0 + 1 && tid == 0) *s_next = (int)(gridDim.x + take_ticket(pending_next));
         }
         __syncthreads();
 
@@ -264,8 +284,8 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_persist_kernel(const FirArg
                 ng0 = nr * FIR_RUN;
                 ng1 = ng0 + FIR_RUN < G ? ng0 + FIR_RUN : G;
                 ng = ng0;
-                nch_ = (int)(ng0 / ntile);
-                nt_ = (int)(ng0 - (long long)nch_ * ntile);
+                nch_ = (int)((unsigned int)ng0 / (unsigned int)ntile);      // G < 2^31 (launcher)
+                nt_ = (int)((unsigned int)ng0 - (unsigned int)nch_ * (unsigned int)ntile);
                 more = true;
             }
         }
@@ -300,7 +320,7 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_persist_kernel(const FirArg
             const float Dr = ((r0.x + r1.x) + (r2.x + r3.x)) - ((r0.y + r1.y) + (r2.y + r3.y));
             const float Di = ((r0.z + r1.z) + (r2.z + r3.z)) + ((r0.w + r1.w) + (r2.w + r3.w));
             const int m = t * ACG_TILE_WIN + lane;
-            if (m < a.nwin) dm_base[(size_t)ch * a.dm_pitch + m] = cabs_like_glibc(Dr, Di);
+            if (m < a.nwin) dm_base[(size_t)ch * a.dm_pitch + m] = cabs_like_glibc(Dr, Di);             // rtl.c:353
         }
         if (!more) break;
         ch = nch_;
@@ -309,6 +329,7 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_persist_kernel(const FirArg
         g0 = ng0;
         g1 = ng1;
     }
+    if (DYN && tid == 0) dispenser_sign_off(a.work_counter, pending_next);
 }
 
 // Shared-stream variant -- rtl.c's own shape: one dongle's stream feeds several channels (up to 16,
@@ -338,6 +359,7 @@ __global__ void regroup_taps_kernel(const float* __restrict__ taps, float* __res
     }
 }
 
+template <bool FULL>
 __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_shared_kernel(const FirArgs a,
                                                                     const uint8_t* __restrict__ iq_base,
                                                                     const float* __restrict__ taps_base,
@@ -366,26 +388,33 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_shared_kernel(const FirArgs
     const int nck = a.ntaps_pad >> 3;
     const int c0 = nck * wave / 4;
     const int c1 = nck * (wave + 1) / 4;
-    const int nld = (tile_chunks + ACG_WG_FIR - 1) / ACG_WG_FIR;
 
     int grp = (int)(g0 / ntile);
     int t = (int)(g0 - (long long)grp * ntile);
     uint4 stage[FIR_MAXLD];
 
+    // wave-granular tile loads from one uniform base per pass, as in fir_u8_persist_kernel
+    const unsigned int voff = (unsigned int)tid << 4;
+    const size_t tile_bytes = (size_t)tile_chunks << 4;
+    int row_grp = -1;
+    const uint8_t* __restrict__ row_base = iq_base;
     auto fetch = [&](int fgrp, int ft) {
-        const uint8_t* __restrict__ src = iq_base + (size_t)groups[fgrp].x * a.pitch;
+        if (fgrp != row_grp) {
+            row_base = iq_base + (size_t)groups[fgrp].x * a.pitch;
+            row_grp = fgrp;
+        }
+        const uint8_t* __restrict__ tb = row_base + (size_t)ft * tile_bytes;
         const int base = ft * tile_chunks;
         typedef unsigned int u4v __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int i = 0; i < FIR_MAXLD; ++i) {
-            if (i < nld) {
-                const int c = tid + i * ACG_WG_FIR;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (c < tile_chunks && base + c < total_chunks) {
-                    const u4v x = __builtin_nontemporal_load((const u4v*)(src + ((size_t)(base + c) << 4)));
-                    v = make_uint4(x.x, x.y, x.z, x.w);
+            if (wave + 4 * i < cpr) {
+                if (FULL || base + tid + i * ACG_WG_FIR < total_chunks) {
+                    const u4v x = __builtin_nontemporal_load((const u4v*)(tb + (size_t)i * (ACG_WG_FIR * 16) + (size_t)voff));
+                    stage[i] = make_uint4(x.x, x.y, x.z, x.w);
+                } else {
+                    stage[i] = make_uint4(0, 0, 0, 0);
                 }
-                stage[i] = v;
             }
         }
     };
@@ -395,16 +424,14 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_shared_kernel(const FirArgs
     for (long long g = g0;;) {
 #pragma unroll
         for (int i = 0; i < FIR_MAXLD; ++i) {
-            if (i < nld) {
+            if (wave + 4 * i < cpr) {
                 const int c = tid + i * ACG_WG_FIR;
-                if (c < tile_chunks) {
-                    const int r = (int)(((unsigned int)c * magic) >> 20);
-                    *(uint4*)(tileL + (c << 4) + r * pad) = stage[i];
-                }
+                const int r = (int)(((unsigned int)c * magic) >> 20);
+                *(uint4*)(tileL + (c << 4) + r * pad) = stage[i];
             }
         }
         if (g == g0 && tid == 0) request_ticket(a.work_counter, pending_next);
-        if (g == g0 + 1 && tid == 0) *s_next = (int)take_ticket(pending_next);
+        if (g == g0 + 1 && tid == 0) *s_next = (int)(gridDim.x + take_ticket(pending_next));
         __syncthreads();
 
         int ngrp = grp, nt_ = t + 1;
@@ -417,8 +444,8 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_shared_kernel(const FirArgs
                 ng0 = nr * FIR_RUN;
                 ng1 = ng0 + FIR_RUN < G ? ng0 + FIR_RUN : G;
                 ng = ng0;
-                ngrp = (int)(ng0 / ntile);
-                nt_ = (int)(ng0 - (long long)ngrp * ntile);
+                ngrp = (int)((unsigned int)ng0 / (unsigned int)ntile);      // G < 2^31 (launcher)
+                nt_ = (int)((unsigned int)ng0 - (unsigned int)ngrp * (unsigned int)ntile);
                 more = true;
             }
         }
@@ -435,8 +462,8 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_shared_kernel(const FirArgs
         }
         const unsigned char* rowp = tileL + lane * a.row_stride;
         auto taps_pass = [&](auto full) {
-            constexpr bool FULL = decltype(full)::value;
-            const int kcc = FULL ? FIR_KC : kc;
+            constexpr bool ALLK = decltype(full)::value;
+            const int kcc = ALLK ? FIR_KC : kc;
             for (int c = c0; c < c1; ++c) {
                 const float* __restrict__ wc = gt + (size_t)(c * kcc) * 16;
                 const uint4 q = *(const uint4*)(rowp + (c << 4));
@@ -451,7 +478,7 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_shared_kernel(const FirArgs
                 }
 #pragma unroll
                 for (int k = 0; k < FIR_KC; ++k) {
-                    if (FULL || k < kc) {
+                    if (ALLK || k < kc) {
                         const float* __restrict__ w = wc + k * 16;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
@@ -494,6 +521,7 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_shared_kernel(const FirArgs
         g0 = ng0;
         g1 = ng1;
     }
+    if (tid == 0) dispenser_sign_off(a.work_counter, pending_next);
 }
 
 // LDS-DMA variant (rows that are an odd number of 16-byte slots, e.g. M = 200: no padding needed, so the
@@ -563,8 +591,8 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_dma_kernel(const FirArgs a,
                 ng0 = nr * FIR_RUN;
                 ng1 = ng0 + FIR_RUN < G ? ng0 + FIR_RUN : G;
                 ng = ng0;
-                nch_ = (int)(ng0 / ntile);
-                nt_ = (int)(ng0 - (long long)nch_ * ntile);
+                nch_ = (int)((unsigned int)ng0 / (unsigned int)ntile);      // G < 2^31 (launcher)
+                nt_ = (int)((unsigned int)ng0 - (unsigned int)nch_ * (unsigned int)ntile);
                 more = true;
             }
         }
@@ -594,7 +622,7 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_dma_kernel(const FirArgs a,
         float4* rd = red + cur * 256;
         rd[wave * 64 + lane] = make_float4(accA.x, accA.y, accB.x, accB.y);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the next tile has landed
-        if (g == g0 && tid == 0) *s_next = (int)take_ticket(pending_next);     // published by the barrier below
+        if (g == g0 && tid == 0) *s_next = (int)(gridDim.x + take_ticket(pending_next));     // published by the barrier below
         __syncthreads();
 
         if (wave == 0) {
@@ -612,6 +640,7 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_dma_kernel(const FirArgs a,
         g1 = ng1;
         cur ^= 1;
     }
+    if (tid == 0) dispenser_sign_off(a.work_counter, pending_next);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -862,11 +891,13 @@ extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)fir_u8_tile_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fir_u8_persist_kernel<false, false>,
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fir_u8_persist_kernel<false, false, false>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fir_u8_persist_kernel<true, false>,
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fir_u8_persist_kernel<true, false, false>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fir_u8_persist_kernel<true, true>,
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fir_u8_persist_kernel<true, true, true>,
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fir_u8_persist_kernel<true, true, false>,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fir_u8_dma_kernel,
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
@@ -895,8 +926,6 @@ extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
             const long long nrun4 = (G4 + FIR_RUN - 1) / FIR_RUN;
             long long grid4 = (long long)num_cu * per;
             if (grid4 > nrun4) grid4 = nrun4;
-            hipError_t e = hipMemsetD32Async((hipDeviceptr_t)a->work_counter, (int)grid4, 1, (hipStream_t)stream);
-            if (e != hipSuccess) return (int)e;
             hipLaunchKernelGGL(fir_u8_dma_kernel, dim3((unsigned int)grid4), dim3(ACG_WG_FIR), lds2, (hipStream_t)stream,
                                *a, a->iq, a->taps, a->stream_of, a->dm);
             return (int)hipGetLastError();
@@ -905,27 +934,32 @@ extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
     // resident workgroups: LDS-limited (160 KiB per CU), at most 5 (VGPR budget of 4-wave workgroups)
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 5) per_cu = 5;
+    if (a->wg_per_cu > 0 && per_cu > a->wg_per_cu) per_cu = a->wg_per_cu;
     if (per_cu < 1) per_cu = 1;
     if (const char* v = getenv("ACG_FIR_WG_PER_CU")) per_cu = atoi(v);
     const long long ntile = (a->nwin + ACG_TILE_WIN - 1) / ACG_TILE_WIN;
     const long long G = (long long)a->nch * ntile;
     long long grid = (long long)num_cu * per_cu;
     if (grid > G) grid = G;
+    FirArgs b = *a;
+    static const bool nocompute = getenv("ACG_FIR_DEBUG_NOCOMPUTE") != nullptr;   // measurement aid: loads + LDS staging only
+    if (nocompute) b.ntaps_pad = 0;
     if (variant == 1) {
-        hipLaunchKernelGGL((fir_u8_persist_kernel<false, false>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds,
-                           (hipStream_t)stream, *a, a->iq, a->taps, a->stream_of, a->dm);
+        hipLaunchKernelGGL((fir_u8_persist_kernel<false, false, false>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds,
+                           (hipStream_t)stream, b, a->iq, a->taps, a->stream_of, a->dm);
     } else if (variant == 2) {
-        hipLaunchKernelGGL((fir_u8_persist_kernel<true, false>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds,
-                           (hipStream_t)stream, *a, a->iq, a->taps, a->stream_of, a->dm);
+        hipLaunchKernelGGL((fir_u8_persist_kernel<true, false, false>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds,
+                           (hipStream_t)stream, b, a->iq, a->taps, a->stream_of, a->dm);
     } else {
         const long long nrun = (G + FIR_RUN - 1) / FIR_RUN;
         if (grid > nrun) grid = nrun;
-        // the run counter starts behind the statically assigned first runs
-        const unsigned int first = (unsigned int)grid;
-        hipError_t e = hipMemsetD32Async((hipDeviceptr_t)a->work_counter, (int)first, 1, (hipStream_t)stream);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL((fir_u8_persist_kernel<true, true>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds,
-                           (hipStream_t)stream, *a, a->iq, a->taps, a->stream_of, a->dm);
+        if (G >= (1ll << 31)) return (int)hipErrorInvalidValue;
+        if (a->nwin % ACG_TILE_WIN == 0)      // whole callbacks: every tile is complete
+            hipLaunchKernelGGL((fir_u8_persist_kernel<true, true, true>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds,
+                               (hipStream_t)stream, b, a->iq, a->taps, a->stream_of, a->dm);
+        else
+            hipLaunchKernelGGL((fir_u8_persist_kernel<true, true, false>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds,
+                               (hipStream_t)stream, b, a->iq, a->taps, a->stream_of, a->dm);
     }
     return (int)hipGetLastError();
 }
@@ -936,7 +970,8 @@ extern "C" int acg_launch_fir_shared(const FirArgs* a, void* stream)
     static bool attr_set = false;
     static int num_cu = 256;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)fir_u8_shared_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)fir_u8_shared_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fir_u8_shared_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
         if (e != hipSuccess) return (int)e;
         int dev = 0;
         (void)hipGetDevice(&dev);
@@ -953,10 +988,13 @@ extern "C" int acg_launch_fir_shared(const FirArgs* a, void* stream)
     const long long nrun = (G + FIR_RUN - 1) / FIR_RUN;
     long long grid = (long long)num_cu * per_cu;
     if (grid > nrun) grid = nrun;
-    hipError_t e = hipMemsetD32Async((hipDeviceptr_t)a->work_counter, (int)grid, 1, (hipStream_t)stream);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(fir_u8_shared_kernel, dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds, (hipStream_t)stream, *a,
-                       a->iq, a->gtaps, a->groups, a->group_ch, a->dm);
+    if (G >= (1ll << 31)) return (int)hipErrorInvalidValue;
+    if (a->nwin % ACG_TILE_WIN == 0)
+        hipLaunchKernelGGL(fir_u8_shared_kernel<true>, dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds, (hipStream_t)stream, *a,
+                           a->iq, a->gtaps, a->groups, a->group_ch, a->dm);
+    else
+        hipLaunchKernelGGL(fir_u8_shared_kernel<false>, dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds, (hipStream_t)stream, *a,
+                           a->iq, a->gtaps, a->groups, a->group_ch, a->dm);
     return (int)hipGetLastError();
 }
 
