@@ -340,7 +340,8 @@ def main():
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "bytes_per_launch": int(fir_bytes), "avg_launch_ms": round(fir_avg_ms, 4), "launches_per_step": lps,
                          "frac_of_measured_copy_ceiling_6290": round(achieved / 6290.0, 4),
-                         "read_probe_GBs_torch_sum_same_buffer": round(probe_gbs, 1), "frac_of_read_probe": round(achieved / probe_gbs, 4)},
+                         "read_probe_GBs_torch_sum_same_buffer": round(probe_gbs, 1), "frac_of_read_probe": round(achieved / probe_gbs, 4),
+                         "pure_nt_reader_GBs_profiles_probe": 7050.0, "frac_of_pure_nt_reader": round(achieved / 7050.0, 4)},
             "kernels": {"fir_ms_per_step": round(tim["fir_ms"] / args.steps, 4), "msk_ms_per_step": round(tim["msk_ms"] / args.steps, 4),
                         "note": "FIR chunks (own stream) overlap the MSK chunks of the previous chunk; per-step sums of event-timed launches"},
             "parity": parity,
