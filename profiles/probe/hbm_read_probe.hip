@@ -142,6 +142,103 @@ __global__ __launch_bounds__(256) void fir_like_reader(const u4v* __restrict__ s
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = 1;
 }
 
+// (4) the real kernel's skeleton, feature by feature (bit flags):
+//   1  second barrier + 4 KB partial-sum exchange through LDS per tile
+//   2  wave 0 finishes the tile: f64 sqrt per lane + one 256-byte store
+//   4  wave-uniform branches around every load / LDS write (as fir_u8_persist_kernel)
+//   8  dynamic runs of 4 tiles from an atomic dispenser instead of the static contiguous partition
+template <int F>
+__global__ __launch_bounds__(256) void fir_skel(const unsigned char* __restrict__ src, size_t ntile, unsigned int* sink, float* out,
+                                                int cpr, unsigned int* counter)
+{
+    extern __shared__ unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tile_chunks = 64 * cpr;
+    const size_t tile_bytes = (size_t)tile_chunks * 16;
+    float4* red = (float4*)(smem + tile_bytes);
+    int* s_next = (int*)(smem + tile_bytes + 8192);
+    uint4 stage[10];
+    const unsigned int voff = tid * 16;
+    auto fetch = [&](size_t t) {
+        const unsigned char* tb = src + t * tile_bytes;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            if (F & 4) {
+                if (wave + 4 * i < cpr) {
+                    const u4v x = __builtin_nontemporal_load((const u4v*)(tb + (size_t)i * 4096 + voff));
+                    stage[i] = make_uint4(x.x, x.y, x.z, x.w);
+                }
+            } else {
+                const int c = tid + i * 256;
+                if (c < tile_chunks) {
+                    const u4v x = __builtin_nontemporal_load((const u4v*)(tb + (size_t)c * 16));
+                    stage[i] = make_uint4(x.x, x.y, x.z, x.w);
+                }
+            }
+        }
+    };
+    size_t g0, g1;
+    const size_t nrun = (ntile + 3) / 4;
+    if (F & 8) { g0 = (size_t)blockIdx.x * 4; g1 = g0 + 4 < ntile ? g0 + 4 : ntile; }
+    else { g0 = ntile * blockIdx.x / gridDim.x; g1 = ntile * (blockIdx.x + 1) / gridDim.x; }
+    if (g0 >= g1) return;
+    float acc = 0.f;
+    unsigned int pending = 0;
+    bool have_prev = false; size_t prev_g = 0; int par = 0;
+    fetch(g0);
+    for (size_t g = g0;;) {
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+            const int c = tid + i * 256;
+            if ((F & 4) ? (wave + 4 * i < cpr) : (c < tile_chunks)) *(uint4*)(smem + (size_t)c * 16) = stage[i];
+        }
+        if (F & 8) {
+            if (g == g0 && tid == 0) pending = atomicAdd(counter, 1u);
+            if (g == g0 + 1 && tid == 0) *s_next = (int)(gridDim.x + pending);
+        }
+        __syncthreads();
+        bool more = g + 1 < g1;
+        size_t ng = g + 1, ng0 = g0, ng1 = g1;
+        if ((F & 8) && !more) {
+            const size_t nr = (g1 - g0 >= 2) ? (size_t)*s_next : nrun;
+            if (nr < nrun) { ng0 = nr * 4; ng1 = ng0 + 4 < ntile ? ng0 + 4 : ntile; ng = ng0; more = true; }
+        }
+        if (more) fetch(ng);
+        if ((F & 16) && wave == 0 && have_prev) {      // finish the PREVIOUS tile now, off the barrier-to-barrier path
+            const float4* rp = red + ((par ^ 1) * 256);
+            const float4 r0 = rp[lane], r1 = rp[64 + lane], r2 = rp[128 + lane], r3 = rp[192 + lane];
+            const float Dr = ((r0.x + r1.x) + (r2.x + r3.x)) - ((r0.y + r1.y) + (r2.y + r3.y));
+            const float Di = ((r0.z + r1.z) + (r2.z + r3.z)) + ((r0.w + r1.w) + (r2.w + r3.w));
+            out[prev_g * 64 + lane] = (float)__dsqrt_rn((double)Dr * (double)Dr + (double)Di * (double)Di);
+        }
+        const float4 q = *(const float4*)(smem + (size_t)lane * cpr * 16 + wave * 16);
+        acc += q.x;
+        if (F & 16) {
+            red[par * 256 + wave * 64 + lane] = q;
+            __syncthreads();
+            have_prev = true; prev_g = g; par ^= 1;
+        } else if (F & 1) {
+            red[wave * 64 + lane] = q;
+            __syncthreads();
+        }
+        if ((F & 2) && !(F & 16) && wave == 0) {
+            float4 r0 = q, r1 = q, r2 = q, r3 = q;
+            if (F & 1) { r0 = red[lane]; r1 = red[64 + lane]; r2 = red[128 + lane]; r3 = red[192 + lane]; }
+            const float Dr = ((r0.x + r1.x) + (r2.x + r3.x)) - ((r0.y + r1.y) + (r2.y + r3.y));
+            const float Di = ((r0.z + r1.z) + (r2.z + r3.z)) + ((r0.w + r1.w) + (r2.w + r3.w));
+            out[g * 64 + lane] = (float)__dsqrt_rn((double)Dr * (double)Dr + (double)Di * (double)Di);
+        }
+        if (!more) break;
+        g = ng; g0 = ng0; g1 = ng1;
+    }
+    if ((F & 8) && tid == 0) {
+        const unsigned int d = atomicAdd(counter + 1, 1u);
+        if (d == gridDim.x - 1) { counter[0] = 0; counter[1] = 0; }
+    }
+    if (acc == 1.2345f) sink[0] = 1;
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
 template <typename F>
@@ -219,6 +316,17 @@ int main()
             FL(1, false, true, false)
             FL(16, true, true, true)
         }
+    }
+
+    {
+        float* out; CK(hipMalloc(&out, (nvec / tile_vec) * 64 * sizeof(float)));
+        unsigned int* counter; CK(hipMalloc(&counter, 8)); CK(hipMemset(counter, 0, 8));
+        const size_t ntile = nvec / tile_vec;
+        const size_t lds = (size_t)tile_vec * 16 + 8192 + 16;
+        const int grid = 256 * 4;
+#define SK(F) printf("skeleton flags=%2d (wg/cu=4): %.0f GB/s\n", F, \
+            time_it([&] { hipLaunchKernelGGL((fir_skel<F>), dim3(grid), dim3(256), lds, 0, d, ntile, sink, out, 25, counter); }, bytes));
+        SK(0) SK(1) SK(3) SK(19) SK(7) SK(23) SK(8) SK(15) SK(31) SK(0)
     }
     return 0;
 }
