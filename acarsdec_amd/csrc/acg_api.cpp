@@ -30,6 +30,9 @@ struct acg_ctx {
     hipStream_t msk_stream = nullptr;   // demodulator launches (they carry the channel state) run here, in order
     hipStream_t copy_stream = nullptr;  // result copies that must not queue behind running kernels
     hipEvent_t in_ev = nullptr;
+    hipStream_t fir_stream = nullptr;   // CU partition: down-converter on the CUs the demodulator does not own
+    hipEvent_t fir_in = nullptr, fir_out = nullptr;
+    int fir_ncu = 0;
     std::vector<hipEvent_t> fir_done;   // per chunk slot: FIR of the slot finished (recorded on the caller's stream)
     hipEvent_t msk_go = nullptr;        // the demodulator stream has reached the launch of the newest chunk
     bool msk_go_valid = false;
@@ -51,6 +54,7 @@ struct acg_ctx {
     int last_len = 0;               // samples per channel of the last demod call
     int msk_lpc = 8;                // lanes per channel in the MSK kernel
     int msk_high_prio = 1;
+    int msk_cus_default = 0;        // CUs reserved for the demodulator (0 = no partition)
     bool last_had_demod = false;
 
     float* d_taps = nullptr;
@@ -143,6 +147,9 @@ static void free_all(acg_ctx* c)
     for (auto e : c->call_done) if (e) hipEventDestroy(e);
     if (c->h_call_count) hipHostFree(c->h_call_count);
     if (c->in_ev) hipEventDestroy(c->in_ev);
+    if (c->fir_in) hipEventDestroy(c->fir_in);
+    if (c->fir_out) hipEventDestroy(c->fir_out);
+    if (c->fir_stream) hipStreamDestroy(c->fir_stream);
     if (c->msk_stream) hipStreamDestroy(c->msk_stream);
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -218,6 +225,9 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
     }
     if (const char* e = std::getenv("ACG_PIPE_BLOCKS")) c->pipe_blocks = std::max(0, std::atoi(e));
     c->msk_high_prio = cfg->nch <= 2048 ? 1 : 0;
+    // few channels: the demodulator's serial chain is the critical path -> give its waves CUs of their own
+    // (one wave per SIMD), the down-converter keeps the rest (it is HBM-bound and loses nothing)
+    if (cfg->nch <= 2048) c->msk_cus_default = std::max(1, std::min(64, (cfg->nch * c->msk_lpc / 64 + 3) / 4));
     if (const char* e = std::getenv("ACG_MSK_PRIO")) c->msk_high_prio = std::atoi(e) ? 1 : 0;
     if (const char* e = std::getenv("ACG_MSK_LPC")) {
         const int v = std::atoi(e);
@@ -229,16 +239,22 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
         HIPCHK(c, hipSetDevice(cfg->device));
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         {
-            // Optionally confine the demodulator to a subset of CUs (ACG_MSK_CUS=n, ACG_MSK_CU_STRIDE=s):
-            // its few long-running high-priority waves then disturb the down-converter on those CUs only.
+            // CU partition (ACG_MSK_CUS=n): the demodulator's few long-lived waves get n CUs of their own
+            // (mask bits [0, n)) and the down-converter runs on the other 256 - n through an internal
+            // stream that is ordered against the caller's stream by events.  Whatever physical CUs the
+            // driver maps the bits to, the two masks are disjoint.
             const char* e = std::getenv("ACG_MSK_CUS");
-            const int ncu = e ? std::atoi(e) : 0;
-            if (ncu > 0 && ncu < 256) {
-                const char* es = std::getenv("ACG_MSK_CU_STRIDE");
-                const int stride = es ? std::max(1, std::atoi(es)) : 256 / ncu;
-                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (int i = 0, cu = 0; i < ncu && cu < 256; ++i, cu += stride) mask[cu >> 5] |= 1u << (cu & 31);
-                HIPCHK(c, hipExtStreamCreateWithCUMask(&c->msk_stream, 8, mask));
+            int ncu = e ? std::atoi(e) : c->msk_cus_default;
+            int total = 256;
+            (void)hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, cfg->device);
+            if (ncu > 0 && ncu < total && total <= 256) {
+                uint32_t mm[8] = {0, 0, 0, 0, 0, 0, 0, 0}, fm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int cu = 0; cu < total; ++cu) (cu < ncu ? mm : fm)[cu >> 5] |= 1u << (cu & 31);
+                HIPCHK(c, hipExtStreamCreateWithCUMask(&c->msk_stream, 8, mm));
+                HIPCHK(c, hipExtStreamCreateWithCUMask(&c->fir_stream, 8, fm));
+                HIPCHK(c, hipEventCreateWithFlags(&c->fir_in, hipEventDisableTiming));
+                HIPCHK(c, hipEventCreateWithFlags(&c->fir_out, hipEventDisableTiming));
+                c->fir_ncu = total - ncu;
             } else {
                 HIPCHK(c, hipStreamCreateWithFlags(&c->msk_stream, hipStreamNonBlocking));
             }
@@ -383,7 +399,9 @@ static int launch_fir(acg_ctx* c, const uint8_t* iq_dev, size_t pitch, int nbloc
     a.work_counter = c->d_work + 2 * block0;     // {tickets, finished} per chunk slot
     // few channels: the demodulator's serial chain is the critical path; three resident workgroups per CU
     // cost the down-converter ~5 % of its bandwidth and give the demodulator waves ~10 % (whole job +5 %)
-    a.wg_per_cu = c->msk_high_prio ? 3 : 0;
+    a.wg_per_cu = (c->msk_high_prio && !c->fir_stream) ? 3 : 0;
+    if (const char* e = std::getenv("ACG_FIR_WG_HINT")) a.wg_per_cu = std::atoi(e);
+    a.ncu = (s == c->fir_stream) ? c->fir_ncu : 0;
     const bool timing = (g.flags & ACG_F_TIMING) != 0;
     EvPair ev{};
     if (timing) {
@@ -446,6 +464,7 @@ static int launch_msk(acg_ctx* c, const float* dm_dev, size_t pitch_floats, int 
     a.len = len;
     a.bit_append = append ? 1 : 0;
     a.high_prio = c->msk_high_prio;
+    a.waves_per_group = c->fir_stream ? 4 : 1;
     a.dm_vec_ok = ((((uintptr_t)dm_dev) & 15) == 0 && (pitch_floats % 4) == 0) ? 1 : 0;
     const bool timing = (g.flags & ACG_F_TIMING) != 0;
     EvPair ev{};
@@ -519,7 +538,15 @@ extern "C" int acg_process_iq_u8_dev(acg_ctx* ctx, const uint8_t* iq_dev, size_t
     if (ctx->tile_path && (((uintptr_t)iq_dev | pitch_bytes) & 15))
         return fail(ctx, ACG_EINVAL, "I/Q base and pitch must be 16-byte aligned");
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
-    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    hipStream_t caller = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
+    hipStream_t s = caller;
+    if (ctx->fir_stream) {
+        // CU partition: the down-converter runs on its own masked stream, ordered after what the caller
+        // has enqueued so far (the input is ready) ...
+        s = ctx->fir_stream;
+        HIPCHK(ctx, hipEventRecord(ctx->fir_in, caller));
+        HIPCHK(ctx, hipStreamWaitEvent(s, ctx->fir_in, 0));
+    }
     // Software pipeline.  The (bandwidth-bound, wide) down-converter chunks run on the CALLER's
     // stream: they are the only consumers of the input, so whatever the caller enqueues next on
     // that stream (refilling the buffer, the next call) is ordered correctly.  The (latency-bound,
@@ -556,6 +583,12 @@ extern "C" int acg_process_iq_u8_dev(acg_ctx* ctx, const uint8_t* iq_dev, size_t
             HIPCHK(ctx, hipEventRecord(ctx->msk_done[(size_t)j], ctx->msk_stream));
             ctx->msk_done_valid[(size_t)j] = 1;
         }
+    }
+    if (ctx->fir_stream) {
+        // ... and whatever the caller enqueues next on its stream (refilling the input) waits for the
+        // last down-converter launch of this call
+        HIPCHK(ctx, hipEventRecord(ctx->fir_out, s));
+        HIPCHK(ctx, hipStreamWaitEvent(caller, ctx->fir_out, 0));
     }
     ctx->last_len = nblocks * ACG_BLOCK;
     return end_of_call(ctx);
@@ -865,8 +898,15 @@ static int fmt_geometry(acg_ctx* ctx, int fmt, FirArgs* a, int nwin)
 
 // Same software pipeline as acg_process_iq_u8_dev: down-converter chunks on stream s, demodulator
 // chunks in order on the context's stream, per-block guards on the dm buffer.
-static int run_fmt(acg_ctx* ctx, int fmt, FirArgs* a, hipStream_t s)
+static int run_fmt(acg_ctx* ctx, int fmt, FirArgs* a, hipStream_t caller)
 {
+    hipStream_t s = caller;
+    if (ctx->fir_stream) {                       // CU partition, see acg_process_iq_u8_dev
+        s = ctx->fir_stream;
+        HIPCHK(ctx, hipEventRecord(ctx->fir_in, caller));
+        HIPCHK(ctx, hipStreamWaitEvent(s, ctx->fir_in, 0));
+        a->ncu = ctx->fir_ncu;
+    }
     const int nwin = a->nwin;
     const uint8_t* iq0 = a->iq;
     const size_t win_bytes = (size_t)(fmt == ACG_FMT_S16_SPLIT ? a->row_bytes / 2 : a->row_bytes);
@@ -912,6 +952,10 @@ static int run_fmt(acg_ctx* ctx, int fmt, FirArgs* a, hipStream_t s)
     }
     a->iq = iq0;
     a->nwin = nwin;
+    if (ctx->fir_stream) {
+        HIPCHK(ctx, hipEventRecord(ctx->fir_out, s));
+        HIPCHK(ctx, hipStreamWaitEvent(caller, ctx->fir_out, 0));
+    }
     ctx->last_len = nwin;
     return end_of_call(ctx);
 }

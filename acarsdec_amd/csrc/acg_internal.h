@@ -6,7 +6,7 @@
 
 #define ACG_WG_FIR 256          // FIR workgroup: 4 waves, one 64-window tile, taps split over waves
 #define ACG_TILE_WIN 64         // windows (12.5 kHz outputs) per FIR tile = one per lane
-#define ACG_WG_MSK 64           // MSK workgroup: one wave, 64/LPC channels (LPC lanes per channel)
+#define ACG_WG_MSK 64           // one MSK wave: 64/LPC channels (LPC lanes per channel); 1 or 4 waves per workgroup
 
 // Per-channel demodulator + framing state, resident in HBM across calls.
 // Mirrors the MSK/ACARS fields of channel_t (acarsdec.h:76-89) plus bookkeeping.
@@ -66,6 +66,7 @@ struct FirArgs {
     int ngroups;
     const float* gtaps;         // shared-stream kernel: taps regrouped [group][step][channel][16]
     int wg_per_cu;              // resident down-converter workgroups per CU (0 = as many as fit, at most 5)
+    int ncu;                    // CUs the launch may use (0 = the whole device; fewer on a CU-masked stream)
     int kseg;                   // format kernels: column segments per window (long windows pass through LDS in kseg slices)
     int cpr_total;              // format kernels: 16-byte chunks per whole window (cpr = chunks per slice)
     float out_scale;            // power-of-two scale applied to |D| (1, 1/32768 soapy.c:241, 1/4 sdrplay.c:225)
@@ -87,6 +88,7 @@ struct MskArgs {
     int nch;
     int len;                    // samples per channel this launch
     int bit_append;             // 0: bit records start at 0; 1: append after nbits_out[ch] (same call)
+    int waves_per_group;        // 4 on a CU-masked stream (placement), else 1
     int high_prio;              // raise wave priority (latency mode)
     int dm_vec_ok;              // dm rows are 16-byte aligned: the window refill may use float4 loads
 };

@@ -838,7 +838,7 @@ extern "C" int acg_launch_fir_fmt(const FirArgs* a, int fmt, void* stream)
     if (per_cu > 4) per_cu = 4;
     const long long ntile = (a->nwin + ACG_TILE_WIN - 1) / ACG_TILE_WIN;
     const long long G = (long long)a->nch * ntile;
-    long long grid = (long long)num_cu * per_cu;
+    long long grid = (long long)(a->ncu > 0 ? a->ncu : num_cu) * per_cu;
     if (grid > G) grid = G;
     switch (fmt) {
     case FMT_CS16:
@@ -939,7 +939,7 @@ extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
     if (const char* v = getenv("ACG_FIR_WG_PER_CU")) per_cu = atoi(v);
     const long long ntile = (a->nwin + ACG_TILE_WIN - 1) / ACG_TILE_WIN;
     const long long G = (long long)a->nch * ntile;
-    long long grid = (long long)num_cu * per_cu;
+    long long grid = (long long)(a->ncu > 0 ? a->ncu : num_cu) * per_cu;
     if (grid > G) grid = G;
     FirArgs b = *a;
     static const bool nocompute = getenv("ACG_FIR_DEBUG_NOCOMPUTE") != nullptr;   // measurement aid: loads + LDS staging only
@@ -986,7 +986,7 @@ extern "C" int acg_launch_fir_shared(const FirArgs* a, void* stream)
     const long long ntile = (a->nwin + ACG_TILE_WIN - 1) / ACG_TILE_WIN;
     const long long G = (long long)a->ngroups * ntile;
     const long long nrun = (G + FIR_RUN - 1) / FIR_RUN;
-    long long grid = (long long)num_cu * per_cu;
+    long long grid = (long long)(a->ncu > 0 ? a->ncu : num_cu) * per_cu;
     if (grid > nrun) grid = nrun;
     if (G >= (1ll << 31)) return (int)hipErrorInvalidValue;
     if (a->nwin % ACG_TILE_WIN == 0)

@@ -201,27 +201,37 @@ __device__ __forceinline__ void sincos_2pi(double x, double* sn, double* cs)
 // rounding order matters), which also tells how many samples this bit period consumes.
 //   LPC = 8: latency mode (few thousand channels: one sincos per lane per bit)
 //   LPC = 1: throughput mode (tens of thousands of channels: no redundant work)
-template <int LPC>
-__global__ __launch_bounds__(ACG_WG_MSK) void msk_demod_kernel(const MskArgs a)
+// Workgroup shape: the waves are independent, but placement is not: the dispatcher puts the waves of ONE
+// workgroup on different SIMDs of a CU, whereas consecutive single-wave workgroups can land two to a SIMD
+// while other SIMDs of the same CU stay empty (measured with profiles/probe/cumask_probe.hip), which
+// doubles the per-bit time of both.  On a CU-masked stream (few channels, the demodulator owns a
+// handful of CUs) four waves therefore form a workgroup; unmasked, single-wave workgroups spread over
+// the whole chip and are ~3 % faster (less LDS sharing).
+
+template <int LPC, int WPG>
+__global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
 {
-    constexpr int CPW = ACG_WG_MSK / LPC;          // channels per wave
+    constexpr int CPW = 64 / LPC;                  // channels per wave
     constexpr int SPL = (6 + LPC - 1) / LPC;       // mixer samples per lane per bit period
     constexpr int WB = 32;                         // dm samples per refill block
     constexpr int SPB = WB / LPC;                  // dm samples per lane per refill
     constexpr int WSTR = 2 * WB + 1;               // odd row stride: conflict-free across channel slots
     // inb[] of the wave's channels, every sample stored twice (k and k+FLEN) so that the 11 taps of
     // the matched filter are always 11 consecutive rows starting at idx: no wrap, constant offsets
-    __shared__ float2 ring[2 * FLEN][CPW];
-    __shared__ float win[CPW][WSTR];               // sliding window of dm: blocks j and j+1
+    __shared__ float2 ring_all[WPG][2 * FLEN][CPW];
+    __shared__ float win_all[WPG][CPW][WSTR];      // sliding window of dm: blocks j and j+1
     __shared__ float hs[FLEN * MFLTOVER + 1];
 
-    const int tid = threadIdx.x;
-    for (int i = tid; i < FLEN * MFLTOVER + 1; i += ACG_WG_MSK) hs[i] = a.h[i];
+    for (int i = threadIdx.x; i < FLEN * MFLTOVER + 1; i += 64 * WPG) hs[i] = a.h[i];
 
+    const int wv = threadIdx.x >> 6;               // the waves of a workgroup never talk to each other
+    const int tid = threadIdx.x & 63;
+    float2 (*ring)[CPW] = ring_all[wv];
+    float (*win)[WSTR] = win_all[wv];
     const int slot = tid / LPC;                    // channel slot inside the wave
     const int g = tid - slot * LPC;                // lane inside the group
     const bool leader = g == 0;
-    const int ch = blockIdx.x * CPW + slot;
+    const int ch = (blockIdx.x * WPG + wv) * CPW + slot;
     const bool active = ch < a.nch;
     const int chc = active ? ch : a.nch - 1;
     AcgChan* st = a.st + chc;
@@ -469,13 +479,19 @@ extern "C" int acg_launch_sincos_selftest(const double* x, double* s, double* c,
 
 extern "C" int acg_launch_msk(const MskArgs* a, int lpc, void* stream)
 {
-    const int cpw = ACG_WG_MSK / lpc;
-    const unsigned int grid = (unsigned int)((a->nch + cpw - 1) / cpw);
-    switch (lpc) {
-    case 1: hipLaunchKernelGGL(msk_demod_kernel<1>, dim3(grid), dim3(ACG_WG_MSK), 0, (hipStream_t)stream, *a); break;
-    case 2: hipLaunchKernelGGL(msk_demod_kernel<2>, dim3(grid), dim3(ACG_WG_MSK), 0, (hipStream_t)stream, *a); break;
-    case 4: hipLaunchKernelGGL(msk_demod_kernel<4>, dim3(grid), dim3(ACG_WG_MSK), 0, (hipStream_t)stream, *a); break;
-    case 8: hipLaunchKernelGGL(msk_demod_kernel<8>, dim3(grid), dim3(ACG_WG_MSK), 0, (hipStream_t)stream, *a); break;
+    const int cpw = 64 / lpc;
+    const int wpg = (a->waves_per_group == 4 && lpc >= 4) ? 4 : 1;
+    const unsigned int waves = (unsigned int)((a->nch + cpw - 1) / cpw);
+    const unsigned int grid = (waves + wpg - 1) / wpg;
+    const dim3 blk(64 * wpg);
+    hipStream_t s = (hipStream_t)stream;
+    switch (lpc * 16 + wpg) {
+    case 1 * 16 + 1: hipLaunchKernelGGL((msk_demod_kernel<1, 1>), dim3(grid), blk, 0, s, *a); break;
+    case 2 * 16 + 1: hipLaunchKernelGGL((msk_demod_kernel<2, 1>), dim3(grid), blk, 0, s, *a); break;
+    case 4 * 16 + 1: hipLaunchKernelGGL((msk_demod_kernel<4, 1>), dim3(grid), blk, 0, s, *a); break;
+    case 8 * 16 + 1: hipLaunchKernelGGL((msk_demod_kernel<8, 1>), dim3(grid), blk, 0, s, *a); break;
+    case 4 * 16 + 4: hipLaunchKernelGGL((msk_demod_kernel<4, 4>), dim3(grid), blk, 0, s, *a); break;
+    case 8 * 16 + 4: hipLaunchKernelGGL((msk_demod_kernel<8, 4>), dim3(grid), blk, 0, s, *a); break;
     default: return (int)hipErrorInvalidValue;
     }
     return (int)hipGetLastError();
