@@ -69,6 +69,7 @@ SYMBOLS = {
     "acg_replay_bits": (C.c_int, [C.c_void_p, BIT_SINK, C.c_void_p]),
     "acg_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int),
                                  C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "acg_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "acg_fill_random_u8_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_uint64, C.c_void_p]),
     "acg_synth_iq_u8_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_uint64, C.c_void_p]),

@@ -37,7 +37,7 @@ struct acg_ctx {
     hipEvent_t msk_go = nullptr;        // the demodulator stream has reached the launch of the newest chunk
     bool msk_go_valid = false;
     std::vector<hipEvent_t> msk_done;   // per chunk slot: MSK has consumed the slot's dm (recorded on msk_stream)
-    std::vector<char> msk_done_valid;
+    std::vector<int> msk_done_owner;    // per dm block: index of the event its last reader recorded, -1 = none
     int pipe_blocks = 1;            // 1024-output blocks per pipelined chunk (0 = no pipelining)
     // per process call: frame-queue length at its end (pinned host word) + completion event
     static constexpr int NCALL = 8;
@@ -54,6 +54,7 @@ struct acg_ctx {
     int last_len = 0;               // samples per channel of the last demod call
     int msk_lpc = 8;                // lanes per channel in the MSK kernel
     int msk_high_prio = 1;
+    int timing_mode = 0;            // 0 none, 1 both stages, 2 down-converter only (acg_set_timing)
     int msk_cus_default = 0;        // CUs reserved for the demodulator (0 = no partition)
     bool last_had_demod = false;
 
@@ -225,6 +226,7 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
     }
     if (const char* e = std::getenv("ACG_PIPE_BLOCKS")) c->pipe_blocks = std::max(0, std::atoi(e));
     c->msk_high_prio = cfg->nch <= 2048 ? 1 : 0;
+    c->timing_mode = (cfg->flags & ACG_F_TIMING) ? 1 : 0;
     // few channels: the demodulator's serial chain is the critical path -> give its waves CUs of their own
     // (one wave per SIMD), the down-converter keeps the rest (it is HBM-bound and loses nothing)
     if (cfg->nch <= 2048) c->msk_cus_default = std::max(1, std::min(64, (cfg->nch * c->msk_lpc / 64 + 3) / 4));
@@ -263,7 +265,7 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
         HIPCHK(c, hipEventCreateWithFlags(&c->in_ev, hipEventDisableTiming));
         c->fir_done.resize((size_t)cfg->max_blocks);
         c->msk_done.resize((size_t)cfg->max_blocks);
-        c->msk_done_valid.assign((size_t)cfg->max_blocks, 0);
+        c->msk_done_owner.assign((size_t)cfg->max_blocks, -1);
         for (auto& e : c->fir_done) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->msk_go, hipEventDisableTiming));
         for (auto& e : c->msk_done) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -329,7 +331,7 @@ extern "C" int acg_reset(acg_ctx* ctx)
     ctx->consumed = 0;
     ctx->call_seq = 0;
     ctx->feed_fill = 0;
-    std::fill(ctx->msk_done_valid.begin(), ctx->msk_done_valid.end(), 0);
+    std::fill(ctx->msk_done_owner.begin(), ctx->msk_done_owner.end(), -1);
     // initMsk (msk.c:34-41): MskPhi = MskClk = MskS = MskDf = idx = 0, inb zeroed;
     // static storage: MskLvlSum = MskBitCount = 0; initAcars (acars.c:230-234): outbits 0, nbits 8, WSYN
     std::vector<AcgChan> st((size_t)ctx->cfg.nch);
@@ -381,6 +383,28 @@ static int get_event(acg_ctx* c, hipEvent_t* e)
     return ACG_OK;
 }
 
+// dm guards: the demodulator launch that read dm block j last recorded msk_done[owner(j)] (one event
+// per chunk; every record is on the in-order demodulator stream, so a newer record of the same event
+// only makes a wait more conservative).  guard_wait makes stream s wait for the readers of blocks [j0, j1).
+static int guard_wait(acg_ctx* ctx, hipStream_t s, int j0, int j1)
+{
+    int last = -1;
+    for (int j = j0; j < j1; ++j) {
+        const int o = ctx->msk_done_owner[(size_t)j];
+        if (o >= 0 && o != last) {
+            HIPCHK(ctx, hipStreamWaitEvent(s, ctx->msk_done[(size_t)o], 0));
+            last = o;
+        }
+    }
+    return ACG_OK;
+}
+static int guard_record(acg_ctx* ctx, int j0, int j1)
+{
+    HIPCHK(ctx, hipEventRecord(ctx->msk_done[(size_t)j0], ctx->msk_stream));
+    for (int j = j0; j < j1; ++j) ctx->msk_done_owner[(size_t)j] = j0;
+    return ACG_OK;
+}
+
 static int launch_fir(acg_ctx* c, const uint8_t* iq_dev, size_t pitch, int nblocks, hipStream_t s, int block0 = 0)
 {
     const acg_config& g = c->cfg;
@@ -402,7 +426,7 @@ static int launch_fir(acg_ctx* c, const uint8_t* iq_dev, size_t pitch, int nbloc
     a.wg_per_cu = (c->msk_high_prio && !c->fir_stream) ? 3 : 0;
     if (const char* e = std::getenv("ACG_FIR_WG_HINT")) a.wg_per_cu = std::atoi(e);
     a.ncu = (s == c->fir_stream) ? c->fir_ncu : 0;
-    const bool timing = (g.flags & ACG_F_TIMING) != 0;
+    const bool timing = c->timing_mode != 0;
     EvPair ev{};
     if (timing) {
         int r;
@@ -466,7 +490,7 @@ static int launch_msk(acg_ctx* c, const float* dm_dev, size_t pitch_floats, int 
     a.high_prio = c->msk_high_prio;
     a.waves_per_group = c->fir_stream ? 4 : 1;
     a.dm_vec_ok = ((((uintptr_t)dm_dev) & 15) == 0 && (pitch_floats % 4) == 0) ? 1 : 0;
-    const bool timing = (g.flags & ACG_F_TIMING) != 0;
+    const bool timing = c->timing_mode == 1;
     EvPair ev{};
     if (timing) {
         int r;
@@ -506,8 +530,7 @@ extern "C" int acg_fir_only_dev(acg_ctx* ctx, const uint8_t* iq_dev, size_t pitc
         return fail(ctx, ACG_EINVAL, "I/Q base and pitch must be 16-byte aligned");
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
-    for (int j = 0; j < nblocks; ++j)
-        if (ctx->msk_done_valid[(size_t)j]) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->msk_done[(size_t)j], 0));
+    if ((r = guard_wait(ctx, s, 0, nblocks)) != ACG_OK) return r;
     r = launch_fir(ctx, iq_dev, pitch_bytes, nblocks, s);
     if (r == ACG_OK) ctx->last_len = nblocks * ACG_BLOCK;
     return r;
@@ -560,8 +583,7 @@ extern "C" int acg_process_iq_u8_dev(acg_ctx* ctx, const uint8_t* iq_dev, size_t
     for (int b0 = 0; b0 < nblocks; b0 += cb, ++k) {
         const int nb = std::min(cb, nblocks - b0);
         // dm blocks [b0, b0+nb) may still be read by demodulator launches of the previous call
-        for (int j = b0; j < b0 + nb; ++j)
-            if (ctx->msk_done_valid[(size_t)j]) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->msk_done[(size_t)j], 0));
+        if ((r = guard_wait(ctx, s, b0, b0 + nb)) != ACG_OK) return r;
         // dispatch order: the demodulator launch of the previous chunk goes to the chip BEFORE this
         // down-converter launch floods it (otherwise its few long-lived waves are placed into whatever the
         // persistent workgroups left over and run ~20 % slower): wait until the demodulator stream has
@@ -576,13 +598,7 @@ extern "C" int acg_process_iq_u8_dev(acg_ctx* ctx, const uint8_t* iq_dev, size_t
         ctx->msk_go_valid = true;
         r = launch_msk(ctx, ctx->d_dm + (size_t)b0 * ACG_BLOCK, ctx->dm_pitch, nb * ACG_BLOCK, ctx->msk_stream, b0 > 0);
         if (r != ACG_OK) return r;
-        // one event per dm block so that a later call with different chunking still finds its guards
-        HIPCHK(ctx, hipEventRecord(ctx->msk_done[(size_t)b0], ctx->msk_stream));
-        for (int j = b0; j < b0 + nb; ++j) ctx->msk_done_valid[(size_t)j] = (j == b0);
-        for (int j = b0 + 1; j < b0 + nb; ++j) {
-            HIPCHK(ctx, hipEventRecord(ctx->msk_done[(size_t)j], ctx->msk_stream));
-            ctx->msk_done_valid[(size_t)j] = 1;
-        }
+        if ((r = guard_record(ctx, b0, b0 + nb)) != ACG_OK) return r;
     }
     if (ctx->fir_stream) {
         // ... and whatever the caller enqueues next on its stream (refilling the input) waits for the
@@ -842,6 +858,13 @@ extern "C" int acg_set_state(acg_ctx* ctx, int ch, const acg_chan_state* st)
     return ACG_OK;
 }
 
+extern "C" int acg_set_timing(acg_ctx* ctx, int mode)
+{
+    if (!ctx || mode < 0 || mode > 2) return ACG_EINVAL;
+    ctx->timing_mode = mode;
+    return ACG_OK;
+}
+
 extern "C" int acg_get_timing(acg_ctx* ctx, double* fir_ms, int* fir_launches, double* msk_ms, int* msk_launches)
 {
     if (!ctx) return ACG_EINVAL;
@@ -912,14 +935,13 @@ static int run_fmt(acg_ctx* ctx, int fmt, FirArgs* a, hipStream_t caller)
     const size_t win_bytes = (size_t)(fmt == ACG_FMT_S16_SPLIT ? a->row_bytes / 2 : a->row_bytes);
     int cb = ctx->pipe_blocks > 0 ? (ctx->pipe_blocks + 1) / 2 : ctx->cfg.max_blocks;   // 4-byte samples: half the callbacks per ~2 GB
     const int cw = cb * ACG_BLOCK;
-    const bool timing = (ctx->cfg.flags & ACG_F_TIMING) != 0;
+    const bool timing = ctx->timing_mode != 0;
     int k = 0;
     for (int w0 = 0; w0 < nwin; w0 += cw, ++k) {
         const int nw = std::min(cw, nwin - w0);
         const int j0 = w0 / ACG_BLOCK;
         const int j1 = std::min(ctx->cfg.max_blocks, (w0 + nw + ACG_BLOCK - 1) / ACG_BLOCK);
-        for (int j = j0; j < j1; ++j)
-            if (ctx->msk_done_valid[(size_t)j]) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->msk_done[(size_t)j], 0));
+        { const int gr = guard_wait(ctx, s, j0, j1); if (gr != ACG_OK) return gr; }
         a->iq = iq0 + (size_t)w0 * win_bytes;
         a->dm = ctx->d_dm + w0;
         a->nwin = nw;
@@ -945,10 +967,7 @@ static int run_fmt(acg_ctx* ctx, int fmt, FirArgs* a, hipStream_t caller)
         ctx->msk_go_valid = true;
         int r = launch_msk(ctx, ctx->d_dm + w0, ctx->dm_pitch, nw, ctx->msk_stream, w0 > 0);
         if (r != ACG_OK) return r;
-        for (int j = j0; j < j1; ++j) {
-            HIPCHK(ctx, hipEventRecord(ctx->msk_done[(size_t)j], ctx->msk_stream));
-            ctx->msk_done_valid[(size_t)j] = 1;
-        }
+        if ((r = guard_record(ctx, j0, j1)) != ACG_OK) return r;
     }
     a->iq = iq0;
     a->nwin = nwin;

@@ -221,6 +221,10 @@ class Decoder:
                     inb=np.array(s.inb[:], dtype=np.float32), outbits=s.outbits, nbits=s.nbits,
                     Acarsstate=s.Acarsstate, blk_len=s.blk_len, blk_err=s.blk_err)
 
+    def set_timing(self, mode):
+        """0 = off, 1 = both stages, 2 = down-converter launches only."""
+        _chk(self.ctx, self.L.acg_set_timing(self.ctx, int(mode)))
+
     def timing(self):
         f, m = C.c_double(0), C.c_double(0)
         nf, nm = C.c_int(0), C.c_int(0)

@@ -179,6 +179,9 @@ int  acg_replay_bits(acg_ctx *ctx, acg_bit_sink sink, void *user);
 /* Sums of HIP-event-bracketed kernel time since the last call (ACG_F_TIMING), in ms, and the
  * number of launches they cover.  Synchronises. */
 int  acg_get_timing(acg_ctx *ctx, double *fir_ms, int *fir_launches, double *msk_ms, int *msk_launches);
+/* 0 = no events, 1 = both stages (what ACG_F_TIMING starts with), 2 = down-converter launches only:
+ * event records on the demodulator stream sit on its serial launch chain (~10 us per launch). */
+int  acg_set_timing(acg_ctx *ctx, int mode);
 /* device-side generator for large synthetic workloads: fills [nstreams] rows with seeded
  * uniform bytes */
 int  acg_fill_random_u8_dev(uint8_t *dev, size_t pitch_bytes, int nrows, size_t row_bytes,
