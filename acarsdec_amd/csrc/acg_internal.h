@@ -89,6 +89,8 @@ struct MskArgs {
     int len;                    // samples per channel this launch
     int bit_append;             // 0: bit records start at 0; 1: append after nbits_out[ch] (same call)
     int waves_per_group;        // 4 on a CU-masked stream (placement), else 1
+    unsigned int* snap;         // host-mapped word: the last workgroup out publishes the queue length there
+    unsigned int* done_ctr;     // workgroups finished (re-armed by the last one)
     int high_prio;              // raise wave priority (latency mode)
     int dm_vec_ok;              // dm rows are 16-byte aligned: the window refill may use float4 loads
 };

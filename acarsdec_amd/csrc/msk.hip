@@ -462,6 +462,20 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
         }
         a.nbits_out[ch] = nb;
     }
+    // the last workgroup out publishes the block-queue length of this launch to the host-mapped word of the
+    // call (no copy packet on the launch chain; the host reads it after the call's event)
+    if (a.snap) {
+        if (WPG > 1) __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            const unsigned int d = atomicAdd(a.done_ctr, 1u);
+            if (d == gridDim.x - 1) {
+                const unsigned int c = __hip_atomic_load(a.frame_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.snap, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(a.done_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 // test hook: the device sin/cos used by the mixer, on n arguments
