@@ -142,11 +142,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    local = local % torch.cuda.device_count()       # (a rehearsal of the N > 1 path on a 1-GPU box maps all ranks to GPU 0)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    backend = os.environ.get("ACG_BENCH_BACKEND", "nccl")    # "gloo": rehearsal without RCCL (several ranks on one GPU)
+    cdev = dev if backend == "nccl" else None                # where the few collective tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     L = K.load()
 
     # ---- per-channel configuration: made on rank 0 for ALL channels of the job, scattered over RCCL
@@ -160,7 +166,7 @@ def main():
         off[np.abs(off) < 25000] = 50000.0                             # >= 25 kHz from DC like chooseFc enforces
         cfg_rows = np.stack([off, r0.uniform(0, 2 * np.pi, nch_total), r0.integers(0, NPOOL, nch_total).astype(np.float64),
                              np.arange(nch_total, dtype=np.float64)], axis=1)
-    mine = shard.scatter_channel_config(cfg_rows, world, rank, dist if world > 1 else None, device=dev)
+    mine = shard.scatter_channel_config(cfg_rows, world, rank, dist if world > 1 else None, device=cdev)
     own = shard.owned_channels(nch_total, rank, world)
     assert mine.shape[0] == nch and np.array_equal(mine[:, 3].astype(np.int64), own)
     offs, phases, pool_idx = mine[:, 0], mine[:, 1], mine[:, 2].astype(np.int32)
@@ -236,7 +242,7 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier(device_ids=[local])
+            dist.barrier(device_ids=[local]) if backend == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
     # ---- correctness gate on the first pass (state starts from reset): a subset of rank 0's channels
@@ -277,7 +283,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     tim = dec.timing()
-    dt, nfr_total = shard.reduce_timing(dt, nfr, world, dist if world > 1 else None, dev)
+    dt, nfr_total = shard.reduce_timing(dt, nfr, world, dist if world > 1 else None, cdev)
 
     # what a plain vendor read-reduction gets out of HBM on this very buffer (outside the timed region):
     # the practical read ceiling next to the 8 TB/s spec figure
