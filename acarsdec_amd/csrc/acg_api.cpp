@@ -227,8 +227,10 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
     c->msk_lpc = cfg->nch <= 8192 ? 8 : cfg->nch <= 16384 ? 4 : cfg->nch <= 32768 ? 2 : 1;
     // pipeline chunk: 4 callbacks per launch pair.  Few large launches beat many small ones at every size
     // measured (1024 ... 16384 channels: launch tails, event packets); with the two dm buffers the chunks of a
-    // call only serve to let its demodulator start before its down-converter has finished.
-    c->pipe_blocks = 4;
+    // call only serve to let its demodulator start before its down-converter has finished.  Up to 1024
+    // channels even that is not worth a second pair: the down-converter of call i+1 hides under the
+    // demodulator of call i entirely (0 = whole calls).
+    c->pipe_blocks = cfg->nch <= 1024 ? 0 : 4;
     if (const char* e = std::getenv("ACG_PIPE_BLOCKS")) c->pipe_blocks = std::max(0, std::atoi(e));
     c->msk_high_prio = cfg->nch <= 2048 ? 1 : 0;
     c->timing_mode = (cfg->flags & ACG_F_TIMING) ? 1 : 0;
