@@ -454,6 +454,74 @@ def test_streaming_collect_equals_blocking_drain(D, O, S):
     assert sum(len(v) for v in results[0].values()) >= nch
 
 
+@pytest.mark.parametrize("pipe", ["", "1", "3"])
+def test_soak_mixed_call_sizes_device_input(D, O, S, pipe, monkeypatch):
+    """a long stream cut into calls of 1..4 callbacks in random order, device input refilled in place between
+    calls (the stream contract), lagged collection, two dm buffers, shared streams (3 dongles x 4/5/3
+    channels), CU partition, every pipeline chunking: blocks bit-exact per channel against the oracle run
+    over the uncut stream, and state doubles identical to a one-call-per-callback run."""
+    import torch
+    if pipe:
+        monkeypatch.setenv("ACG_PIPE_BLOCKS", pipe)
+    rng = np.random.default_rng(90210)
+    M, maxb = 160, 4
+    sizes = [int(x) for x in rng.integers(1, maxb + 1, size=14)]
+    total = sum(sizes)
+    groups = [4, 5, 3]
+    smap = np.repeat(np.arange(len(groups)), groups)
+    nch = int(smap.size)
+    offs = {}
+    iq_rows = []
+    for s_, g in enumerate(groups):
+        env = []
+        for k in range(g):
+            a, _ = S.channel_audio(rng, total * 1024, gap=(1500, 3000), text_len=(5, 40))
+            env.append(0.5 * (1 + 0.5 * a))
+        off = [25000.0 * (k + 1) * (-1) ** k for k in range(g)]
+        offs[s_] = off
+        iq_rows.append(S.iq_u8_from_envelopes(np.array(env), M, off, phases=list(np.linspace(0.1, 2.0, g)), scale=0.5 / g,
+                                              noise=0.01, rng=rng))
+    iq = np.stack(iq_rows)
+    fc = 131000000
+    taps = np.stack([D.rtl_taps(fc + int(offs[smap[c]][c - int(np.flatnonzero(smap == smap[c])[0])]), fc, M) for c in range(nch)])
+    row1 = 1024 * M * 2
+
+    def run(call_sizes):
+        dec = D.Decoder(nch, decim=M, nstreams=len(groups), max_blocks=maxb)
+        dec.set_taps(taps)
+        dec.set_channel_streams(smap)
+        dbuf = torch.empty((len(groups), maxb * row1), dtype=torch.uint8, device="cuda")
+        st = torch.cuda.Stream()
+        got, pos = [], 0
+        with torch.cuda.stream(st):
+            for nb in call_sizes:
+                chunk = torch.from_numpy(np.ascontiguousarray(iq[:, pos * row1:(pos + nb) * row1]))
+                dbuf[:, : nb * row1].copy_(chunk, non_blocking=False)      # refill in place, ordered on the caller's stream
+                dec.in_callback(dbuf, nblocks=nb, pitch=maxb * row1, stream=st.cuda_stream)
+                n, buf = dec.collect_frames_raw(lag=1)
+                got += [D.frame_tuple(buf[i]) for i in range(n)]
+                pos += nb
+        got += [D.frame_tuple(f) for f in dec.drain_frames()]
+        states = [dec.state(c) for c in range(nch)]
+        dec.close()
+        return blocks_by_channel_tuples(got), states
+
+    mixed, st_mixed = run(sizes)
+    single, st_single = run([1] * total)
+    assert mixed == single
+    for a, b in zip(st_mixed, st_single):
+        for k in a:
+            assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+    nblocks = 0
+    for c in range(nch):
+        ch = O.Channel(c)
+        ch.demod(O.fir_u8(iq[smap[c]], M, taps[c]))
+        want = [O.frame_tuple(f) for f in ch.frames]
+        nblocks += len(want)
+        assert mixed.get(c, []) == want, c
+    assert nblocks >= nch
+
+
 # ------------------------------------------------------------------------------------ other front ends' formats (SURVEY 8f.2)
 @pytest.mark.parametrize("M,feeds", [(160, [1000, 163841 - 1000, 70000, 999999]), (200, [5, 204800, 3 * 204800 + 17, 10 ** 7]), (192, [10 ** 7]),
                                       (400, [123457, 10 ** 7])])
