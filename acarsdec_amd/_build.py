@@ -44,11 +44,13 @@ def build_lib(force=False):
     units = [
         ("fir.hip", ["-O3"]),
         # -ffp-contract=off keeps the reference's separate mul/add roundings.  The -mllvm switches only move
-        # instructions: the demodulator is one long dependent chain per wave, and ILP-first scheduling
-        # without machine sinking / branch folding / tail duplication measured 5.7 % faster per bit
-        # (1.160 -> 1.094 us; profiles/probe/msk_only.py) than the default heuristics.
+        # instructions and shape control flow: the demodulator is one long dependent chain per wave, and
+        # ILP-first scheduling without machine sinking / branch folding / tail duplication, uniform regions
+        # left unstructured and small diamonds folded into selects measured 13 % faster per bit
+        # (1.160 -> 1.005 us; profiles/probe/msk_only.py) than the default heuristics.
         ("msk.hip", ["-O3", "-ffp-contract=off", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-disable-machine-sink",
-                     "-mllvm", "-disable-branch-fold", "-mllvm", "-disable-tail-duplicate"]),
+                     "-mllvm", "-disable-branch-fold", "-mllvm", "-disable-tail-duplicate",
+                     "-mllvm", "-structurizecfg-skip-uniform-regions", "-mllvm", "-phi-node-folding-threshold=4"]),
         ("synth.hip", ["-O3"]),
         ("blk.hip", ["-O3"]),
         ("acg_api.cpp", ["-O2"]),
