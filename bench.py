@@ -317,8 +317,8 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                 for e in json.load(f)["entries"]:
-                    if (e["channels"], e["decim"], e["ntaps"]) == (nch, M, ntaps) and abs(e["blocks_per_launch"] - nblk / lps) < 1e-9 \
-                            and e["kernel"].startswith("fir_u8_persist"):
+                    if fmt == 0 and share == 1 and (e["channels"], e["decim"], e["ntaps"]) == (nch, M, ntaps) \
+                            and abs(e["blocks_per_launch"] - nblk / lps) < 1e-9 and e["kernel"].startswith("fir_u8_persist"):
                         traffic = e["traffic_bytes"]
         except Exception:
             traffic = None
