@@ -192,6 +192,15 @@ __device__ __forceinline__ void sincos_2pi(double x, double* sn, double* cs)
     *cs = ((q + 1) & 2) ? -cc : cc;
 }
 
+// msk.c:83 `if (p >= 2*M_PI) p -= 2*M_PI;` as compare + one select + one fma: fma(-1, 2pi, p) is p - 2pi
+// with its single rounding, fma(-0.0, 2pi, p) is p itself (p + -0.0), and -1.0 / -0.0 differ in the high
+// word only.  Same results, one instruction less than subtract + two-word select on the serial chain.
+__device__ __forceinline__ double wrap_2pi(double p)
+{
+    const double k = __hiloint2double(p >= K_TWOPI ? (int)0xBFF00000 : (int)0x80000000, 0);
+    return __builtin_fma(k, K_TWOPI, p);
+}
+
 // LPC lanes cooperate on one channel ("replicated state machine, distributed sincos"): every lane
 // of a group carries an identical copy of the channel's scalar state and executes the same bit
 // logic, so nothing has to be broadcast; only the expensive per-sample work (f64 sin/cos + mix) of
@@ -325,7 +334,7 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             p4 += s;
-            if (p4 >= K_TWOPI) p4 -= K_TWOPI;
+            p4 = wrap_2pi(p4);
             c4 = (float)((double)c4 + s);
             pq[u] = p4;
         }
@@ -341,7 +350,7 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
                 for (int u = 4; u < 6; ++u) {
                     const bool go = !fired && (n + u < len);
                     double pn = p + s;                                     // msk.c:82-83
-                    if (pn >= K_TWOPI) pn -= K_TWOPI;
+                    pn = wrap_2pi(pn);
                     const float cn = (float)((double)L.clk + s);           // msk.c:95
                     if (go) {
                         p = pn;
@@ -356,7 +365,7 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
             // advances one sample in this pass (its bit period is then simply spread over several passes)
             // while the others do their normal period; it is back in step as soon as its bit fires
             double pn = p + s;                                             // msk.c:82-83
-            if (pn >= K_TWOPI) pn -= K_TWOPI;
+            pn = wrap_2pi(pn);
             const float cn = (float)((double)L.clk + s);                   // msk.c:95
             p = pn;
             L.clk = cn;
