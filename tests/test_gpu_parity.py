@@ -13,6 +13,7 @@ Stated tolerances:
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -145,6 +146,43 @@ def test_fir_shared_stream_kernel_ragged_groups(D, O, M, monkeypatch):
         assert np.all(np.abs(shared[c] - want) <= 1e-5 * np.abs(want) + 1e-6), c
         want2 = O.fir_u8(iq[smap[c]], M, taps[nch - 1 - c], nout=nout)
         assert np.all(np.abs(shared2[c] - want2) <= 1e-5 * np.abs(want2) + 1e-6), c
+
+
+FIR_VARIANT_CHILD = r'''
+import sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from acarsdec_amd import decoder as D
+from oracle import oracle as O
+M = int(sys.argv[1])
+rng = np.random.default_rng(99)
+nch, nblk = 6, 2
+nout = nblk * 1024
+iq = rng.integers(0, 256, size=(nch, nout * M * 2), dtype=np.uint8)
+taps = np.stack([O.rtl_taps(131000000 + 25000 * (c + 1), 131000000, M) for c in range(nch)])
+dec = D.Decoder(nch, decim=M, max_blocks=nblk)
+dec.set_taps(taps)
+dec.in_callback(iq)
+worst = 0.0
+for c in range(nch):
+    want = O.fir_u8(iq[c], M, taps[c], nout=nout)
+    got = dec.dm(c, nout)
+    assert np.all(np.abs(got - want) <= 1e-5 * np.abs(want) + 1e-6), c
+    worst = max(worst, float(np.abs(got - want).max()))
+print("OK", worst)
+'''
+
+
+@pytest.mark.parametrize("variant,M", [("0", 200), ("1", 200), ("2", 160), ("4", 200), ("3", 192)])
+def test_fir_kernel_variants_all_match_oracle(variant, M):
+    """the down-converter's alternative kernels stay selectable (ACG_FIR_VARIANT: 0 one workgroup per
+    segment, 1/2 static persistent partition without/with non-temporal loads, 3 the default dynamic
+    dispenser, 4 LDS-DMA double buffering): each one against the oracle, in a fresh process (the knob is
+    read once)."""
+    env = dict(os.environ, ACG_FIR_VARIANT=variant)
+    r = subprocess.run([sys.executable, "-c", FIR_VARIANT_CHILD % dict(root=ROOT), str(M)], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("OK"), (r.stdout[-500:], r.stderr[-1500:])
 
 
 # ------------------------------------------------------------------------------------ error behaviour of the ABI
