@@ -105,3 +105,16 @@ def test_iq_upconverter_shape_and_range():
     iq = S.iq_u8_from_envelopes(env, 160, [-50000.0, 75000.0])
     assert iq.dtype == np.uint8 and iq.size == 1024 * 160 * 2
     assert 90 < iq.min() < iq.max() < 165
+
+
+def test_build_recipe_keeps_the_exactness_critical_flags():
+    """msk.hip must be built without multiply-add contraction (the reference's IEEE build keeps mul and add
+    separate, msk.c:86-113) and host_setup.c likewise; the -mllvm switches may only be layout switches."""
+    src = open(os.path.join(ROOT, "acarsdec_amd", "_build.py")).read()
+    unit = src[src.index('("msk.hip"'):src.index('("synth.hip"')]
+    assert '"-ffp-contract=off"' in unit
+    assert "fast-math" not in src and "-Ofast" not in src and "-ffast" not in src
+    assert re.search(r'"gcc", "-O2", "-ffp-contract=off"', src)
+    allowed = {"-amdgpu-sched-strategy=max-ilp", "-disable-machine-sink", "-disable-branch-fold", "-disable-tail-duplicate",
+               "-structurizecfg-skip-uniform-regions", "-phi-node-folding-threshold=4"}
+    assert set(re.findall(r'"-mllvm", "([^"]+)"', unit)) <= allowed
