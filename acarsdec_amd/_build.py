@@ -16,6 +16,7 @@ INC = os.path.join(os.path.dirname(HERE), "include")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libacarsdec_amd.so")
+LIB_STAMP = os.path.join(LIBDIR, "libacarsdec_amd_stamp.so")
 DEMO = os.path.join(LIBDIR, "acarsdec_gpu")
 REF = os.environ.get("ACARSDEC_REF", "/root/reference")
 ARCH = "gfx950"
@@ -38,8 +39,13 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def build_lib(force=False):
+def build_lib(force=False, stamp=False):
+    """stamp=True: the measurement build (lib/libacarsdec_amd_stamp.so, -DACG_MSK_STAMP: s_memtime stamps in the
+    demodulator's per-bit loop, read by profiles/probe/msk_phase_stamps.py); never loaded by the product."""
     os.makedirs(OBJDIR, exist_ok=True)
+    tag = "_stamp" if stamp else ""
+    extra = ["-DACG_MSK_STAMP"] if stamp else []
+    out_lib = LIB_STAMP if stamp else LIB
     hdrs = [os.path.join(CSRC, "acg_internal.h"), os.path.join(INC, "acarsdec_amd.h"), os.path.abspath(__file__)]   # flags live here
     units = [
         ("fir.hip", ["-O3"]),
@@ -59,9 +65,12 @@ def build_lib(force=False):
     hc = hipcc()
     for name, flags in units:
         src = os.path.join(CSRC, name)
-        obj = os.path.join(OBJDIR, name + ".o")
+        if stamp and name not in ("msk.hip", "acg_api.cpp"):
+            objs.append(os.path.join(OBJDIR, name + ".o"))          # unchanged units are shared with the product build
+            continue
+        obj = os.path.join(OBJDIR, name + tag + ".o")
         if force or _newer([src] + hdrs, obj):
-            _run([hc, "--offload-arch=" + ARCH, "-std=c++17", "-fPIC", "-I" + INC, "-I" + CSRC] + flags +
+            _run([hc, "--offload-arch=" + ARCH, "-std=c++17", "-fPIC", "-I" + INC, "-I" + CSRC] + flags + extra +
                  ["-c", src, "-o", obj])
         objs.append(obj)
     src = os.path.join(CSRC, "host_setup.c")
@@ -69,9 +78,9 @@ def build_lib(force=False):
     if force or _newer([src] + hdrs, obj):
         _run(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-I" + INC, "-c", src, "-o", obj])
     objs.append(obj)
-    if force or _newer(objs, LIB):
-        _run([hc, "--offload-arch=" + ARCH, "-shared", "-o", LIB] + objs + ["-lm"])
-    return LIB
+    if force or _newer(objs, out_lib):
+        _run([hc, "--offload-arch=" + ARCH, "-shared", "-o", out_lib] + objs + ["-lm"])
+    return out_lib
 
 
 def build_demo(force=False):

@@ -16,6 +16,7 @@
 extern "C" void acg_host_msk_h(float* h);
 extern "C" float acg_host_level_db(double lvlsum, int bitcount);
 extern "C" void acg_host_crc_tables(unsigned short* crc, unsigned short* synd);
+extern "C" void acg_host_crc_tables_n(unsigned short* crc, unsigned short* synd, int nk);
 
 namespace {
 
@@ -78,11 +79,13 @@ struct acg_ctx {
     unsigned int* d_msk_done = nullptr;     // workgroups-finished counter of the demodulator kernel
     AcgFrameRec* h_stage = nullptr;         // host staging for acg_collect_frames / acg_drain_frames
     size_t h_stage_cap = 0;
-    unsigned int* d_work = nullptr;     // FIR run dispensers, one word per chunk slot
+    unsigned int* d_work = nullptr;     // FIR run dispensers, ACG_DISP_WORDS words per chunk slot
+    bool stream_identity = true;        // channel c reads stream c
     unsigned short* d_crctab = nullptr; // [256] + syndromes [1936] (ACG_F_REPAIR)
     unsigned int* d_rep_upto = nullptr; // blocks already through the repair kernel
     float2* d_bits = nullptr;
     int* d_nbits = nullptr;
+    unsigned long long* d_stamp = nullptr;   // measurement build (ACG_MSK_STAMP): per-wave phase cycle sums of the last demodulator launch
     void* d_stage = nullptr;        // staging for *_host entry points
     int feed_fmt = 0;               // acg_feed_samples_host: format and samples of the incomplete window carried
     size_t feed_fill = 0;
@@ -145,6 +148,7 @@ static void free_all(acg_ctx* c)
     if (!c) return;
     hipFree(c->d_taps); hipFree(c->d_stream_of); hipFree(c->d_groups); hipFree(c->d_group_ch); hipFree(c->d_gtaps); hipFree(c->d_dm_all); hipFree(c->d_st);
     hipFree(c->d_h); hipFree(c->d_txt); hipFree(c->d_frames); hipFree(c->d_frame_count);
+    hipFree(c->d_stamp);
     hipFree(c->d_bits); hipFree(c->d_nbits); hipFree(c->d_stage); hipFree(c->d_work); hipFree(c->d_msk_done); std::free(c->h_stage); hipFree(c->d_crctab); hipFree(c->d_rep_upto);
     for (auto& p : c->fir_ev) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto& p : c->msk_ev) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
@@ -178,6 +182,8 @@ static int upload_stream_map(acg_ctx* c, const int* so)
 {
     const int nch = c->cfg.nch, ns = c->cfg.nstreams;
     HIPCHK(c, hipMemcpy(c->d_stream_of, so, (size_t)nch * sizeof(int), hipMemcpyHostToDevice));
+    c->stream_identity = true;
+    for (int i = 0; i < nch; ++i) c->stream_identity &= so[i] == i;
     std::vector<int> cnt((size_t)ns + 1, 0), ord((size_t)nch);
     for (int i = 0; i < nch; ++i) cnt[(size_t)so[i] + 1]++;
     bool shared = false;
@@ -301,13 +307,17 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
         if (cfg->flags & ACG_F_BITLOG)
             HIPCHK(c, hipMalloc(&c->d_bits, nch * (size_t)c->bit_cap * sizeof(float2)));
         HIPCHK(c, hipMalloc(&c->d_nbits, nch * sizeof(int)));
-        HIPCHK(c, hipMalloc(&c->d_work, sizeof(unsigned int) * 2 * (size_t)(cfg->max_blocks + 1)));
-        HIPCHK(c, hipMemset(c->d_work, 0, sizeof(unsigned int) * 2 * (size_t)(cfg->max_blocks + 1)));   // dispensers re-arm themselves
+#ifdef ACG_MSK_STAMP
+        HIPCHK(c, hipMalloc(&c->d_stamp, (nch + 64) * 10 * sizeof(unsigned long long)));      // <= one wave per channel
+        HIPCHK(c, hipMemset(c->d_stamp, 0, (nch + 64) * 10 * sizeof(unsigned long long)));
+#endif
+        HIPCHK(c, hipMalloc(&c->d_work, sizeof(unsigned int) * ACG_DISP_WORDS * (size_t)(cfg->max_blocks + 1)));
+        HIPCHK(c, hipMemset(c->d_work, 0, sizeof(unsigned int) * ACG_DISP_WORDS * (size_t)(cfg->max_blocks + 1)));   // dispensers re-arm themselves
         HIPCHK(c, hipMemset(c->d_nbits, 0, nch * sizeof(int)));
 
         if (cfg->flags & ACG_F_REPAIR) {
-            std::vector<unsigned short> tabs(256 + 8 * 242);
-            acg_host_crc_tables(tabs.data(), tabs.data() + 256);
+            std::vector<unsigned short> tabs(256 + 8 * 243);          // one row beyond the reference's table, see host_setup.c
+            acg_host_crc_tables_n(tabs.data(), tabs.data() + 256, 243);
             HIPCHK(c, hipMalloc(&c->d_crctab, tabs.size() * sizeof(unsigned short)));
             HIPCHK(c, hipMemcpy(c->d_crctab, tabs.data(), tabs.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
             HIPCHK(c, hipMalloc(&c->d_rep_upto, sizeof(unsigned int)));
@@ -443,7 +453,8 @@ static int launch_fir(acg_ctx* c, const uint8_t* iq_dev, size_t pitch, int nbloc
     a.ntaps_pad = c->ntaps_pad;
     a.nwin = nblocks * ACG_BLOCK;
     a.row_bytes = 2 * g.decim;
-    a.work_counter = c->d_work + 2 * block0;     // {tickets, finished} per chunk slot
+    a.work_counter = c->d_work + (size_t)ACG_DISP_WORDS * block0;     // one dispenser per chunk slot
+    a.stream_identity = c->stream_identity ? 1 : 0;
     // few channels: the demodulator's serial chain is the critical path; three resident workgroups per CU
     // cost the down-converter ~5 % of its bandwidth and give the demodulator waves ~10 % (whole job +5 %)
     a.wg_per_cu = (c->msk_high_prio && !c->fir_stream) ? 3 : 0;
@@ -515,6 +526,7 @@ static int launch_msk(acg_ctx* c, const float* dm_dev, size_t pitch_floats, int 
     a.snap = c->d_call_count + (c->call_seq % acg_ctx::NCALL);
     a.done_ctr = c->d_msk_done;
     a.dm_vec_ok = ((((uintptr_t)dm_dev) & 15) == 0 && (pitch_floats % 4) == 0) ? 1 : 0;
+    a.stamp = c->d_stamp;
     const bool timing = c->timing_mode == 1;
     EvPair ev{};
     if (timing) {
@@ -673,6 +685,10 @@ extern "C" int acg_process_dm_dev(acg_ctx* ctx, const float* dm_dev, size_t pitc
     HIPCHK(ctx, hipStreamWaitEvent(ctx->msk_stream, ctx->in_ev, 0));
     int r = launch_msk(ctx, dm_dev, pitch_floats, len, ctx->msk_stream);
     if (r != ACG_OK) return r;
+    // the demodulator is the only reader of dm_dev: whatever the caller enqueues next on its stream
+    // (refilling the buffer in place) is ordered behind it, the same contract as the iq entry points
+    HIPCHK(ctx, hipEventRecord(ctx->in_ev, ctx->msk_stream));
+    HIPCHK(ctx, hipStreamWaitEvent(s, ctx->in_ev, 0));
     return end_of_call(ctx);
 }
 
@@ -941,6 +957,8 @@ static int fmt_geometry(acg_ctx* ctx, int fmt, FirArgs* a, int nwin)
     if (fmt < ACG_FMT_CS16 || fmt > ACG_FMT_F32_REAL) return fail(ctx, ACG_EINVAL, "unknown sample format");
     if (g.decim % (fmt == ACG_FMT_S16_SPLIT ? 8 : 4) || (fmt == ACG_FMT_S16_SPLIT && g.decim > 208))
         return fail(ctx, ACG_EINVAL, "this sample format needs decim % 4 == 0 (split planes: % 8 and <= 208)");
+    if (ctx->ntaps_pad % (fmt == ACG_FMT_S16_SPLIT ? 8 : 4))
+        return fail(ctx, ACG_EINVAL, "this sample format needs ntaps % 4 == 0 when decim % 8 != 0");
     std::memset(a, 0, sizeof(*a));
     a->stream_of = ctx->d_stream_of;
     a->taps = ctx->d_taps;
@@ -1121,6 +1139,46 @@ extern "C" int acg_fill_random_u8_dev(uint8_t* dev, size_t pitch_bytes, int nrow
     if (!dev || nrows < 1 || (row_bytes & 15) || (pitch_bytes & 15) || ((uintptr_t)dev & 15)) return ACG_EINVAL;
     const int e = acg_launch_fill_random(dev, pitch_bytes, nrows, row_bytes, seed, hip_stream);
     return e == 0 ? ACG_OK : ACG_EHIP;
+}
+
+#ifdef ACG_MSK_STAMP
+// measurement build only: phase cycle sums of the LAST demodulator launch, [waves][10]
+extern "C" int acg_msk_stamp_read(acg_ctx* ctx, unsigned long long* out, int nwaves)
+{
+    if (!ctx || !out || nwaves < 1 || nwaves > ctx->cfg.nch + 64) return ACG_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    HIPCHK(ctx, hipMemcpy(out, ctx->d_stamp, (size_t)nwaves * 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return ACG_OK;
+}
+extern "C" int acg_msk_lanes_per_channel(const acg_ctx* ctx) { return ctx ? ctx->msk_lpc : 0; }
+#endif
+
+extern "C" int acg_probe_read_dev(const void* dev, size_t bytes, int repeats, double* gb_per_s)
+{
+    if (!dev || bytes < 16 || ((uintptr_t)dev & 15) || repeats < 1 || !gb_per_s) return ACG_EINVAL;
+    unsigned int* sink = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int ncu = 256, devid = 0;
+    int rc = ACG_EHIP;
+    float ms = 0.f;
+    if (hipGetDevice(&devid) == hipSuccess && hipMalloc(&sink, sizeof(unsigned int)) == hipSuccess &&
+        hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, devid);
+        bool ok = acg_launch_read_probe(dev, bytes, sink, ncu, nullptr) == 0;           // warm-up
+        ok = ok && hipEventRecord(e0, nullptr) == hipSuccess;
+        for (int i = 0; ok && i < repeats; ++i) ok = acg_launch_read_probe(dev, bytes, sink, ncu, nullptr) == 0;
+        ok = ok && hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+             hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+        if (ok && ms > 0.f) {
+            *gb_per_s = (double)(bytes & ~(size_t)15) * repeats / (ms * 1e-3) / 1e9;
+            rc = ACG_OK;
+        }
+    }
+    if (e0) hipEventDestroy(e0);
+    if (e1) hipEventDestroy(e1);
+    hipFree(sink);
+    return rc;
 }
 
 extern "C" int acg_synth_iq_u8_dev(uint8_t* iq_dev, size_t pitch_bytes, int nrows, int nout, int decim,

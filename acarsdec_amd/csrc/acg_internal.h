@@ -70,8 +70,16 @@ struct FirArgs {
     int kseg;                   // format kernels: column segments per window (long windows pass through LDS in kseg slices)
     int cpr_total;              // format kernels: 16-byte chunks per whole window (cpr = chunks per slice)
     float out_scale;            // power-of-two scale applied to |D| (1, 1/32768 soapy.c:241, 1/4 sdrplay.c:225)
-    unsigned int* work_counter; // run dispenser of the dynamically scheduled kernel (one word per launch in flight)
+    unsigned int* work_counter; // run dispenser of the dynamically scheduled kernels (ACG_DISP_WORDS words per launch in flight)
+    int stream_identity;        // stream_of[ch] == ch for every channel: the row base needs no lookup
 };
+
+// Run dispenser of one launch in flight: words [0], [1] = {tickets, finished} of the workgroup-granular
+// kernels; the wave-granular kernel uses ACG_DISP_SHARDS ticket words, one 128-byte line apart (so that the
+// atomics of different shards go to different L2 channels), and a `finished` word after them.
+#define ACG_DISP_SHARDS 8
+#define ACG_DISP_STRIDE 32
+#define ACG_DISP_WORDS ((ACG_DISP_SHARDS + 1) * ACG_DISP_STRIDE)
 
 struct MskArgs {
     AcgChan* st;                // [nch]
@@ -93,6 +101,7 @@ struct MskArgs {
     unsigned int* done_ctr;     // workgroups finished (re-armed by the last one)
     int high_prio;              // raise wave priority (latency mode)
     int dm_vec_ok;              // dm rows are 16-byte aligned: the window refill may use float4 loads
+    unsigned long long* stamp;  // measurement build (ACG_MSK_STAMP) only: [waves][10] phase cycle sums, else null
 };
 
 #ifdef __cplusplus
@@ -113,6 +122,7 @@ int acg_launch_synth_iq(uint8_t* iq, size_t pitch, int nrows, int nout, int deci
                         size_t env_pitch, const int* env_index, const float* off_hz, const float* phase,
                         float scale, float noise, uint64_t seed, void* stream);
 int acg_launch_fill_random(uint8_t* dev, size_t pitch, int nrows, size_t row_bytes, uint64_t seed, void* stream);
+int acg_launch_read_probe(const void* dev, size_t bytes, unsigned int* sink, int ncu, void* stream);
 #ifdef __cplusplus
 }
 #endif

@@ -29,7 +29,10 @@ __global__ void blk_repair_kernel(AcgFrameRec* frames, unsigned int cap, const u
                                   const unsigned int* done_upto, const unsigned short* synd,
                                   const unsigned short* crctab)
 {
-    const unsigned int lo = *done_upto, hi = *count;
+    // at most one lap of the ring: if the demodulator queued more than `cap` blocks since the last repair pass
+    // (the host reports that as ACG_EOVERFLOW), the surviving newest `cap` are each processed exactly once
+    const unsigned int hi = *count;
+    const unsigned int lo = (hi - *done_upto > cap) ? hi - cap : *done_upto;
     for (unsigned int q = lo + blockIdx.x * blockDim.x + threadIdx.x; q - lo < hi - lo; q += gridDim.x * blockDim.x) {
         AcgFrameRec* f = frames + (q % cap);
         const int len = f->len;

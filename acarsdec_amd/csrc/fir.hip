@@ -644,6 +644,271 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_dma_kernel(const FirArgs a,
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Wave-private streaming variant -- the default for whole callbacks at the documented rates
+// (rtlMult 160 / 192 / 200, rtl.c:244-262).  What the workgroup-granular kernels above pay for is
+// structure, not arithmetic: two barriers per tile, a partial-sum exchange between the four
+// waves and a single finishing wave.  Here a wave owns its tiles outright and never talks to another wave:
+//   * the input never passes through LDS: a tile (64 windows x 2M bytes = CPR KiB, contiguous in HBM) is
+//     read as CPR wave-loads of 1 KiB (16 bytes per lane, non-temporal, one uniform base + lane offset),
+//     U loads always in flight per wave, across tile and run boundaries -- the access pattern of a pure
+//     streaming reader;
+//   * lane L of wave-load q holds 16-byte chunk i = 64 q + L = 8 consecutive complex samples of window
+//     i / CPR at column i % CPR.  The taps of that column come from a per-wave LDS copy of the channel's
+//     tap table, laid out [4 planes][CPR + 63 columns] with the columns replicated past CPR, so that
+//     the lane address is one base + a compile-time offset per q (no per-lane modulo) and the four
+//     ds_read_b128 of a step are bank-conflict free;
+//   * the 8-sample partial sum (re, im) of every chunk goes to a per-wave LDS array; after the CPR-th load
+//     lane = window adds the CPR partials of its window (row stride odd: conflict free), takes |D| and
+//     the wave writes 64 consecutive floats of dm.  All 64 lanes of every wave do this (no finishing wave);
+//   * work is handed out per WAVE in runs of 2 tiles (one channel) by a sharded ticket dispenser
+//     (ACG_DISP_SHARDS counters, each serving a contiguous eighth of the run space in address order;
+//     a wave whose shard is exhausted moves on to the next one).  The ticket for the next run is
+//     requested a whole tile before it is needed; the next run's taps are fetched during the last tile.
+// Summation order: 8 sequential fused multiply-adds per chunk, then CPR sequential adds (the reference
+// adds M terms sequentially; its own -Ofast build reassociates, SURVEY 8c: dm within 1e-5 relative).
+#define FIRD_R 2
+
+template <int CPR>
+struct FirD {
+    static constexpr int U = (CPR % 5 == 0) ? 5 : (CPR % 6 == 0) ? 6 : 4;      // wave-loads in flight; divides CPR
+    static constexpr int TS = CPR + 63;                                        // tap columns incl. replicas
+    static constexpr int PW = (CPR & 1) ? CPR : CPR + 1;                       // partial-sum row stride (odd)
+    static constexpr int TAB_BYTES = 4 * TS * 16;
+    static constexpr int P_BYTES = 64 * PW * 8;
+    static constexpr int WAVE_LDS = TAB_BYTES + P_BYTES;
+    static_assert(CPR % U == 0, "prefetch depth must divide the loads per tile");
+};
+
+typedef unsigned int u4v_t __attribute__((ext_vector_type(4)));
+
+// Raw buffer descriptor over [base, base + bytes): loads beyond `bytes` return 0 without touching memory,
+// so "no next run" is a descriptor of 0 bytes instead of a branch around every prefetch.  Loads through a
+// descriptor are `buffer_load_dwordx4 v, voff, s[rsrc], soffset offen nt`: one VGPR offset (lane * 16), the
+// tile / load position as scalar offset, no vector address arithmetic, the non-temporal bit explicit.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t fird_rsrc(const void* base, unsigned int bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ u4v_t fird_load(__amdgpu_buffer_rsrc_t r, unsigned int voff, unsigned int soff)
+{
+    return __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 2 /* nt */);
+}
+
+// The ticket for the run after the current one is requested by lane 0 a whole tile before it is looked at.
+// As a compiler builtin the atomic is waited for on the spot (the uniform-address atomic optimiser wants
+// its result at once); as inline asm the compiler does not know about it.  Returns are in issue order, so
+// once at most `younger` vector-memory operations are outstanding the (older) atomic has returned:
+// ticket_take waits for exactly that and costs nothing when U later loads have long been consumed.
+// tests/test_host_logic.py disassembles the kernel and checks that nothing touches the ticket register
+// between the two statements.
+__device__ __forceinline__ void ticket_request(unsigned int* counter, unsigned int& ticket)
+{
+    const unsigned int one = 1u;
+    asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(counter), "v"(one) : "memory");
+}
+template <int YOUNGER>
+__device__ __forceinline__ unsigned int ticket_take(unsigned int& ticket)
+{
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(ticket) : "i"(YOUNGER) : "memory");
+    return (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
+}
+
+// one tile: CPR wave-loads; as the registers of a consumed load free up, the load U positions further on
+// is issued -- inside the run through `cur` (compile-time scalar offsets), beyond it through `nxt`
+template <int CPR, int TILE>
+__device__ __forceinline__ void fird_tile(u4v_t (&st)[FirD<CPR>::U], __amdgpu_buffer_rsrc_t cur, __amdgpu_buffer_rsrc_t nxt,
+                                          unsigned int voff, const float4* __restrict__ Tl, f2* __restrict__ Pw,
+                                          const f2* __restrict__ Pr, float* __restrict__ dm_out, int lane)
+{
+    typedef FirD<CPR> F;
+#pragma unroll
+    for (int q = 0; q < CPR; ++q) {
+        const u4v_t d = st[q % F::U];
+        const int pos = TILE * CPR + q + F::U;               // position of the load issued now, in loads from the run's base
+        if (pos < FIRD_R * CPR) st[q % F::U] = fird_load(cur, voff, (unsigned int)pos * 1024u);
+        else st[q % F::U] = fird_load(nxt, voff, (unsigned int)(pos - FIRD_R * CPR) * 1024u);
+        const int c0 = (q * 64) % CPR;                       // column of lane 0 in this load (compile time)
+        const float4 w0 = Tl[0 * F::TS + c0], w1 = Tl[1 * F::TS + c0], w2 = Tl[2 * F::TS + c0], w3 = Tl[3 * F::TS + c0];
+        const float w[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
+        f2 accA = {0.f, 0.f};       // (sum tr*wr, sum ti*wi)
+        f2 accB = {0.f, 0.f};       // (sum tr*wi, sum ti*wr)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned int word = d[j >> 1];
+            const unsigned int sh = (j & 1) * 16;
+            f2 tt;
+            tt.x = (float)((word >> sh) & 0xffu) - 127.37f;            // rtl.c:338 (exact in f32)
+            tt.y = (float)((word >> (sh + 8)) & 0xffu) - 127.37f;      // rtl.c:339
+            const f2 wv = {w[2 * j], w[2 * j + 1]};
+            const f2 ws = {w[2 * j + 1], w[2 * j]};
+            accA = __builtin_elementwise_fma(tt, wv, accA);
+            accB = __builtin_elementwise_fma(tt, ws, accB);
+        }
+        const f2 part = {accA.x - accA.y, accB.x + accB.y};
+        if (F::PW == CPR) {
+            Pw[q * 64] = part;                                         // chunk i = 64 q + lane, rows of CPR
+        } else {
+            const unsigned int i = (unsigned int)(q * 64 + lane);
+            const unsigned int r = (i * ((65536u + CPR - 1) / CPR)) >> 16;   // i / CPR for i < 64 * CPR <= 2048
+            Pw[q * 64 + (int)r] = part;                                // + one pad entry per completed row
+        }
+    }
+    // lane = window: add the CPR partial sums of the row, |D| (rtl.c:353), 64 consecutive floats
+    f2 D = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < CPR; ++j) D = D + Pr[j];
+    dm_out[lane] = cabs_like_glibc(D.x, D.y);
+}
+
+template <int CPR>
+__device__ __forceinline__ void fird_body(const FirArgs& a, const uint8_t* __restrict__ iq_base, const float* __restrict__ taps_base,
+                                          const int* __restrict__ stream_of, float* __restrict__ dm_base)
+{
+    typedef FirD<CPR> F;
+    constexpr unsigned int NONE = 0xffffffffu;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned char* my = fir_smem + wave * F::WAVE_LDS;
+    float4* T = (float4*)my;
+    f2* P = (f2*)(my + F::TAB_BYTES);
+    const float4* Tl = T + lane;                                   // + (plane * TS + c0(q)) compile-time slots
+    f2* Pw = P + lane;                                             // + 64 q entries
+    const f2* Pr = P + lane * F::PW;
+
+    const unsigned int ntile = (unsigned int)a.nwin / ACG_TILE_WIN;                 // whole tiles only (launcher)
+    const unsigned int runs_per_ch = ntile / FIRD_R;                                // ntile % FIRD_R == 0 (launcher)
+    const unsigned int nrun = (unsigned int)a.nch * runs_per_ch;
+    const unsigned int nwaves = gridDim.x * (ACG_WG_FIR / 64);
+    const unsigned int wg = blockIdx.x * (ACG_WG_FIR / 64) + (unsigned int)wave;
+    unsigned int* ctr = a.work_counter;
+    constexpr unsigned int tile_bytes = (unsigned int)CPR * 1024u;
+    constexpr unsigned int run_bytes = FIRD_R * tile_bytes;
+    const unsigned int voff = (unsigned int)lane << 4;
+    const int nck = a.ntaps_pad >> 3;                                               // tap columns that carry taps
+
+    auto shard_lo = [&](unsigned int s) { return (unsigned int)((unsigned long long)nrun * s / ACG_DISP_SHARDS); };
+    // static first runs: wave wg takes run (wg / SHARDS) of shard (wg % SHARDS); tickets count on from there
+    auto shard_static = [&](unsigned int s) { return (nwaves + ACG_DISP_SHARDS - 1 - s) / ACG_DISP_SHARDS; };
+    auto run_of_ticket = [&](unsigned int s, unsigned int t) -> unsigned int {
+        const unsigned long long idx = (unsigned long long)shard_lo(s) + shard_static(s) + t;
+        return idx < shard_lo(s + 1) ? (unsigned int)idx : NONE;
+    };
+    auto probe = [&](unsigned int& s) -> unsigned int {             // synchronous: next run of shard s, else of the following shards
+        for (int k = 0; k < ACG_DISP_SHARDS; ++k) {
+            unsigned int t = 0;
+            if (lane == 0) t = __hip_atomic_fetch_add(ctr + s * ACG_DISP_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+            const unsigned int r = run_of_ticket(s, t);
+            if (r != NONE) return r;
+            s = (s + 1 == ACG_DISP_SHARDS) ? 0 : s + 1;
+        }
+        return NONE;
+    };
+    auto sign_off = [&]() {
+        if (lane == 0) {
+            const unsigned int d = atomicAdd(ctr + ACG_DISP_SHARDS * ACG_DISP_STRIDE, 1u);
+            if (d == nwaves - 1) {                                  // every wave's requests have been answered: re-arm
+#pragma unroll
+                for (int k = 0; k <= ACG_DISP_SHARDS; ++k)
+                    __hip_atomic_store(ctr + k * ACG_DISP_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+    auto run_base = [&](unsigned int run, unsigned int& ch, unsigned int& t0) -> const uint8_t* {
+        ch = run / runs_per_ch;
+        t0 = (run - ch * runs_per_ch) * FIRD_R;
+        const size_t row = (size_t)(a.stream_identity ? (int)ch : stream_of[ch]) * a.pitch;
+        return iq_base + row + (size_t)t0 * tile_bytes;
+    };
+    // taps of channel ch, column = lane (64 bytes); the values are not looked at before write_taps, so the
+    // loads stay in flight under the last tile of the run
+    auto fetch_taps = [&](unsigned int ch, float4 (&tp)[4]) {
+        const float4* src = (const float4*)(taps_base + (size_t)ch * a.ntaps_pad * 2) + (lane < nck ? lane : 0) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tp[k] = src[k];
+    };
+    auto write_taps = [&](const float4 (&tp)[4]) {
+        const bool on = lane < nck;                                 // columns beyond the last tap: zero
+#pragma unroll
+        for (int rep = 0; rep * CPR < F::TS; ++rep) {
+            const int u = lane + rep * CPR;
+            if (lane < CPR && u < F::TS) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) T[k * F::TS + u] = on ? tp[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+
+    unsigned int s = wg % ACG_DISP_SHARDS;
+    unsigned int run;
+    {
+        const unsigned long long idx = (unsigned long long)shard_lo(s) + wg / ACG_DISP_SHARDS;
+        run = idx < shard_lo(s + 1) ? (unsigned int)idx : NONE;
+        if (run == NONE) {                                          // tiny launches: fewer runs than waves in this shard
+            s = (s + 1 == ACG_DISP_SHARDS) ? 0 : s + 1;
+            run = probe(s);
+        }
+    }
+    if (run == NONE) { sign_off(); return; }
+
+    unsigned int ch, t0;
+    const uint8_t* base = run_base(run, ch, t0);
+    {
+        float4 tp[4];
+        fetch_taps(ch, tp);
+        write_taps(tp);
+    }
+    __amdgpu_buffer_rsrc_t cur = fird_rsrc(base, run_bytes);
+    u4v_t st[F::U];
+#pragma unroll
+    for (int i = 0; i < F::U; ++i) {
+        st[i] = fird_load(cur, voff, (unsigned int)i * 1024u);
+        asm volatile("" ::: "memory");                              // keep the loads in issue order (the waits count on it)
+    }
+
+    for (;;) {
+        // ask for the run after this one now; the answer is looked at a tile later
+        unsigned int tk;
+        if (lane == 0) ticket_request(ctr + s * ACG_DISP_STRIDE, tk);
+        float* __restrict__ dm_out = dm_base + (size_t)ch * a.dm_pitch + (size_t)t0 * ACG_TILE_WIN;
+        static_assert(FIRD_R == 2, "the run is unrolled by hand: first tile, last tile");
+        fird_tile<CPR, 0>(st, cur, cur, voff, Tl, Pw, Pr, dm_out, lane);
+        // last tile of the run: where does the stream go next?  (U loads and a store are in flight, all younger than the ticket)
+        unsigned int nrun_ = run_of_ticket(s, ticket_take<F::U + 1>(tk));   // + the dm store of the first tile
+        if (nrun_ == NONE) {
+            s = (s + 1 == ACG_DISP_SHARDS) ? 0 : s + 1;
+            nrun_ = probe(s);
+        }
+        const bool has_next = nrun_ != NONE;
+        unsigned int nch_ = ch, nt0 = t0;
+        const uint8_t* nbase = base;
+        if (has_next) nbase = run_base(nrun_, nch_, nt0);
+        const __amdgpu_buffer_rsrc_t nxt = fird_rsrc(nbase, has_next ? run_bytes : 0u);
+        float4 tp[4];
+        fetch_taps(nch_, tp);
+        fird_tile<CPR, 1>(st, cur, nxt, voff, Tl, Pw, Pr, dm_out + ACG_TILE_WIN, lane);
+        if (!has_next) break;
+        write_taps(tp);
+        run = nrun_;
+        ch = nch_;
+        t0 = nt0;
+        base = nbase;
+        cur = nxt;
+    }
+    sign_off();
+}
+
+template <int CPR>
+__global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_direct_kernel(const FirArgs a,
+                                                                    const uint8_t* __restrict__ iq_base,
+                                                                    const float* __restrict__ taps_base,
+                                                                    const int* __restrict__ stream_of,
+                                                                    float* __restrict__ dm_base)
+{
+    fird_body<CPR>(a, iq_base, taps_base, stream_of, dm_base);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // The other front ends' sample formats: same tile scheme, 4 bytes per input sample.
 //   FMT_CS16   interleaved int16 I,Q        soapy.c:238-241   (x/32768 folded into the output scale)
 //   FMT_SPLIT  int16 I plane + int16 Q plane sdrplay.c:219-223 (cabsf(D)/4 = output scale)
@@ -818,21 +1083,64 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_fmt_kernel(const FirArgs a,
     }
 }
 
+// Launch-side state is per DEVICE (function attributes belong to the device's code object; the CU count is
+// the device's): a process may hold contexts on several GPUs.
+#define FIR_MAXDEV 64
+struct FirDev {
+    bool ready;
+    int num_cu;
+};
+static FirDev g_firdev[FIR_MAXDEV];
+
+static int fir_device(FirDev** out)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= FIR_MAXDEV) return (int)hipErrorInvalidDevice;
+    FirDev* d = &g_firdev[dev];
+    if (!d->ready) {
+        const int big = 64 * 1024;
+        struct { const void* f; int bytes; } attrs[] = {
+            {(const void*)fir_u8_tile_kernel, big},
+            {(const void*)fir_u8_persist_kernel<false, false, false>, big},
+            {(const void*)fir_u8_persist_kernel<true, false, false>, big},
+            {(const void*)fir_u8_persist_kernel<true, true, true>, big},
+            {(const void*)fir_u8_persist_kernel<true, true, false>, big},
+            {(const void*)fir_u8_dma_kernel, 96 * 1024},
+            {(const void*)fir_u8_shared_kernel<true>, big},
+            {(const void*)fir_u8_shared_kernel<false>, big},
+            {(const void*)fir_fmt_kernel<FMT_CS16>, big},
+            {(const void*)fir_fmt_kernel<FMT_SPLIT>, big},
+            {(const void*)fir_fmt_kernel<FMT_F32R>, big},
+            {(const void*)fir_u8_direct_kernel<20>, 4 * FirD<20>::WAVE_LDS},
+            {(const void*)fir_u8_direct_kernel<24>, 4 * FirD<24>::WAVE_LDS},
+            {(const void*)fir_u8_direct_kernel<25>, 4 * FirD<25>::WAVE_LDS},
+        };
+        for (const auto& at : attrs) {
+            e = hipFuncSetAttribute(at.f, hipFuncAttributeMaxDynamicSharedMemorySize, at.bytes);
+            if (e != hipSuccess) return (int)e;
+        }
+        d->num_cu = 256;
+        (void)hipDeviceGetAttribute(&d->num_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        d->ready = true;
+    }
+    *out = d;
+    return 0;
+}
+
+static int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 extern "C" int acg_launch_fir_fmt(const FirArgs* a, int fmt, void* stream)
 {
     const size_t lds = (size_t)ACG_TILE_WIN * a->row_stride + 4 * 64 * sizeof(float4);
-    static bool attr_set = false;
-    static int num_cu = 256;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)fir_fmt_kernel<FMT_CS16>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fir_fmt_kernel<FMT_SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fir_fmt_kernel<FMT_F32R>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        if (e != hipSuccess) return (int)e;
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev);
-        attr_set = true;
-    }
+    FirDev* fd = nullptr;
+    if (int e = fir_device(&fd)) return e;
+    const int num_cu = fd->num_cu;
     if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 4) per_cu = 4;
@@ -883,30 +1191,41 @@ extern "C" size_t acg_fir_lds_bytes(const FirArgs* a)
     return (size_t)ACG_TILE_WIN * a->row_stride + 4 * 64 * sizeof(float4) + 16;
 }
 
+// wave-private streaming kernel: whole tiles, runs inside one channel, a rate it is instantiated for
+template <int CPR>
+static int launch_direct(const FirArgs* a, int num_cu, hipStream_t stream)
+{
+    const size_t lds = (size_t)(ACG_WG_FIR / 64) * FirD<CPR>::WAVE_LDS;
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 2) per_cu = 2;
+    per_cu = env_int("ACG_FIR_WG_PER_CU", per_cu);
+    const long long nrun = (long long)a->nch * (a->nwin / ACG_TILE_WIN / FIRD_R);
+    long long grid = (long long)(a->ncu > 0 ? a->ncu : num_cu) * per_cu;
+    const long long need = (nrun + ACG_WG_FIR / 64 - 1) / (ACG_WG_FIR / 64);
+    if (grid > need) grid = need;
+    hipLaunchKernelGGL(fir_u8_direct_kernel<CPR>, dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds, stream, *a, a->iq, a->taps,
+                       a->stream_of, a->dm);
+    return (int)hipGetLastError();
+}
+
 extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
 {
     const size_t lds = acg_fir_lds_bytes(a);
-    static bool attr_set = false;
-    static int variant = 3, num_cu = 256;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)fir_u8_tile_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fir_u8_persist_kernel<false, false, false>,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fir_u8_persist_kernel<true, false, false>,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fir_u8_persist_kernel<true, true, true>,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fir_u8_persist_kernel<true, true, false>,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fir_u8_dma_kernel,
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        if (e != hipSuccess) return (int)e;
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (const char* v = getenv("ACG_FIR_VARIANT")) variant = atoi(v);
-        attr_set = true;
+    FirDev* fd = nullptr;
+    if (int e = fir_device(&fd)) return e;
+    const int num_cu = fd->num_cu;
+    // ACG_FIR_VARIANT: 5 (default) wave-private streaming kernel where it applies, else 3; 0 one workgroup per
+    // segment; 1 / 2 static persistent partition without / with non-temporal loads; 3 workgroup-granular dynamic
+    // dispenser; 4 LDS-DMA double buffering
+    const int variant = env_int("ACG_FIR_VARIANT", 5);
+    if (variant == 5 && a->nwin > 0 && a->nwin % ACG_TILE_WIN == 0 && (a->nwin / ACG_TILE_WIN) % FIRD_R == 0 &&
+        (long long)a->nch * (a->nwin / ACG_TILE_WIN) < (1ll << 31) && a->ntaps_pad <= a->decim) {
+        switch (a->cpr) {
+        case 20: return launch_direct<20>(a, num_cu, (hipStream_t)stream);
+        case 24: return launch_direct<24>(a, num_cu, (hipStream_t)stream);
+        case 25: return launch_direct<25>(a, num_cu, (hipStream_t)stream);
+        default: break;
+        }
     }
     if (variant == 0) {
         const unsigned int grid = (unsigned int)a->nch * (unsigned int)a->nseg;
@@ -920,7 +1239,7 @@ extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
         if (lds2 <= 96 * 1024) {
             int per = (int)((160 * 1024) / lds2);
             if (per > 4) per = 4;
-            if (const char* v = getenv("ACG_FIR_WG_PER_CU")) per = atoi(v);
+            per = env_int("ACG_FIR_WG_PER_CU", per);
             const long long ntile4 = (a->nwin + ACG_TILE_WIN - 1) / ACG_TILE_WIN;
             const long long G4 = (long long)a->nch * ntile4;
             const long long nrun4 = (G4 + FIR_RUN - 1) / FIR_RUN;
@@ -936,13 +1255,13 @@ extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
     if (per_cu > 5) per_cu = 5;
     if (a->wg_per_cu > 0 && per_cu > a->wg_per_cu) per_cu = a->wg_per_cu;
     if (per_cu < 1) per_cu = 1;
-    if (const char* v = getenv("ACG_FIR_WG_PER_CU")) per_cu = atoi(v);
+    per_cu = env_int("ACG_FIR_WG_PER_CU", per_cu);
     const long long ntile = (a->nwin + ACG_TILE_WIN - 1) / ACG_TILE_WIN;
     const long long G = (long long)a->nch * ntile;
     long long grid = (long long)(a->ncu > 0 ? a->ncu : num_cu) * per_cu;
     if (grid > G) grid = G;
     FirArgs b = *a;
-    static const bool nocompute = getenv("ACG_FIR_DEBUG_NOCOMPUTE") != nullptr;   // measurement aid: loads + LDS staging only
+    const bool nocompute = getenv("ACG_FIR_DEBUG_NOCOMPUTE") != nullptr;   // measurement aid: loads + LDS staging only
     if (nocompute) b.ntaps_pad = 0;
     if (variant == 1) {
         hipLaunchKernelGGL((fir_u8_persist_kernel<false, false, false>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds,
@@ -967,22 +1286,14 @@ extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
 extern "C" int acg_launch_fir_shared(const FirArgs* a, void* stream)
 {
     const size_t lds = (size_t)ACG_TILE_WIN * a->row_stride + 16 * 64 * sizeof(float4) + 16;
-    static bool attr_set = false;
-    static int num_cu = 256;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)fir_u8_shared_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)fir_u8_shared_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        if (e != hipSuccess) return (int)e;
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev);
-        attr_set = true;
-    }
+    FirDev* fd = nullptr;
+    if (int e = fir_device(&fd)) return e;
+    const int num_cu = fd->num_cu;
     if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 4) per_cu = 4;
     if (per_cu < 1) per_cu = 1;
-    if (const char* v = getenv("ACG_FIR_WG_PER_CU")) per_cu = atoi(v);
+    per_cu = env_int("ACG_FIR_WG_PER_CU", per_cu);
     const long long ntile = (a->nwin + ACG_TILE_WIN - 1) / ACG_TILE_WIN;
     const long long G = (long long)a->ngroups * ntile;
     const long long nrun = (G + FIR_RUN - 1) / FIR_RUN;

@@ -87,7 +87,10 @@ float acg_host_level_db(double lvlsum, int bitcount)
 /* syndrom.h:15-49 (reflected CRC-CCITT byte table, poly 0x8408) and syndrom.h:52-295 (entry i + 8k =
  * remainder of a single wrong bit i in the byte followed by k more bytes), generated from their
  * definitions.  crc[256], synd[8*242]. */
-void acg_host_crc_tables(unsigned short *crc, unsigned short *synd)
+/* nk rows of 8 syndromes.  The reference's table has 242 rows (syndrom.h:52-295) but its block repair indexes
+ * row len - pr + 1 = 242 for a 241-byte text with a flagged first byte (acars.c:48,77): an out-of-bounds read
+ * there.  The device table carries that row too (same definition), so the result is defined and in bounds. */
+void acg_host_crc_tables_n(unsigned short *crc, unsigned short *synd, int nk)
 {
 	int i, k, j;
 	for (i = 0; i < 256; i++) {
@@ -96,13 +99,18 @@ void acg_host_crc_tables(unsigned short *crc, unsigned short *synd)
 			c = (c & 1) ? (unsigned short)((c >> 1) ^ 0x8408) : (unsigned short)(c >> 1);
 		crc[i] = c;
 	}
-	for (k = 0; k < 242; k++)
+	for (k = 0; k < nk; k++)
 		for (i = 0; i < 8; i++) {
 			unsigned short s = crc[1 << i];
 			for (j = 0; j < k; j++)
 				s = (unsigned short)((s >> 8) ^ crc[s & 0xff]);
 			synd[8 * k + i] = s;
 		}
+}
+
+void acg_host_crc_tables(unsigned short *crc, unsigned short *synd)
+{
+	acg_host_crc_tables_n(crc, synd, 242);
 }
 
 /* soapy.c:163-166: oscillator[ind] = cexpf(-j*AMFreq*ind)/rateMult with ch->Fr a float (acarsdec.h:70) */

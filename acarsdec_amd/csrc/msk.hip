@@ -217,6 +217,17 @@ __device__ __forceinline__ double wrap_2pi(double p)
 // handful of CUs) four waves therefore form a workgroup; unmasked, single-wave workgroups spread over
 // the whole chip and are ~3 % faster (less LDS sharing).
 
+// ACG_MSK_STAMP (measurement build only, lib/libacarsdec_amd_stamp.so): s_memtime at the phase boundaries of
+// the per-bit loop, summed per wave, written to MskArgs::stamp at the end -- the cycle breakdown of the serial
+// chain (profiles/probe/msk_phase_stamps.py).  The product build compiles none of it.
+#ifdef ACG_MSK_STAMP
+#define STAMP_DECL unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+#define STAMP(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); stamp_acc[k] += t_ - stamp_prev; stamp_prev = t_; } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(k) do { } while (0)
+#endif
+
 template <int LPC, int WPG>
 __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
 {
@@ -302,8 +313,15 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
     // few channels: this serial chain is the critical path of the whole job -> win issue arbitration;
     // many channels: the down-converter is, and these waves have slack -> stay at normal priority
     if (a.high_prio) __builtin_amdgcn_s_setprio(3);
+    STAMP_DECL
+#ifdef ACG_MSK_STAMP
+    unsigned long long stamp_iters = 0, stamp_bits = 0;
+#endif
 
     while (__any(n < len)) {
+#ifdef ACG_MSK_STAMP
+        ++stamp_iters;
+#endif
         // ---- window upkeep (rare: once per 32 samples per channel)
         if (n >= (pend_blk - 1) * WB && n < len) {
             store_block(pend_blk);
@@ -317,6 +335,7 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
 #pragma unroll
         for (int j = 0; j < SPL; ++j) in_cur[j] = win[slot][(n + g + j * LPC) & (2 * WB - 1)];
 
+        STAMP(0);                                                          // window upkeep + loop control
         // ---- A: advance VCO phase and bit clock over this bit period (replicated, sequential)
         const double s = K_VCO + L.df;                                     // msk.c:81
         const double thr = K_3PI2 - s / 2;                                 // msk.c:96
@@ -373,6 +392,7 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
             fired = (double)cn >= thr;
             if (g == 0) myp[0] = pn;
         }
+        STAMP(1);                                                          // A
         // ---- B: mixer for the cnt samples, spread over the group's lanes (msk.c:86-91)
 #pragma unroll
         for (int j = 0; j < SPL; ++j) {
@@ -395,8 +415,12 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
         // writes above; only the compiler has to be told not to move them
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        STAMP(2);                                                          // B
         // ---- C: bit decision (replicated; side effects by the group leader only)
         if (fired) {
+#ifdef ACG_MSK_STAMP
+            ++stamp_bits;
+#endif
             L.clk = (float)((double)L.clk - K_3PI2);                      // msk.c:100
             // matched filter, msk.c:103-107: taps h[o + 12 j] against inb[(j + idx) % 11], oldest first
             int o = (int)(MFLTOVER * ((double)L.clk / s + 0.5));
@@ -422,6 +446,10 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
                 acc = acc + hh * x;
             }
             float vr = acc.x, vi = acc.y;
+#ifdef ACG_MSK_STAMP
+            asm volatile("" : "+v"(vr), "+v"(vi));                          // the filter output exists before the stamp
+#endif
+            STAMP(3);                                                      // C1: tap phase (f64 divide), ring + h reads, matched filter
             // normalise, msk.c:110-113
             const float lvl = (float)__dsqrt_rn((double)vr * (double)vr + (double)vi * (double)vi);
             const double d = (double)lvl + 1e-8;
@@ -429,6 +457,10 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
             vi = (float)((double)vi / d);
             L.lvlsum += (double)(lvl * lvl / 4);
             L.bitcount++;
+#ifdef ACG_MSK_STAMP
+            asm volatile("" : "+v"(vr), "+v"(vi));
+#endif
+            STAMP(4);                                                      // C2: |v| (f64 sqrt), two f64 divides
             // decision + phase detector, msk.c:115-121, as sign-bit arithmetic (exact: only signs move):
             //   odd  S: vo = Im v, dphi = (vo >= 0) ? -Re v :  Re v
             //   even S: vo = Re v, dphi = (vo >= 0) ?  Im v : -Im v
@@ -452,10 +484,23 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
             }
             L.nbit_total++;
             L.S++;
+            STAMP(5);                                                      // C3: decision, bit record, putbit, framing FSM
             // PLL filter, msk.c:130 (float constants promoted to double)
             L.df = (double)0.52f * L.df + (1.0 - (double)0.52f) * (double)38e-4f * dphi;
+#ifdef ACG_MSK_STAMP
+            asm volatile("" : "+v"(L.df));
+#endif
+            STAMP(6);                                                      // C4: loop filter
         }
     }
+#ifdef ACG_MSK_STAMP
+    if (a.stamp && tid == 0) {
+        unsigned long long* o = a.stamp + (size_t)(blockIdx.x * WPG + wv) * 10;
+        for (int k = 0; k < 8; ++k) o[k] = stamp_acc[k];
+        o[8] = stamp_iters;
+        o[9] = stamp_bits;
+    }
+#endif
 
     if (active && leader) {
         st->phi = p; st->df = L.df; st->lvlsum = L.lvlsum;

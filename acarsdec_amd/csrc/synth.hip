@@ -76,6 +76,34 @@ __global__ void synth_iq_u8_kernel(uint8_t* iq, size_t pitch, int nrows, int nou
     }
 }
 
+// Measurement aid: a pure streaming reader (16 bytes per lane, non-temporal, 8 loads in flight per lane,
+// persistent grid) over `bytes` of device memory -- what HBM delivers to a kernel that does nothing
+// else.  bench.py times it on the benchmark's own input buffer, next to the 8 TB/s spec figure.
+typedef unsigned int probe_u4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void read_probe_kernel(const probe_u4* __restrict__ p, size_t nvec, unsigned int* sink)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    probe_u4 acc = {0u, 0u, 0u, 0u};
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 7 * stride < nvec; i += 8 * stride) {
+        probe_u4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = __builtin_nontemporal_load(p + i + k * stride);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc ^= v[k];
+    }
+    for (; i < nvec; i += stride) acc ^= __builtin_nontemporal_load(p + i);
+    const unsigned int x = acc.x ^ acc.y ^ acc.z ^ acc.w;
+    if (x == 0x9E3779B9u) *sink = x;          // never true for real data, keeps the loads alive
+}
+
+extern "C" int acg_launch_read_probe(const void* dev, size_t bytes, unsigned int* sink, int ncu, void* stream)
+{
+    hipLaunchKernelGGL(read_probe_kernel, dim3((unsigned int)(ncu > 0 ? ncu : 256) * 2), dim3(256), 0, (hipStream_t)stream,
+                       (const probe_u4*)dev, bytes / 16, sink);
+    return (int)hipGetLastError();
+}
+
 extern "C" int acg_launch_synth_iq(uint8_t* iq, size_t pitch, int nrows, int nout, int decim, const float* env,
                                    size_t env_pitch, const int* env_index, const float* off_hz, const float* phase,
                                    float scale, float noise, uint64_t seed, void* stream)

@@ -69,3 +69,14 @@ def reduce_timing(seconds, count, world, dist=None, device=None):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(c, op=dist.ReduceOp.SUM)
     return float(t.item()), float(c.item())
+
+
+def gather_scalars(x, world, dist=None, device=None):
+    """every rank's scalar, in rank order, on every rank (per-GPU timings of the bench report)."""
+    if world == 1 or dist is None:
+        return [float(x)]
+    import torch
+    mine = torch.tensor([float(x)], dtype=torch.float64, device=device)
+    box = [torch.zeros(1, dtype=torch.float64, device=device) for _ in range(world)]
+    dist.all_gather(box, mine)
+    return [float(b.item()) for b in box]

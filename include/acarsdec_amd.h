@@ -118,7 +118,9 @@ int  acg_process_iq_u8_dev(acg_ctx *ctx, const uint8_t *iq_dev, size_t pitch_byt
 			   void *hip_stream);
 int  acg_process_iq_u8_host(acg_ctx *ctx, const uint8_t *iq_host, size_t pitch_bytes, int nblocks);
 /* demodMSK() for every channel straight from 12.5 kHz samples (soundfile.c:71-77, alsa.c:122):
- * dm is [nch] rows of `len` floats, row c at dm + c*pitch_floats; len <= max_blocks*1024. */
+ * dm is [nch] rows of `len` floats, row c at dm + c*pitch_floats; len <= max_blocks*1024.
+ * *_dev: asynchronous like the iq entry points -- dm is consumed after what hip_stream holds so far, and
+ * later work on hip_stream (refilling dm in place) is ordered behind the demodulator that reads it. */
 int  acg_process_dm_dev(acg_ctx *ctx, const float *dm_dev, size_t pitch_floats, int len,
 			void *hip_stream);
 int  acg_process_dm_host(acg_ctx *ctx, const float *dm_host, size_t pitch_floats, int len);
@@ -186,6 +188,11 @@ int  acg_set_timing(acg_ctx *ctx, int mode);
  * uniform bytes */
 int  acg_fill_random_u8_dev(uint8_t *dev, size_t pitch_bytes, int nrows, size_t row_bytes,
 			    uint64_t seed, void *hip_stream);
+
+/* measurement aid: a pure streaming reader (non-temporal 16-byte loads, nothing else) over `bytes` of
+ * device memory, `repeats` back-to-back launches timed with HIP events on the default stream: the read
+ * bandwidth this GPU delivers to a kernel that only reads.  Synchronises. */
+int  acg_probe_read_dev(const void *dev, size_t bytes, int repeats, double *gb_per_s);
 
 /* device-side AM up-converter: row r = scale*env[env_index[r]][n/decim] *
  * exp(j(2*pi*off_hz[r]*n/(12500*decim) + phase[r])) + N(0, noise_sigma^2), quantised like an RTL

@@ -139,8 +139,12 @@ def test_fir_shared_stream_kernel_ragged_groups(D, O, M, monkeypatch):
 
     shared, shared2 = run()
     monkeypatch.setenv("ACG_FIR_SHARED", "0")
+    monkeypatch.setenv("ACG_FIR_VARIANT", "3")          # the workgroup-granular kernel shares the tap split and reduction order
     plain, plain2 = run()
     assert np.array_equal(shared, plain) and np.array_equal(shared2, plain2)
+    monkeypatch.delenv("ACG_FIR_VARIANT")               # the default (wave-private) kernel: same sums in another order
+    direct, direct2 = run()
+    assert np.all(np.abs(direct - shared) <= 1e-5 * np.abs(shared) + 1e-6) and np.all(np.abs(direct2 - shared2) <= 1e-5 * np.abs(shared2) + 1e-6)
     for c in range(nch):
         want = O.fir_u8(iq[smap[c]], M, taps[c], nout=nout)
         assert np.all(np.abs(shared[c] - want) <= 1e-5 * np.abs(want) + 1e-6), c
@@ -173,16 +177,52 @@ print("OK", worst)
 '''
 
 
-@pytest.mark.parametrize("variant,M", [("0", 200), ("1", 200), ("2", 160), ("4", 200), ("3", 192)])
+@pytest.mark.parametrize("variant,M", [("0", 200), ("1", 200), ("2", 160), ("4", 200), ("3", 192), ("3", 200), ("5", 200), ("5", 160), ("5", 192)])
 def test_fir_kernel_variants_all_match_oracle(variant, M):
     """the down-converter's alternative kernels stay selectable (ACG_FIR_VARIANT: 0 one workgroup per
-    segment, 1/2 static persistent partition without/with non-temporal loads, 3 the default dynamic
-    dispenser, 4 LDS-DMA double buffering): each one against the oracle, in a fresh process (the knob is
-    read once)."""
+    segment, 1/2 static persistent partition without/with non-temporal loads, 3 the workgroup-granular dynamic
+    dispenser, 4 LDS-DMA double buffering, 5 the default wave-private streaming kernel): each one against the
+    oracle, in a fresh process."""
     env = dict(os.environ, ACG_FIR_VARIANT=variant)
     r = subprocess.run([sys.executable, "-c", FIR_VARIANT_CHILD % dict(root=ROOT), str(M)], capture_output=True, text=True,
                        timeout=600, env=env)
     assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("OK"), (r.stdout[-500:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("M,ntaps", [(200, 200), (200, 192), (160, 160), (192, 192)])
+def test_fir_direct_kernel_many_runs_scrambled_streams(D, O, M, ntaps):
+    """the wave-private streaming kernel where its run dispenser matters: far more runs than resident waves (every
+    wave goes through many tickets, shards run dry and waves move on to the next shard), a channel -> stream map that
+    is a permutation (row lookup instead of the identity shortcut), fewer taps than the window (zero columns), and
+    three launches in a row on the same dispenser (it re-arms itself).  Every channel against the oracle."""
+    rng = np.random.default_rng(4242 + M + ntaps)
+    nch, nblk = 300, 8
+    nout = nblk * 1024
+    iq = torch_randint_u8((nch, nout * M * 2), seed=M)
+    host = iq.cpu().numpy()
+    win = np.ones(ntaps) if ntaps == M else np.hamming(ntaps) / np.hamming(ntaps).mean() * (M / ntaps)
+    taps = np.stack([(O.rtl_taps(131000000 + 25000 * int(rng.integers(-40, 41)), 131000000, M)[:ntaps] * win[:, None]).astype(np.float32)
+                     for c in range(nch)])
+    perm = rng.permutation(nch)
+    dec = D.Decoder(nch, decim=M, ntaps=ntaps, max_blocks=nblk, bitlog=False)
+    dec.set_taps(taps)
+    want = [None] * nch
+    for rnd, smap in enumerate((np.arange(nch), perm, perm)):
+        dec.set_channel_streams(smap)
+        dec.fir_only(iq, nblk, iq.stride(0))
+        for c in range(nch):
+            if rnd < 2:
+                want[c] = O.fir_u8(host[smap[c]], M, taps[c], nout=nout, ntaps=ntaps)
+            got = dec.dm(c, nout)
+            assert np.all(np.abs(got - want[c]) <= 1e-5 * np.abs(want[c]) + 1e-6), (rnd, c)
+    dec.close()
+
+
+def torch_randint_u8(shape, seed):
+    import torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    return torch.randint(0, 256, shape, dtype=torch.uint8, device="cuda", generator=g)
 
 
 # ------------------------------------------------------------------------------------ error behaviour of the ABI
@@ -220,6 +260,37 @@ def test_abi_rejects_misuse_loudly(D):
     fr = (K.Frame * 1)()
     n = C.c_int(0)
     assert L.acg_drain_frames(None, fr, 1, C.byref(n)) == K.EINVAL
+
+
+def test_process_dm_dev_input_may_be_refilled_in_place(D, O):
+    """acg_process_dm_dev is asynchronous like the iq entry points: the caller may overwrite dm_dev with the next
+    chunk on the same stream right after the call -- the demodulator that reads it runs on another stream and the
+    refill must be ordered behind it.  16 chunks through ONE device buffer, blocks vs the oracle."""
+    import torch
+    from acarsdec_amd import _capi as K, synth as S
+    L = K.load()
+    nch, chunk, nchunk = 64, 4096, 16
+    rng = np.random.default_rng(31)
+    audio = np.stack([S.envelope(S.channel_audio(np.random.default_rng(500 + c), chunk * nchunk, gap=(1500, 4000), text_len=(10, 60))[0],
+                                 noise=0.01, rng=rng) for c in range(nch)]).astype(np.float32)
+    src = torch.from_numpy(audio).cuda()
+    buf = torch.empty((nch, chunk), dtype=torch.float32, device="cuda")
+    dec = D.Decoder(nch, decim=8, ntaps=8, max_blocks=chunk // 1024, bitlog=False)
+    st = torch.cuda.Stream()
+    got = []
+    with torch.cuda.stream(st):
+        for k in range(nchunk):
+            buf.copy_(src[:, k * chunk:(k + 1) * chunk])                  # refill in place, same stream
+            assert L.acg_process_dm_dev(dec.ctx, buf.data_ptr(), chunk, chunk, st.cuda_stream) == 0
+            buf.mul_(0.0)                                                 # and scribble over it right away
+    got = sorted(D.frame_tuple(f) for f in dec.drain_frames(8192))
+    want = []
+    for c in range(nch):
+        ch = O.Channel(c)
+        ch.demod(audio[c])
+        want += [O.frame_tuple(f) for f in ch.frames]
+    assert got == sorted(want) and len(got) >= nch
+    dec.close()
 
 
 # ------------------------------------------------------------------------------------ MSK stage on test.wav

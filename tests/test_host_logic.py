@@ -118,3 +118,53 @@ def test_build_recipe_keeps_the_exactness_critical_flags():
     allowed = {"-amdgpu-sched-strategy=max-ilp", "-disable-machine-sink", "-disable-branch-fold", "-disable-tail-duplicate",
                "-structurizecfg-skip-uniform-regions", "-phi-node-folding-threshold=4"}
     assert set(re.findall(r'"-mllvm", "([^"]+)"', unit)) <= allowed
+
+
+def _regs_of(line):
+    """VGPR numbers a line of gfx950 assembly mentions (v7, v[8:11])."""
+    regs = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", line):
+        regs.update(range(int(a), int(b) + 1))
+    regs.update(int(x) for x in re.findall(r"\bv(\d+)\b", line))
+    return regs
+
+
+def test_async_ticket_register_is_left_alone_until_its_wait():
+    """The down-converter's run dispenser issues `global_atomic_add vN, ...` from inline asm and looks at vN a
+    tile later, after an asm `s_waitcnt vmcnt(k)` (fir.hip ticket_request / ticket_take, request_ticket /
+    take_ticket).  The compiler does not know the register is still in flight in between: a copy, a spill or a
+    reuse of vN there would read or destroy garbage.  Disassemble the kernels as they are built and
+    check that, in every kernel, nothing but those two asm statements touches vN between them."""
+    import shutil
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else shutil.which("hipcc")
+    if not hipcc:
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "acarsdec_amd", "csrc")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "--cuda-device-only", "-std=c++17", "-O3", "-I" + csrc,
+                        "-I" + os.path.join(ROOT, "include"), "-S", "-o", "-", os.path.join(csrc, "fir.hip")],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.splitlines()
+    checked = 0
+    i = 0
+    while i < len(lines):
+        m = re.search(r"^\s*global_atomic_add v(\d+), v\[?[\d:]+\]?, v\d+, off sc0", lines[i])
+        if not (m and "ASMSTART" in lines[i - 1]):
+            i += 1
+            continue
+        reg = int(m.group(1))
+        j = i + 1
+        while j < len(lines):                          # forward to the asm wait that names the register's reader
+            if "ASMSTART" in lines[j] and re.search(r"^\s*s_waitcnt vmcnt\(\d+\)", lines[j + 1]):
+                break
+            assert ".end_amdhsa_kernel" not in lines[j] and "s_endpgm" not in lines[j], "ticket never waited for (line %d)" % i
+            if not lines[j].lstrip().startswith((";", ".")) and "ASM" not in lines[j]:
+                assert reg not in _regs_of(lines[j]), "v%d touched while the ticket is in flight: %s" % (reg, lines[j])
+            j += 1
+        # the first instruction after the wait reads it (readfirstlane / LDS publish), nothing in between may
+        use = [l for l in lines[j + 2:j + 40] if reg in _regs_of(l)]
+        assert use, "ticket v%d is never read after its wait" % reg
+        checked += 1
+        i = j + 1
+    assert checked >= 6, checked       # direct kernel x3 rates, persist x2, shared x2, dma

@@ -52,8 +52,9 @@ def _worker(rank, world, port, nch, q):
             blocks.append((li, int(f.len), bytes(f.txt[: f.len]), int(f.end_bit)))
     merged = shard.gather_blocks(blocks, own, world, rank, dist)
     t, c = shard.reduce_timing(0.5 + rank, len(blocks), world, dist)
+    per = shard.gather_scalars(0.5 + rank, world, dist)
     if rank == 0:
-        q.put((merged, t, c))
+        q.put((merged, t, c, per))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -66,7 +67,7 @@ def test_world2_gloo_shard_scatter_gather():
     procs = [ctx.Process(target=_worker, args=(r, world, port, nch, q)) for r in range(world)]
     for p in procs:
         p.start()
-    merged, t, c = q.get(timeout=240)
+    merged, t, c, per = q.get(timeout=240)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -82,3 +83,26 @@ def test_world2_gloo_shard_scatter_gather():
         want += [(g, int(f.len), bytes(f.txt[: f.len]), int(f.end_bit)) for f in ch.frames]
     assert merged == sorted(want, key=lambda b: (b[0], b[-1])) and len(merged) >= nch - 1
     assert t == 1.5 and c == len(merged)          # max over ranks, sum over ranks
+    assert per == [0.5, 1.5]                      # every rank's own time, in rank order
+
+
+def test_bench_gpus_flag_launches_ranks_itself():
+    """`python bench.py --gpus 2` (no torchrun, no WORLD_SIZE) must start 2 ranks by itself -- the driver invokes
+    exactly that.  Without a GPU the launcher refuses loudly (no silent single-rank run); with the gloo
+    rehearsal backend it starts torch.distributed.run, whose ranks then stop at "needs a GPU"."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    if torch.cuda.is_available():
+        pytest.skip("CPU-side check of the launcher")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-cpu-baseline"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode != 0 and "only 0 GPU(s) visible" in r.stderr, r.stderr[-800:]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-cpu-baseline"], capture_output=True, text=True,
+                       env=dict(env, ACG_BENCH_BACKEND="gloo"), timeout=600)
+    assert r.returncode != 0 and r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-1500:]     # both ranks got that far
+    # a rank count that contradicts the flag is an error, not a silent override
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"], capture_output=True, text=True,
+                       env=dict(env, WORLD_SIZE="2", RANK="0"), timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
