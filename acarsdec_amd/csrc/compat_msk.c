@@ -101,6 +101,18 @@ static void bit_sink(void *user, int slot, float vo, float lvl)
 		decodeAcars(ch);
 }
 
+/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
+ * instead, so the device's copies are dropped to keep its queue empty.  ACG_EOVERFLOW only says that more blocks
+ * were waiting than the scratch holds (the rest is dropped by the same call); anything else is an error. */
+static void discard_device_blocks(acg_ctx *g)
+{
+	acg_frame f[8];
+	int n = 0;
+	const int rc = acg_drain_frames(g, f, 8, &n);
+	if (rc != ACG_OK && rc != ACG_EOVERFLOW)
+		die("drain_frames", g, rc);
+}
+
 void demodMSK(channel_t *ch, int len)
 {
 	int rc;
@@ -129,10 +141,7 @@ void demodMSK(channel_t *ch, int len)
 	if ((rc = acg_replay_bits(g_msk, bit_sink, one)) != ACG_OK)
 		die("replay", g_msk, rc);
 	download(g_msk, 0, ch);
-	{       /* blocks also assembled on the device: not needed here, keep the queue empty */
-		acg_frame f[8]; int n;
-		acg_drain_frames(g_msk, f, 8, &n);
-	}
+	discard_device_blocks(g_msk);
 }
 
 #ifdef WITH_RTL
@@ -177,9 +186,6 @@ void acarsdec_amd_in_callback(unsigned char *rtlinbuff, uint32_t nread, void *ct
 		die("replay", g_rtl, rc);
 	for (n = 0; n < nbch; n++)
 		download(g_rtl, (int)n, &channel[n]);
-	{
-		acg_frame f[64]; int nf;
-		acg_drain_frames(g_rtl, f, 64, &nf);
-	}
+	discard_device_blocks(g_rtl);
 }
 #endif

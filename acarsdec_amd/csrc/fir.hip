@@ -717,8 +717,7 @@ __device__ __forceinline__ unsigned int ticket_take(unsigned int& ticket)
 // is issued -- inside the run through `cur` (compile-time scalar offsets), beyond it through `nxt`
 template <int CPR, int TILE>
 __device__ __forceinline__ void fird_tile(u4v_t (&st)[FirD<CPR>::U], __amdgpu_buffer_rsrc_t cur, __amdgpu_buffer_rsrc_t nxt,
-                                          unsigned int voff, const float4* __restrict__ Tl, f2* __restrict__ Pw,
-                                          const f2* __restrict__ Pr, float* __restrict__ dm_out, int lane)
+                                          unsigned int voff, const float4* Tl, f2* Pw, const f2* Pr, float* __restrict__ dm_out, int lane)
 {
     typedef FirD<CPR> F;
 #pragma unroll
@@ -786,12 +785,15 @@ __device__ __forceinline__ void fird_body(const FirArgs& a, const uint8_t* __res
     const unsigned int voff = (unsigned int)lane << 4;
     const int nck = a.ntaps_pad >> 3;                                               // tap columns that carry taps
 
-    auto shard_lo = [&](unsigned int s) { return (unsigned int)((unsigned long long)nrun * s / ACG_DISP_SHARDS); };
-    // static first runs: wave wg takes run (wg / SHARDS) of shard (wg % SHARDS); tickets count on from there
+    // Shard s hands out runs s, s + SHARDS, s + 2 SHARDS, ...: the shards advance together, so the whole grid reads
+    // ONE front that moves through the input in address order (HBM likes that better than eight distant fronts),
+    // while the ticket atomics are spread over eight L2 channels.  The first run of wave wg is run wg (static);
+    // tickets count on from there.
+    auto shard_runs = [&](unsigned int s) { return (nrun + ACG_DISP_SHARDS - 1 - s) / ACG_DISP_SHARDS; };
     auto shard_static = [&](unsigned int s) { return (nwaves + ACG_DISP_SHARDS - 1 - s) / ACG_DISP_SHARDS; };
     auto run_of_ticket = [&](unsigned int s, unsigned int t) -> unsigned int {
-        const unsigned long long idx = (unsigned long long)shard_lo(s) + shard_static(s) + t;
-        return idx < shard_lo(s + 1) ? (unsigned int)idx : NONE;
+        const unsigned long long k = (unsigned long long)shard_static(s) + t;
+        return k < shard_runs(s) ? (unsigned int)k * ACG_DISP_SHARDS + s : NONE;
     };
     auto probe = [&](unsigned int& s) -> unsigned int {             // synchronous: next run of shard s, else of the following shards
         for (int k = 0; k < ACG_DISP_SHARDS; ++k) {
@@ -840,14 +842,10 @@ __device__ __forceinline__ void fird_body(const FirArgs& a, const uint8_t* __res
     };
 
     unsigned int s = wg % ACG_DISP_SHARDS;
-    unsigned int run;
-    {
-        const unsigned long long idx = (unsigned long long)shard_lo(s) + wg / ACG_DISP_SHARDS;
-        run = idx < shard_lo(s + 1) ? (unsigned int)idx : NONE;
-        if (run == NONE) {                                          // tiny launches: fewer runs than waves in this shard
-            s = (s + 1 == ACG_DISP_SHARDS) ? 0 : s + 1;
-            run = probe(s);
-        }
+    unsigned int run = wg < nrun ? wg : NONE;
+    if (run == NONE) {                                              // tiny launches: fewer runs than waves
+        s = (s + 1 == ACG_DISP_SHARDS) ? 0 : s + 1;
+        run = probe(s);
     }
     if (run == NONE) { sign_off(); return; }
 

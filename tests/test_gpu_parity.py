@@ -336,9 +336,26 @@ def test_testwav_blocks_bits_state(D, testwav, golden, golden_bits, chunk):
         assert st[c]["MskS"] == g["MskS"] and st[c]["idx"] == g["idx"]
         assert st[c]["nbits"] == g["nbits"] and st[c]["Acarsstate"] == g["Acarsstate"]
         assert st[c]["outbits"] == g["outbits"] and st[c]["MskBitCount"] == g["MskBitCount"]
-        assert abs(st[c]["MskDf"] - fhex(g["MskDf"])) < 1e-6
-        assert abs(st[c]["MskClk"] - fhex(g["MskClk"])) < 1e-3
-        assert abs(st[c]["MskPhi"] - fhex(g["MskPhi"])) < 1e-3
+        assert_state_close(st[c], dict(MskDf=fhex(g["MskDf"]), MskClk=fhex(g["MskClk"]), MskPhi=fhex(g["MskPhi"])), "golden test.wav ch %d" % c)
+
+
+def assert_state_close(got, want, what):
+    """The loop's continuous state against the reference's.  The device differs from glibc only in the last bit of
+    the mixer's f64 sin/cos (< 1 ulp, and only the float-rounded product is kept, msk.c:90): a product moves by one
+    f32 ulp about once in 2^29 samples, which the PLL (a contraction, msk.c:130) forgets within a few bits.  So the
+    state agrees far below the soft-symbol tolerance: MskDf 1e-6, MskClk (f32, up to 3*pi/2: ulp 4.8e-7) and
+    MskPhi (mod 2*pi) 1e-5.  The largest deviation seen is appended to gpurun_out/state_deviation.txt."""
+    ddf = abs(got["MskDf"] - want["MskDf"])
+    dclk = abs(got["MskClk"] - want["MskClk"])
+    dphi = abs(got["MskPhi"] - want["MskPhi"])
+    dphi = min(dphi, abs(dphi - 2 * np.pi))
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "state_deviation.txt"), "a") as f:
+            f.write("%s dDf=%.3e dClk=%.3e dPhi=%.3e\n" % (what, ddf, dclk, dphi))
+    except OSError:
+        pass
+    assert ddf < 1e-6 and dclk < 1e-5 and dphi < 1e-5, (what, ddf, dclk, dphi)
 
 
 def test_msk_matches_oracle_noise_and_silence(D, O):
@@ -523,7 +540,7 @@ def test_msk_lane_layouts_are_bit_identical(D, O, S, lpc, monkeypatch):
         s, o = dec.state(c), ch.state()
         for k in ("MskS", "idx", "nbits", "Acarsstate", "outbits", "MskBitCount"):
             assert s[k] == o[k], (lpc, c, k)
-        assert abs(s["MskDf"] - o["MskDf"]) < 1e-6 and abs(s["MskPhi"] - o["MskPhi"]) < 1e-3
+        assert_state_close(s, o, "lane layout %s ch %d" % (lpc, c))
     dec.close()
 
 
