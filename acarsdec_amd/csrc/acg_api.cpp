@@ -1156,7 +1156,7 @@ extern "C" int acg_msk_lanes_per_channel(const acg_ctx* ctx) { return ctx ? ctx-
 
 extern "C" int acg_probe_read_dev(const void* dev, size_t bytes, int repeats, double* gb_per_s)
 {
-    if (!dev || bytes < 16 || ((uintptr_t)dev & 15) || repeats < 1 || !gb_per_s) return ACG_EINVAL;
+    if (!dev || bytes < 51200 || ((uintptr_t)dev & 15) || repeats < 1 || !gb_per_s) return ACG_EINVAL;
     unsigned int* sink = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     int ncu = 256, devid = 0;
@@ -1171,7 +1171,7 @@ extern "C" int acg_probe_read_dev(const void* dev, size_t bytes, int repeats, do
         ok = ok && hipEventRecord(e1, nullptr) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
              hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
         if (ok && ms > 0.f) {
-            *gb_per_s = (double)(bytes & ~(size_t)15) * repeats / (ms * 1e-3) / 1e9;
+            *gb_per_s = (double)(bytes / 51200 * 51200) * repeats / (ms * 1e-3) / 1e9;      // whole 50 KiB runs are read
             rc = ACG_OK;
         }
     }

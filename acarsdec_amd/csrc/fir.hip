@@ -668,15 +668,19 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_dma_kernel(const FirArgs a,
 // adds M terms sequentially; its own -Ofast build reassociates, SURVEY 8c: dm within 1e-5 relative).
 #define FIRD_R 2
 
-template <int CPR>
+template <int CPR, int U_ = 0, int B_ = 0>
 struct FirD {
-    static constexpr int U = (CPR % 5 == 0) ? 5 : (CPR % 6 == 0) ? 6 : 4;      // wave-loads in flight; divides CPR
+    // U staging slots per lane: run position p lives in slot p % U, so U divides the loads of a run.  Loads are
+    // issued in bursts of B consecutive wave-loads (B KiB contiguous per wave) every B steps, as the slots of the
+    // B positions consumed since the last burst are free again: between U - B and U KiB per wave are in flight.
+    static constexpr int U = U_ ? U_ : ((FIRD_R * CPR) % 10 == 0) ? 10 : 12;
+    static constexpr int B = B_ ? B_ : U / 2;
     static constexpr int TS = CPR + 63;                                        // tap columns incl. replicas
     static constexpr int PW = (CPR & 1) ? CPR : CPR + 1;                       // partial-sum row stride (odd)
     static constexpr int TAB_BYTES = 4 * TS * 16;
     static constexpr int P_BYTES = 64 * PW * 8;
     static constexpr int WAVE_LDS = TAB_BYTES + P_BYTES;
-    static_assert(CPR % U == 0, "prefetch depth must divide the loads per tile");
+    static_assert((FIRD_R * CPR) % U == 0 && (FIRD_R * CPR) % B == 0 && B <= U, "slots and bursts must divide the loads per run");
 };
 
 typedef unsigned int u4v_t __attribute__((ext_vector_type(4)));
@@ -713,21 +717,36 @@ __device__ __forceinline__ unsigned int ticket_take(unsigned int& ticket)
     return (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
 }
 
-// one tile: CPR wave-loads; as the registers of a consumed load free up, the load U positions further on
-// is issued -- inside the run through `cur` (compile-time scalar offsets), beyond it through `nxt`
-template <int CPR, int TILE>
-__device__ __forceinline__ void fird_tile(u4v_t (&st)[FirD<CPR>::U], __amdgpu_buffer_rsrc_t cur, __amdgpu_buffer_rsrc_t nxt,
+// one tile: CPR steps.  A step is fenced off from its neighbours with scheduling barriers -- left alone, the scheduler
+// delays the loads to shorten live ranges (the pipeline then runs dry at the end of a tile) or bunches them up at
+// random, and the result changes with every edit.  Inside a step: first the memory instructions whose results are
+// needed LATER (every B-th step the burst of B wave-loads U - B positions ahead, the next step's taps from LDS), then
+// this step's arithmetic on data that arrived long ago.
+template <int CPR, int UU, int BB, int TILE>
+__device__ __forceinline__ void fird_tile(u4v_t* st /* [U] */, __amdgpu_buffer_rsrc_t cur, __amdgpu_buffer_rsrc_t nxt,
                                           unsigned int voff, const float4* Tl, f2* Pw, const f2* Pr, float* __restrict__ dm_out, int lane)
 {
-    typedef FirD<CPR> F;
+    typedef FirD<CPR, UU, BB> F;
+    float4 w0 = Tl[0 * F::TS], w1 = Tl[1 * F::TS], w2 = Tl[2 * F::TS], w3 = Tl[3 * F::TS];          // step 0: column of lane 0 is 0
 #pragma unroll
     for (int q = 0; q < CPR; ++q) {
-        const u4v_t d = st[q % F::U];
-        const int pos = TILE * CPR + q + F::U;               // position of the load issued now, in loads from the run's base
-        if (pos < FIRD_R * CPR) st[q % F::U] = fird_load(cur, voff, (unsigned int)pos * 1024u);
-        else st[q % F::U] = fird_load(nxt, voff, (unsigned int)(pos - FIRD_R * CPR) * 1024u);
-        const int c0 = (q * 64) % CPR;                       // column of lane 0 in this load (compile time)
-        const float4 w0 = Tl[0 * F::TS + c0], w1 = Tl[1 * F::TS + c0], w2 = Tl[2 * F::TS + c0], w3 = Tl[3 * F::TS + c0];
+        __builtin_amdgcn_sched_barrier(0);
+        const int p = TILE * CPR + q;                         // run position consumed by this step
+        const u4v_t d = st[p % F::U];
+        if (p % F::B == 0) {
+#pragma unroll
+            for (int b = 0; b < F::B; ++b) {
+                const int pos = p + F::U - F::B + b;          // slots of positions p - B .. p - 1 are free
+                if (pos < FIRD_R * CPR) st[pos % F::U] = fird_load(cur, voff, (unsigned int)pos * 1024u);
+                else st[pos % F::U] = fird_load(nxt, voff, (unsigned int)(pos - FIRD_R * CPR) * 1024u);
+            }
+        }
+        float4 n0 = w0, n1 = w1, n2 = w2, n3 = w3;
+        if (q + 1 < CPR) {
+            const int c1 = ((q + 1) * 64) % CPR;              // column of lane 0 in the next load (compile time)
+            n0 = Tl[0 * F::TS + c1]; n1 = Tl[1 * F::TS + c1]; n2 = Tl[2 * F::TS + c1]; n3 = Tl[3 * F::TS + c1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
         const float w[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
         f2 accA = {0.f, 0.f};       // (sum tr*wr, sum ti*wi)
         f2 accB = {0.f, 0.f};       // (sum tr*wi, sum ti*wr)
@@ -751,7 +770,9 @@ __device__ __forceinline__ void fird_tile(u4v_t (&st)[FirD<CPR>::U], __amdgpu_bu
             const unsigned int r = (i * ((65536u + CPR - 1) / CPR)) >> 16;   // i / CPR for i < 64 * CPR <= 2048
             Pw[q * 64 + (int)r] = part;                                // + one pad entry per completed row
         }
+        w0 = n0; w1 = n1; w2 = n2; w3 = n3;
     }
+    __builtin_amdgcn_sched_barrier(0);
     // lane = window: add the CPR partial sums of the row, |D| (rtl.c:353), 64 consecutive floats
     f2 D = {0.f, 0.f};
 #pragma unroll
@@ -759,11 +780,11 @@ __device__ __forceinline__ void fird_tile(u4v_t (&st)[FirD<CPR>::U], __amdgpu_bu
     dm_out[lane] = cabs_like_glibc(D.x, D.y);
 }
 
-template <int CPR>
+template <int CPR, int UU, int BB>
 __device__ __forceinline__ void fird_body(const FirArgs& a, const uint8_t* __restrict__ iq_base, const float* __restrict__ taps_base,
                                           const int* __restrict__ stream_of, float* __restrict__ dm_base)
 {
-    typedef FirD<CPR> F;
+    typedef FirD<CPR, UU, BB> F;
     constexpr unsigned int NONE = 0xffffffffu;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -859,9 +880,9 @@ __device__ __forceinline__ void fird_body(const FirArgs& a, const uint8_t* __res
     __amdgpu_buffer_rsrc_t cur = fird_rsrc(base, run_bytes);
     u4v_t st[F::U];
 #pragma unroll
-    for (int i = 0; i < F::U; ++i) {
+    for (int i = 0; i < F::U - F::B; ++i) {                         // step 0 issues the burst U - B .. U - 1 itself
         st[i] = fird_load(cur, voff, (unsigned int)i * 1024u);
-        asm volatile("" ::: "memory");                              // keep the loads in issue order (the waits count on it)
+        __builtin_amdgcn_sched_barrier(0);                          // keep the loads in issue order (the waits count on it)
     }
 
     for (;;) {
@@ -870,7 +891,7 @@ __device__ __forceinline__ void fird_body(const FirArgs& a, const uint8_t* __res
         if (lane == 0) ticket_request(ctr + s * ACG_DISP_STRIDE, tk);
         float* __restrict__ dm_out = dm_base + (size_t)ch * a.dm_pitch + (size_t)t0 * ACG_TILE_WIN;
         static_assert(FIRD_R == 2, "the run is unrolled by hand: first tile, last tile");
-        fird_tile<CPR, 0>(st, cur, cur, voff, Tl, Pw, Pr, dm_out, lane);
+        fird_tile<CPR, UU, BB, 0>(st, cur, cur, voff, Tl, Pw, Pr, dm_out, lane);
         // last tile of the run: where does the stream go next?  (U loads and a store are in flight, all younger than the ticket)
         unsigned int nrun_ = run_of_ticket(s, ticket_take<F::U + 1>(tk));   // + the dm store of the first tile
         if (nrun_ == NONE) {
@@ -884,7 +905,7 @@ __device__ __forceinline__ void fird_body(const FirArgs& a, const uint8_t* __res
         const __amdgpu_buffer_rsrc_t nxt = fird_rsrc(nbase, has_next ? run_bytes : 0u);
         float4 tp[4];
         fetch_taps(nch_, tp);
-        fird_tile<CPR, 1>(st, cur, nxt, voff, Tl, Pw, Pr, dm_out + ACG_TILE_WIN, lane);
+        fird_tile<CPR, UU, BB, 1>(st, cur, nxt, voff, Tl, Pw, Pr, dm_out + ACG_TILE_WIN, lane);
         if (!has_next) break;
         write_taps(tp);
         run = nrun_;
@@ -896,14 +917,14 @@ __device__ __forceinline__ void fird_body(const FirArgs& a, const uint8_t* __res
     sign_off();
 }
 
-template <int CPR>
+template <int CPR, int UU = 0, int BB = 0>
 __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_direct_kernel(const FirArgs a,
                                                                     const uint8_t* __restrict__ iq_base,
                                                                     const float* __restrict__ taps_base,
                                                                     const int* __restrict__ stream_of,
                                                                     float* __restrict__ dm_base)
 {
-    fird_body<CPR>(a, iq_base, taps_base, stream_of, dm_base);
+    fird_body<CPR, UU, BB>(a, iq_base, taps_base, stream_of, dm_base);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1114,6 +1135,10 @@ static int fir_device(FirDev** out)
             {(const void*)fir_u8_direct_kernel<20>, 4 * FirD<20>::WAVE_LDS},
             {(const void*)fir_u8_direct_kernel<24>, 4 * FirD<24>::WAVE_LDS},
             {(const void*)fir_u8_direct_kernel<25>, 4 * FirD<25>::WAVE_LDS},
+            {(const void*)fir_u8_direct_kernel<25, 10, 1>, 4 * FirD<25>::WAVE_LDS},
+            {(const void*)fir_u8_direct_kernel<25, 25, 5>, 4 * FirD<25>::WAVE_LDS},
+            {(const void*)fir_u8_direct_kernel<25, 25, 10>, 4 * FirD<25>::WAVE_LDS},
+            {(const void*)fir_u8_direct_kernel<25, 10, 10>, 4 * FirD<25>::WAVE_LDS},
         };
         for (const auto& at : attrs) {
             e = hipFuncSetAttribute(at.f, hipFuncAttributeMaxDynamicSharedMemorySize, at.bytes);
@@ -1190,7 +1215,7 @@ extern "C" size_t acg_fir_lds_bytes(const FirArgs* a)
 }
 
 // wave-private streaming kernel: whole tiles, runs inside one channel, a rate it is instantiated for
-template <int CPR>
+template <int CPR, int UU = 0, int BB = 0>
 static int launch_direct(const FirArgs* a, int num_cu, hipStream_t stream)
 {
     const size_t lds = (size_t)(ACG_WG_FIR / 64) * FirD<CPR>::WAVE_LDS;
@@ -1201,7 +1226,7 @@ static int launch_direct(const FirArgs* a, int num_cu, hipStream_t stream)
     long long grid = (long long)(a->ncu > 0 ? a->ncu : num_cu) * per_cu;
     const long long need = (nrun + ACG_WG_FIR / 64 - 1) / (ACG_WG_FIR / 64);
     if (grid > need) grid = need;
-    hipLaunchKernelGGL(fir_u8_direct_kernel<CPR>, dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds, stream, *a, a->iq, a->taps,
+    hipLaunchKernelGGL((fir_u8_direct_kernel<CPR, UU, BB>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds, stream, *a, a->iq, a->taps,
                        a->stream_of, a->dm);
     return (int)hipGetLastError();
 }
@@ -1216,12 +1241,17 @@ extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
     // segment; 1 / 2 static persistent partition without / with non-temporal loads; 3 workgroup-granular dynamic
     // dispenser; 4 LDS-DMA double buffering
     const int variant = env_int("ACG_FIR_VARIANT", 5);
-    if (variant == 5 && a->nwin > 0 && a->nwin % ACG_TILE_WIN == 0 && (a->nwin / ACG_TILE_WIN) % FIRD_R == 0 &&
+    if ((variant == 5 || (variant >= 50 && variant <= 53)) && a->nwin > 0 && a->nwin % ACG_TILE_WIN == 0 && (a->nwin / ACG_TILE_WIN) % FIRD_R == 0 &&
         (long long)a->nch * (a->nwin / ACG_TILE_WIN) < (1ll << 31) && a->ntaps_pad <= a->decim) {
         switch (a->cpr) {
         case 20: return launch_direct<20>(a, num_cu, (hipStream_t)stream);
         case 24: return launch_direct<24>(a, num_cu, (hipStream_t)stream);
-        case 25: return launch_direct<25>(a, num_cu, (hipStream_t)stream);
+        case 25:          // 50..53: measurement knobs (staging slots, burst length)
+            if (variant == 50) return launch_direct<25, 10, 1>(a, num_cu, (hipStream_t)stream);
+            if (variant == 51) return launch_direct<25, 25, 5>(a, num_cu, (hipStream_t)stream);
+            if (variant == 52) return launch_direct<25, 25, 10>(a, num_cu, (hipStream_t)stream);
+            if (variant == 53) return launch_direct<25, 10, 10>(a, num_cu, (hipStream_t)stream);
+            return launch_direct<25>(a, num_cu, (hipStream_t)stream);
         default: break;
         }
     }

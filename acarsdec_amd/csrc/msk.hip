@@ -194,7 +194,9 @@ __device__ __forceinline__ void sincos_2pi(double x, double* sn, double* cs)
 
 // msk.c:83 `if (p >= 2*M_PI) p -= 2*M_PI;` as compare + one select + one fma: fma(-1, 2pi, p) is p - 2pi
 // with its single rounding, fma(-0.0, 2pi, p) is p itself (p + -0.0), and -1.0 / -0.0 differ in the high
-// word only.  Same results, one instruction less than subtract + two-word select on the serial chain.
+// word only.  Same results, one instruction less than subtract + two-word select on the serial chain
+// (measured: the three-level form "difference beside compare, then a two-word select" is 4 % slower per bit --
+// the loop is bound by the number of instructions it issues, not by the depth of this chain).
 __device__ __forceinline__ double wrap_2pi(double p)
 {
     const double k = __hiloint2double(p >= K_TWOPI ? (int)0xBFF00000 : (int)0x80000000, 0);
@@ -392,7 +394,32 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
             fired = (double)cn >= thr;
             if (g == 0) myp[0] = pn;
         }
-        STAMP(1);                                                          // A
+        // ---- C0: everything of the matched filter that does not depend on this period's mixer outputs, issued before
+        // them so that its LDS round trips and the f64 divide run beside the sin/cos work (msk.c:100-107):
+        // the tap phase o needs only the clock (known since phase A), h[] is read-only, and with at most 6 new
+        // samples per period the five oldest ring entries inb[(j + idx) % 11], j = 0..4, are already there.
+        // The sum keeps the reference's order (oldest first): j = 0..4 here, j = 5..10 after the mixer.
+        unsigned int idx_n = idx + (unsigned int)cnt;
+        if (idx_n >= FLEN) idx_n -= FLEN;
+        const float clk_f = fired ? (float)((double)L.clk - K_3PI2) : L.clk;   // msk.c:100
+        int o = (int)(MFLTOVER * ((double)clk_f / s + 0.5));                    // msk.c:103
+        if (o > MFLTOVER) o = MFLTOVER;
+        if (o < 0) o = 0;          // memory safety only: the reference indexes h[] out of bounds here
+        float hv[FLEN];
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        f2v acc = {0.f, 0.f};
+        {
+            const float* hp = &hs[o];
+#pragma unroll
+            for (int j = 0; j < FLEN; ++j) hv[j] = hp[j * MFLTOVER];
+        }
+        float2 xo[5];
+        {
+            const float2* rp0 = &ring[idx_n][slot];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) xo[j] = rp0[j * CPW];
+        }
+        STAMP(1);                                                          // A + C0
         // ---- B: mixer for the cnt samples, spread over the group's lanes (msk.c:86-91)
 #pragma unroll
         for (int j = 0; j < SPL; ++j) {
@@ -409,8 +436,15 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
             }
         }
         n += cnt;
-        idx += (unsigned int)cnt;
-        if (idx >= FLEN) idx -= FLEN;
+        idx = idx_n;
+        // the five oldest taps (read before the mixer ran).  (re, im) ride in one packed register pair: v_pk_mul_f32
+        // then v_pk_add_f32 round exactly like the two scalar multiplies and adds of the reference (no fusion in this TU)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const f2v x = {xo[j].x, xo[j].y};
+            const f2v hh = {hv[j], hv[j]};
+            acc = acc + hh * x;
+        }
         // one wave per block: LDS operations of a wave execute in order, so the reads below see the
         // writes above; only the compiler has to be told not to move them
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -421,29 +455,19 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
 #ifdef ACG_MSK_STAMP
             ++stamp_bits;
 #endif
-            L.clk = (float)((double)L.clk - K_3PI2);                      // msk.c:100
-            // matched filter, msk.c:103-107: taps h[o + 12 j] against inb[(j + idx) % 11], oldest first
-            int o = (int)(MFLTOVER * ((double)L.clk / s + 0.5));
-            if (o > MFLTOVER) o = MFLTOVER;
-            if (o < 0) o = 0;      // memory safety only: the reference indexes h[] out of bounds here
-            const float2* rp = &ring[idx][slot];
-            const float* hp = &hs[o];
-            float2 xs[FLEN];
-            float hv[FLEN];
+            L.clk = clk_f;                                                 // msk.c:100
+            // matched filter, msk.c:103-107, second part: the taps whose samples the mixer just wrote
+            {
+                const float2* rp = &ring[idx][slot];
+                float2 xs[FLEN - 5];
 #pragma unroll
-            for (int j = 0; j < FLEN; ++j) {
-                xs[j] = rp[j * CPW];
-                hv[j] = hp[j * MFLTOVER];
-            }
-            // (re, im) ride in one packed register pair: v_pk_mul_f32 then v_pk_add_f32 round exactly
-            // like the two scalar multiplies and adds of the reference (no fusion in this TU)
-            typedef float f2v __attribute__((ext_vector_type(2)));
-            f2v acc = {0.f, 0.f};
+                for (int j = 5; j < FLEN; ++j) xs[j - 5] = rp[j * CPW];
 #pragma unroll
-            for (int j = 0; j < FLEN; ++j) {
-                const f2v x = {xs[j].x, xs[j].y};
-                const f2v hh = {hv[j], hv[j]};
-                acc = acc + hh * x;
+                for (int j = 5; j < FLEN; ++j) {
+                    const f2v x = {xs[j - 5].x, xs[j - 5].y};
+                    const f2v hh = {hv[j], hv[j]};
+                    acc = acc + hh * x;
+                }
             }
             float vr = acc.x, vi = acc.y;
 #ifdef ACG_MSK_STAMP
@@ -476,11 +500,22 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
             L.outbits = (L.outbits >> 1) & 0x7fu;
             if (sv > 0) L.outbits |= 0x80u;
             L.nbits--;
-            if (L.nbits <= 0) {
-                // hunting for sync (acars.c:252-265) is the common state: keep it off the big switch
+            {
+                // decodeAcars (acars.c:246-375) runs when nbits reaches 0.  Two cases cover nearly every call and are
+                // taken without a branch: hunting for sync with no SYN in sight (acars.c:252-265, every bit of an idle
+                // channel) and a plain text byte -- good parity, no terminator, room left (acars.c:303-341, every 8th
+                // bit of a channel inside a block).  Everything else (sync, SOH, parity errors, ETX/ETB/DLE, CRC
+                // bytes, resets: a few per block) goes through the full state machine.
+                const bool ev = L.nbits <= 0;
                 const unsigned int r = L.outbits & 0xffu;
-                if (L.astate == WSYN && r != SYN && r != (0xffu & ~SYN)) L.nbits = 1;
-                else decode_acars(L, a, ch, txt, samp0 + n - 1, leader);
+                const bool syn = (r == SYN) | (r == (0xffu & ~SYN));
+                const bool hunt = ev & (L.astate == WSYN) & !syn;
+                const bool term = (r == ETX) | (r == ETB) | (r == DLE);
+                const bool plain = ev & (L.astate == TXT) & ((__popc(r) & 1) != 0) & !term & (L.blen < 240);
+                if (plain & leader) txt[L.blen] = (unsigned char)r;
+                L.blen += plain ? 1 : 0;
+                L.nbits = hunt ? 1 : (plain ? 8 : L.nbits);
+                if (ev & !hunt & !plain) decode_acars(L, a, ch, txt, samp0 + n - 1, leader);
             }
             L.nbit_total++;
             L.S++;

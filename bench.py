@@ -244,21 +244,37 @@ def run_case(J, name, case, args, steps, warmup, headline):
             data_desc = "uniform random 12-bit int16 samples (format throughput run; blocks of this format are covered by tests/)"
     torch.cuda.synchronize()
 
-    dec = D.Decoder(nch, decim=M, ntaps=ntaps, nstreams=nstreams, max_blocks=nblk, device=J.local, bitlog=True, timing=True)
+    # The batch is streamed through the library in calls of `cb` callbacks (the reference hands over ONE callback at a
+    # time, rtl.c:314; 8 keeps the 12.5 kHz intermediate of a call inside the Infinity Cache at 1024 channels).
+    cb = min(args.call_blocks, nblk)
+    while nblk % cb:
+        cb -= 1
+    ncall = nblk // cb
+    if fmt == K.FMT_S16_SPLIT:
+        cb, ncall = nblk, 1                                # (plane layout: one call)
+    dec = D.Decoder(nch, decim=M, ntaps=ntaps, nstreams=nstreams, max_blocks=cb, device=J.local, bitlog=True, timing=True)
     dec.set_taps(taps)
     if share > 1:
         dec.set_channel_streams(np.arange(nch) // share)
     stream = torch.cuda.current_stream().cuda_stream
-    maxfr = max(8192, int(nch * (nblk / 3.0 + 2)))
+    maxfr = max(8192, int(nch * (cb / 3.0 + 2)))
+    cb_bytes = cb * 1024 * M * bps
 
-    def step(lag=1):
-        """one pass of the hot path; decoded blocks are delivered to the host one call behind
+    def step(lag=1, sink=None):
+        """one pass of the hot path over the batch; decoded blocks are delivered to the host one call behind
         (streaming double buffering: the newest call keeps the GPU busy while the host collects)"""
-        if fmt == 0:
-            dec.in_callback(iq, nblocks=nblk, pitch=row, stream=stream)
-        else:
-            dec.process_samples(fmt, iq, nblk, pitch=row, plane=row // 2 if fmt == K.FMT_S16_SPLIT else 0, stream=stream)
-        return dec.collect_frames_raw(lag, maxfr)
+        n = 0
+        for k in range(ncall):
+            part = iq[:, k * cb_bytes:(k + 1) * cb_bytes]
+            if fmt == 0:
+                dec.in_callback(part, nblocks=cb, pitch=row, stream=stream)
+            else:
+                dec.process_samples(fmt, part, cb, pitch=row, plane=row // 2 if fmt == K.FMT_S16_SPLIT else 0, stream=stream)
+            m, fb = dec.collect_frames_raw(lag, maxfr)
+            if sink is not None:
+                sink += [K.Frame.from_buffer_copy(fb[i]) for i in range(m)]
+            n += m
+        return n
 
     def barrier():
         torch.cuda.synchronize()
@@ -269,13 +285,14 @@ def run_case(J, name, case, args, steps, warmup, headline):
     # ---- correctness gate on the first pass (state starts from reset): a subset of this rank's channels goes
     # through the CPU oracle on the very bytes the GPU consumed.  Blocks bit-exact; where the content carries no
     # frames (random bytes, other sample formats) the 12.5 kHz magnitudes are compared instead (1e-5).
-    n_first, fbuf = step(lag=0)
-    first = [K.Frame.from_buffer_copy(fbuf[i]) for i in range(n_first)]
+    first = []
+    step(lag=0, sink=first)
     parity = None
     if rank == 0:
         from oracle import oracle as O
         ncheck = min(args.check_channels, nch)
-        nb_dm = min(nblk, 4)                                    # callbacks of dm compared per checked channel
+        nb_dm = min(cb, 4)                                      # callbacks of dm compared per checked channel (of the last call)
+        dm0 = (nblk - cb) * 1024                                # where the last call's dm starts in the batch
         got = {}
         for f in first:
             got.setdefault(int(f.chn), []).append(D.frame_tuple(f))
@@ -298,8 +315,9 @@ def run_case(J, name, case, args, steps, warmup, headline):
             nblocks += len(want)
             ok &= got.get(c, []) == want
             g = dec.dm(c, nb_dm * 1024)
-            e = np.abs(g - dm[: nb_dm * 1024])
-            dm_ok &= bool(np.all(e <= 1e-5 * np.abs(dm[: nb_dm * 1024]) + 1e-6))
+            w = dm[dm0: dm0 + nb_dm * 1024]
+            e = np.abs(g - w)
+            dm_ok &= bool(np.all(e <= 1e-5 * np.abs(w) + 1e-6))
             dm_err = max(dm_err, float(e.max()))
         parity = dict(channels_checked=ncheck, blocks=nblocks, bit_exact=bool(ok), dm_within_1e5_rel=bool(dm_ok),
                       dm_max_abs_err=dm_err, dm_samples_per_channel=nb_dm * 1024,
@@ -317,7 +335,7 @@ def run_case(J, name, case, args, steps, warmup, headline):
     t0 = time.perf_counter()
     nfr = 0
     for _ in range(steps):
-        nfr += step()[0]
+        nfr += step()
     nfr += dec.drain_frames_raw(maxfr)[0]      # the last call's blocks: all K steps fully delivered inside the timed region
     barrier()
     dt_local = time.perf_counter() - t0
@@ -358,9 +376,11 @@ def run_case(J, name, case, args, steps, warmup, headline):
         "timed_region_s": round(dt, 4),
         "data": "synthetic: " + data_desc,
         "config": {"workload": "%s: %d channels/GPU x %.1f Msps %s input, one stream per channel, rtlMult=%d, ntaps=%d, %d callbacks "
-                               "(%.3f s of signal) per step; FIR decimate + MSK demod + framing, blocks delivered to the host (one call behind)"
+                               "(%.3f s of signal) per step, streamed through the library in calls of %d callbacks; FIR decimate + MSK demod + "
+                               "framing, blocks delivered to the host (one call behind)"
                                % (case["tag"], nch, 12500 * M / 1e6, {"u8": "u8 IQ", "cs16": "CS16 IQ", "split16": "split int16 I/Q", "f32": "real f32"}[fmt_name],
-                                  M, ntaps, nblk, nblk * 0.08192),
+                                  M, ntaps, nblk, nblk * 0.08192, cb),
+                   "callbacks_per_call": cb,
                    "case": name, "input_format": fmt_name, "channels_per_gpu": nch, "decim": M, "ntaps": ntaps, "blocks_per_step": nblk,
                    "input_bytes_per_gpu": int(nstreams * row),
                    "realtime_channels_equiv": int(value / (12500 * M / 1e6)),
@@ -411,6 +431,7 @@ def main():
     ap.add_argument("--decim", type=int, default=None, help="rtlMult: 200 = 2.5 Msps")
     ap.add_argument("--ntaps", type=int, default=None)
     ap.add_argument("--blocks", type=int, default=None, help="1024-output callbacks per channel per step")
+    ap.add_argument("--call-blocks", type=int, default=8, help="callbacks handed to the library per call (a step streams its batch in calls)")
     ap.add_argument("--check-channels", type=int, default=64, help="channels of rank 0 verified against the oracle (SURVEY 8d: 64)")
     ap.add_argument("--format", choices=["u8", "cs16", "split16", "f32"], default="u8",
                     help="input sample format: u8 = rtl.c (headline); cs16 = soapy.c, split16 = sdrplay.c, f32 = air.c (SURVEY 8f.2)")
