@@ -74,6 +74,7 @@ SYMBOLS = {
     "acg_synth_iq_u8_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_uint64, C.c_void_p]),
     "acg_probe_read_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
+    "acg_selftest_div2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "acg_selftest_sincos": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
 }
 

@@ -1133,6 +1133,23 @@ extern "C" int acg_selftest_sincos(const double* x_host, double* sin_host, doubl
     return rc;
 }
 
+extern "C" int acg_selftest_div2(const double* n0_host, const double* n1_host, const double* d_host, double* out_host, int n)
+{
+    if (!n0_host || !n1_host || !d_host || !out_host || n < 1) return ACG_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return ACG_ENODEV;
+    double *a = nullptr, *b = nullptr, *d = nullptr, *o = nullptr;
+    const size_t by = (size_t)n * sizeof(double);
+    int rc = ACG_EHIP;
+    if (hipMalloc(&a, by) == hipSuccess && hipMalloc(&b, by) == hipSuccess && hipMalloc(&d, by) == hipSuccess &&
+        hipMalloc(&o, 4 * by) == hipSuccess && hipMemcpy(a, n0_host, by, hipMemcpyHostToDevice) == hipSuccess &&
+        hipMemcpy(b, n1_host, by, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(d, d_host, by, hipMemcpyHostToDevice) == hipSuccess &&
+        acg_launch_div2_selftest(a, b, d, o, n, nullptr) == 0 && hipMemcpy(out_host, o, 4 * by, hipMemcpyDeviceToHost) == hipSuccess)
+        rc = ACG_OK;
+    hipFree(a); hipFree(b); hipFree(d); hipFree(o);
+    return rc;
+}
+
 extern "C" int acg_fill_random_u8_dev(uint8_t* dev, size_t pitch_bytes, int nrows, size_t row_bytes,
                                       uint64_t seed, void* hip_stream)
 {

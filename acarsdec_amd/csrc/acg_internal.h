@@ -118,6 +118,7 @@ int acg_launch_msk(const MskArgs* a, int lanes_per_channel, void* stream);
 int acg_launch_blk_repair(AcgFrameRec* frames, unsigned int cap, const unsigned int* count, unsigned int* done_upto,
                           const unsigned short* synd, const unsigned short* crctab, void* stream);
 int acg_launch_sincos_selftest(const double* x, double* s, double* c, int n, void* stream);
+int acg_launch_div2_selftest(const double* n0, const double* n1, const double* d, double* out, int n, void* stream);
 int acg_launch_synth_iq(uint8_t* iq, size_t pitch, int nrows, int nout, int decim, const float* env,
                         size_t env_pitch, const int* env_index, const float* off_hz, const float* phase,
                         float scale, float noise, uint64_t seed, void* stream);

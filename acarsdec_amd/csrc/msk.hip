@@ -192,6 +192,19 @@ __device__ __forceinline__ void sincos_2pi(double x, double* sn, double* cs)
     *cs = ((q + 1) & 2) ? -cc : cc;
 }
 
+// n0 / d and n1 / d, both correctly rounded, for d in [1e-8, ~1e2] and |n| < ~1e2 or n == +0 (the matched filter's
+// sum starts from +0 and so is never -0, the one numerator whose quotient would come out as +0 here): see the call site.
+// acg_selftest_div2 compares it with the compiler's IEEE division on the device.
+__device__ __forceinline__ void div2_shared_rcp(double n0, double n1, double d, double* q0, double* q1)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+    const double a = n0 * r, b = n1 * r;
+    *q0 = __builtin_fma(__builtin_fma(-d, a, n0), r, a);
+    *q1 = __builtin_fma(__builtin_fma(-d, b, n1), r, b);
+}
+
 // msk.c:83 `if (p >= 2*M_PI) p -= 2*M_PI;` as compare + one select + one fma: fma(-1, 2pi, p) is p - 2pi
 // with its single rounding, fma(-0.0, 2pi, p) is p itself (p + -0.0), and -1.0 / -0.0 differ in the high
 // word only.  Same results, one instruction less than subtract + two-word select on the serial chain
@@ -477,8 +490,16 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
             // normalise, msk.c:110-113
             const float lvl = (float)__dsqrt_rn((double)vr * (double)vr + (double)vi * (double)vi);
             const double d = (double)lvl + 1e-8;
-            vr = (float)((double)vr / d);
-            vi = (float)((double)vi / d);
+            // two IEEE quotients over one denominator: the compiler's own f64 division is rcp + two Newton steps on the
+            // reciprocal, q0 = n * r, one remainder step q = fma(fma(-d, q0, n), r, q0), wrapped in div_scale / div_fixup
+            // for operands near the ends of the exponent range.  Here d is in [1e-8, ~1e2] and |n| < ~1e2 (or 0), so the
+            // scaling is the identity and the reciprocal can be shared: the same roundings, 8 instructions fewer.
+            {
+                double qr, qi;
+                div2_shared_rcp((double)vr, (double)vi, d, &qr, &qi);
+                vr = (float)qr;
+                vi = (float)qi;
+            }
             L.lvlsum += (double)(lvl * lvl / 4);
             L.bitcount++;
 #ifdef ACG_MSK_STAMP
@@ -572,6 +593,25 @@ __global__ void sincos_selftest_kernel(const double* x, double* s, double* c, in
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) sincos_2pi(x[i], &s[i], &c[i]);
+}
+
+// test hook: the shared-reciprocal quotients of the normalisation against the compiler's IEEE division
+__global__ void div2_selftest_kernel(const double* n0, const double* n1, const double* d, double* out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double a, b;
+    div2_shared_rcp(n0[i], n1[i], d[i], &a, &b);
+    out[4 * i + 0] = a;
+    out[4 * i + 1] = b;
+    out[4 * i + 2] = n0[i] / d[i];
+    out[4 * i + 3] = n1[i] / d[i];
+}
+
+extern "C" int acg_launch_div2_selftest(const double* n0, const double* n1, const double* d, double* out, int n, void* stream)
+{
+    hipLaunchKernelGGL(div2_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n0, n1, d, out, n);
+    return (int)hipGetLastError();
 }
 
 extern "C" int acg_launch_sincos_selftest(const double* x, double* s, double* c, int n, void* stream)

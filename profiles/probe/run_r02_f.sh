@@ -2,7 +2,7 @@
 O=gpurun_out/r02f
 mkdir -p $O
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "msk or wav or golden or soak or lane or compat or stream or refill" > $O/pytest_msk.log 2>&1; tail -3 $O/pytest_msk.log
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "msk or wav or golden or soak or lane or compat or stream or refill or reciprocal" > $O/pytest_msk.log 2>&1; tail -3 $O/pytest_msk.log
 timeout 300 python profiles/probe/msk_only.py 1024 8 2>&1 | grep -v amdgpu.ids | tee $O/msk_only.txt
 timeout 300 python profiles/probe/msk_phase_stamps.py 1024 8 2>&1 | grep -v amdgpu.ids | tee $O/msk_stamps.txt
 timeout 600 python bench.py --no-cpu-baseline --also none --steps 20 --warmup 3 --check-channels 16 > $O/bench_head.json 2> $O/bench_head.err; python - <<'PY'

@@ -339,6 +339,32 @@ def test_testwav_blocks_bits_state(D, testwav, golden, golden_bits, chunk):
         assert_state_close(st[c], dict(MskDf=fhex(g["MskDf"]), MskClk=fhex(g["MskClk"]), MskPhi=fhex(g["MskPhi"])), "golden test.wav ch %d" % c)
 
 
+def test_shared_reciprocal_normalisation_is_ieee_division():
+    """msk.c:111 divides Re v and Im v by the same double (lvl + 1e-8); the device computes one reciprocal and finishes
+    each quotient with the remainder step of the IEEE algorithm.  Over the operand range the loop produces
+    (d = |v| + 1e-8 with |v| from exact silence to a saturated filter, numerators up to |v|) the quotients must be
+    bit-identical to the compiler's IEEE division, on 4 million random triples plus the edges."""
+    from acarsdec_amd import _capi as K
+    L = K.load()
+    rng = np.random.default_rng(2024)
+    n = 1 << 22
+    lvl = np.concatenate([10.0 ** rng.uniform(-12, 2, n - 8), [0.0, 1e-45, 1e-38, 1.17549435e-38, 3.4e38 ** 0.25, 1.0, 127.5, 1e-8]]).astype(np.float32)
+    d = lvl.astype(np.float64) + 1e-8
+    ang = rng.uniform(0, 2 * np.pi, n)
+    vr = (lvl * np.cos(ang)).astype(np.float32).astype(np.float64)
+    vi = (lvl * np.sin(ang)).astype(np.float32).astype(np.float64)
+    vr[:16] = 0.0
+    vi[16:32] = 0.0
+    vr[32:48] = lvl[32:48]
+    vr[vr == 0] = 0.0                            # the filter output is a sum that starts from +0: it is never -0,
+    vi[vi == 0] = 0.0                            # the one numerator whose quotient's sign the shared form would lose
+    out = np.zeros((n, 4), dtype=np.float64)
+    assert L.acg_selftest_div2(vr.ctypes.data, vi.ctypes.data, d.ctypes.data, out.ctypes.data, n) == K.OK
+    assert np.array_equal(out[:, 0].view(np.uint64), out[:, 2].view(np.uint64))
+    assert np.array_equal(out[:, 1].view(np.uint64), out[:, 3].view(np.uint64))
+    assert np.array_equal(out[:, 2], vr / d) and np.array_equal(out[:, 3], vi / d)          # and the device's IEEE division is IEEE
+
+
 def assert_state_close(got, want, what):
     """The loop's continuous state against the reference's.  The device differs from glibc only in the last bit of
     the mixer's f64 sin/cos (< 1 ulp, and only the float-rounded product is kept, msk.c:90): a product moves by one
