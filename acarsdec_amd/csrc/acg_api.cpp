@@ -1142,9 +1142,9 @@ extern "C" int acg_selftest_div2(const double* n0_host, const double* n1_host, c
     const size_t by = (size_t)n * sizeof(double);
     int rc = ACG_EHIP;
     if (hipMalloc(&a, by) == hipSuccess && hipMalloc(&b, by) == hipSuccess && hipMalloc(&d, by) == hipSuccess &&
-        hipMalloc(&o, 4 * by) == hipSuccess && hipMemcpy(a, n0_host, by, hipMemcpyHostToDevice) == hipSuccess &&
+        hipMalloc(&o, 8 * by) == hipSuccess && hipMemcpy(a, n0_host, by, hipMemcpyHostToDevice) == hipSuccess &&
         hipMemcpy(b, n1_host, by, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(d, d_host, by, hipMemcpyHostToDevice) == hipSuccess &&
-        acg_launch_div2_selftest(a, b, d, o, n, nullptr) == 0 && hipMemcpy(out_host, o, 4 * by, hipMemcpyDeviceToHost) == hipSuccess)
+        acg_launch_div2_selftest(a, b, d, o, n, nullptr) == 0 && hipMemcpy(out_host, o, 8 * by, hipMemcpyDeviceToHost) == hipSuccess)
         rc = ACG_OK;
     hipFree(a); hipFree(b); hipFree(d); hipFree(o);
     return rc;

@@ -205,6 +205,31 @@ __device__ __forceinline__ void div2_shared_rcp(double n0, double n1, double d, 
     *q1 = __builtin_fma(__builtin_fma(-d, b, n1), r, b);
 }
 
+// one quotient, same construction (the tap phase clk / s, msk.c:103: s ~ 0.9, |clk| < 1)
+__device__ __forceinline__ double div1_rcp(double n, double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+    r = __builtin_fma(r, __builtin_fma(-d, r, 1.0), r);
+    const double a = n * r;
+    return __builtin_fma(__builtin_fma(-d, a, n), r, a);
+}
+
+// sqrt(x), correctly rounded, for x = 0 or x in [1e-100, 1e100]: the compiler's own expansion (rsq, one coupled
+// Newton step on (g, h) = (sqrt, 1 / (2 sqrt)), two remainder steps) without the exponent scaling it wraps around
+// it for arguments below 2^-767.  |v|^2 (msk.c:110 through cabsf) is a sum of two squares of floats.
+__device__ __forceinline__ double sqrt_rn_midrange(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+    g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+    return x == 0.0 ? x : g;
+}
+
 // msk.c:83 `if (p >= 2*M_PI) p -= 2*M_PI;` as compare + one select + one fma: fma(-1, 2pi, p) is p - 2pi
 // with its single rounding, fma(-0.0, 2pi, p) is p itself (p + -0.0), and -1.0 / -0.0 differ in the high
 // word only.  Same results, one instruction less than subtract + two-word select on the serial chain
@@ -288,7 +313,8 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
 
     const float* __restrict__ dm = a.dm + (size_t)chc * a.dm_pitch;
     unsigned char* txt = a.txt + (size_t)chc * 256;
-    float2* bits = (a.bits && leader) ? a.bits + (size_t)chc * a.bit_cap : nullptr;
+    // every lane of a group stores the (identical) bit record and text byte: no exec-mask branches on the per-bit path
+    float2* bits = a.bits ? a.bits + (size_t)chc * a.bit_cap : nullptr;
     const int len = active ? a.len : 0;
     int nb = (a.bit_append && active) ? a.nbits_out[ch] : 0;
     int n = 0;
@@ -415,7 +441,7 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
         unsigned int idx_n = idx + (unsigned int)cnt;
         if (idx_n >= FLEN) idx_n -= FLEN;
         const float clk_f = fired ? (float)((double)L.clk - K_3PI2) : L.clk;   // msk.c:100
-        int o = (int)(MFLTOVER * ((double)clk_f / s + 0.5));                    // msk.c:103
+        int o = (int)(MFLTOVER * (div1_rcp((double)clk_f, s) + 0.5));           // msk.c:103
         if (o > MFLTOVER) o = MFLTOVER;
         if (o < 0) o = 0;          // memory safety only: the reference indexes h[] out of bounds here
         float hv[FLEN];
@@ -488,7 +514,7 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
 #endif
             STAMP(3);                                                      // C1: tap phase (f64 divide), ring + h reads, matched filter
             // normalise, msk.c:110-113
-            const float lvl = (float)__dsqrt_rn((double)vr * (double)vr + (double)vi * (double)vi);
+            const float lvl = (float)sqrt_rn_midrange((double)vr * (double)vr + (double)vi * (double)vi);   // cabsf, see fir.hip
             const double d = (double)lvl + 1e-8;
             // two IEEE quotients over one denominator: the compiler's own f64 division is rcp + two Newton steps on the
             // reciprocal, q0 = n * r, one remainder step q = fma(fma(-d, q0, n), r, q0), wrapped in div_scale / div_fixup
@@ -515,7 +541,7 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
             const unsigned int flip = ((vo >= 0) == odd) ? 0x80000000u : 0u;
             const double dphi = (double)__uint_as_float(__float_as_uint(ot) ^ flip);
             const float sv = __uint_as_float(__float_as_uint(vo) ^ ((L.S & 2u) << 30));   // msk.c:122-126
-            if (bits && nb < a.bit_cap) bits[nb] = make_float2(sv, lvl);
+            if (bits) bits[nb < a.bit_cap ? nb : a.bit_cap - 1] = make_float2(sv, lvl);     // (bits is wave-uniform; on overflow the last record is the newest bit)
             ++nb;
             // putbit, msk.c:53-63
             L.outbits = (L.outbits >> 1) & 0x7fu;
@@ -533,7 +559,7 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
                 const bool hunt = ev & (L.astate == WSYN) & !syn;
                 const bool term = (r == ETX) | (r == ETB) | (r == DLE);
                 const bool plain = ev & (L.astate == TXT) & ((__popc(r) & 1) != 0) & !term & (L.blen < 240);
-                if (plain & leader) txt[L.blen] = (unsigned char)r;
+                txt[plain ? L.blen : 255] = (unsigned char)r;          // byte 255 of the 256-byte text buffer is scratch (blen <= 241)
                 L.blen += plain ? 1 : 0;
                 L.nbits = hunt ? 1 : (plain ? 8 : L.nbits);
                 if (ev & !hunt & !plain) decode_acars(L, a, ch, txt, samp0 + n - 1, leader);
@@ -602,10 +628,15 @@ __global__ void div2_selftest_kernel(const double* n0, const double* n1, const d
     if (i >= n) return;
     double a, b;
     div2_shared_rcp(n0[i], n1[i], d[i], &a, &b);
-    out[4 * i + 0] = a;
-    out[4 * i + 1] = b;
-    out[4 * i + 2] = n0[i] / d[i];
-    out[4 * i + 3] = n1[i] / d[i];
+    out[8 * i + 0] = a;
+    out[8 * i + 1] = b;
+    out[8 * i + 2] = n0[i] / d[i];
+    out[8 * i + 3] = n1[i] / d[i];
+    const double x = n0[i] * n0[i] + n1[i] * n1[i];
+    out[8 * i + 4] = sqrt_rn_midrange(x);
+    out[8 * i + 5] = __dsqrt_rn(x);
+    out[8 * i + 6] = div1_rcp(n0[i], d[i]);
+    out[8 * i + 7] = x;
 }
 
 extern "C" int acg_launch_div2_selftest(const double* n0, const double* n1, const double* d, double* out, int n, void* stream)

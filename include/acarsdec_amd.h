@@ -204,9 +204,10 @@ int  acg_synth_iq_u8_dev(uint8_t *iq_dev, size_t pitch_bytes, int nrows, int nou
 /* diagnostics: the device sin/cos used by the mixer (msk.c:90 calls cexp), evaluated on the GPU
  * for n host arguments in [0, 2*pi) -- lets a test bound its error against libm */
 int  acg_selftest_sincos(const double *x_host, double *sin_host, double *cos_host, int n);
-/* diagnostics: the normalisation v /= lvl + 1e-8 (msk.c:111) divides two numerators by one f64 denominator; the device
- * shares the reciprocal.  out[4i..4i+3] = {shared n0/d, shared n1/d, IEEE n0/d, IEEE n1/d} for n host triples -- a test
- * checks the pairs are bit-identical over the operand range the loop produces */
+/* diagnostics: the loop's f64 divisions and square root as the device computes them (msk.c:103,110-111: shared
+ * reciprocal, no exponent scaling) next to the compiler's IEEE forms, for n host triples:
+ * out[8i..8i+7] = {n0/d, n1/d (shared reciprocal), n0/d, n1/d (IEEE), sqrt(x), sqrt(x) (IEEE), n0/d (single), x}
+ * with x = n0^2 + n1^2 -- a test checks the pairs are bit-identical over the operand range the loop produces */
 int  acg_selftest_div2(const double *n0_host, const double *n1_host, const double *d_host, double *out_host, int n);
 
 #ifdef __cplusplus

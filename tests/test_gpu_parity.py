@@ -358,11 +358,20 @@ def test_shared_reciprocal_normalisation_is_ieee_division():
     vr[32:48] = lvl[32:48]
     vr[vr == 0] = 0.0                            # the filter output is a sum that starts from +0: it is never -0,
     vi[vi == 0] = 0.0                            # the one numerator whose quotient's sign the shared form would lose
-    out = np.zeros((n, 4), dtype=np.float64)
+    out = np.zeros((n, 8), dtype=np.float64)
     assert L.acg_selftest_div2(vr.ctypes.data, vi.ctypes.data, d.ctypes.data, out.ctypes.data, n) == K.OK
     assert np.array_equal(out[:, 0].view(np.uint64), out[:, 2].view(np.uint64))
     assert np.array_equal(out[:, 1].view(np.uint64), out[:, 3].view(np.uint64))
     assert np.array_equal(out[:, 2], vr / d) and np.array_equal(out[:, 3], vi / d)          # and the device's IEEE division is IEEE
+    assert np.array_equal(out[:, 6].view(np.uint64), out[:, 2].view(np.uint64))             # the single-quotient form (tap phase)
+    # |v| = sqrt(re^2 + im^2) without the exponent scaling: bit-identical to the IEEE square root, which is numpy's
+    assert np.array_equal(out[:, 4].view(np.uint64), out[:, 5].view(np.uint64))
+    assert np.array_equal(out[:, 5], np.sqrt(out[:, 7]))
+    # the tap phase's operands: clock in (-1, 1) over s = 0.9 +- 0.05
+    clk = rng.uniform(-1, 1, n).astype(np.float32).astype(np.float64)
+    sden = 1800.0 / 12500 * 2 * np.pi + rng.uniform(-0.05, 0.05, n)
+    assert L.acg_selftest_div2(clk.ctypes.data, clk.ctypes.data, sden.ctypes.data, out.ctypes.data, n) == K.OK
+    assert np.array_equal(out[:, 6].view(np.uint64), out[:, 2].view(np.uint64)) and np.array_equal(out[:, 2], clk / sden)
 
 
 def assert_state_close(got, want, what):
