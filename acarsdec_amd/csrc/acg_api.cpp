@@ -2,6 +2,7 @@
 // Host runtime only: buffers, launches, result queues.  There is deliberately no CPU compute
 // path here: without a GPU acg_create() fails with ACG_ENODEV.
 #include <hip/hip_runtime.h>
+#include <rocprofiler-sdk-roctx/roctx.h>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -468,6 +469,8 @@ static int launch_fir(acg_ctx* c, const uint8_t* iq_dev, size_t pitch, int nbloc
         HIPCHK(c, hipEventRecord(ev.a, s));
     }
     int e;
+    roctxRangePushA("acg:down-converter");                 // named range around the launch (rocprofv3 --marker-trace)
+    struct RangePop { ~RangePop() { roctxRangePop(); } } range_pop;
     if (c->tile_path) {
         a.cpr = a.row_bytes / 16;
         a.row_stride = (a.cpr & 1) ? a.row_bytes : a.row_bytes + 16;
@@ -534,7 +537,9 @@ static int launch_msk(acg_ctx* c, const float* dm_dev, size_t pitch_floats, int 
         if ((r = get_event(c, &ev.a)) != ACG_OK || (r = get_event(c, &ev.b)) != ACG_OK) return r;
         HIPCHK(c, hipEventRecord(ev.a, s));
     }
+    roctxRangePushA("acg:demodulator");
     const int e = acg_launch_msk(&a, c->msk_lpc, s);
+    roctxRangePop();
     if (e != 0) {
         c->err = std::string("MSK launch: ") + hipGetErrorString((hipError_t)e);
         return ACG_EHIP;
@@ -1014,7 +1019,9 @@ static int run_fmt(acg_ctx* ctx, int fmt, FirArgs* a, hipStream_t caller)
             HIPCHK(ctx, hipEventRecord(ev.a, s));
         }
         if (ctx->msk_go_valid) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->msk_go, 0));   // see acg_process_iq_u8_dev
+        roctxRangePushA("acg:down-converter");
         const int e = acg_launch_fir_fmt(a, fmt, s);
+        roctxRangePop();
         if (e != 0) {
             ctx->err = std::string("FIR launch: ") + hipGetErrorString((hipError_t)e);
             return ACG_EHIP;
