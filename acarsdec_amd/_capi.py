@@ -31,6 +31,15 @@ class Frame(C.Structure):
                 ("end_bit", C.c_longlong), ("end_sample", C.c_longlong)]
 
 
+class Msg(C.Structure):
+    """acg_msg: outputmsg()'s field split as a fixed binary record"""
+    _fields_ = [("chn", C.c_int), ("err", C.c_int), ("lvl", C.c_float), ("txt_len", C.c_int),
+                ("end_bit", C.c_longlong), ("end_sample", C.c_longlong), ("reserved0", C.c_double), ("reserved1", C.c_int),
+                ("reserved2", C.c_char), ("mode", C.c_char), ("addr", C.c_char * 8), ("ack", C.c_char), ("label", C.c_char * 3),
+                ("bid", C.c_char), ("no", C.c_char * 5), ("fid", C.c_char * 7), ("bs", C.c_char), ("be", C.c_char),
+                ("down", C.c_char), ("txt", C.c_ubyte * 242)]
+
+
 BIT_SINK = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_float, C.c_float)
 
 # name -> (restype, argtypes): every symbol include/acarsdec_amd.h declares
@@ -60,6 +69,8 @@ SYMBOLS = {
     "acg_feed_samples_host": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
     "acg_drain_frames": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.c_int, C.POINTER(C.c_int)]),
     "acg_collect_frames": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Frame), C.c_int, C.POINTER(C.c_int)]),
+    "acg_drain_msgs": (C.c_int, [C.c_void_p, C.POINTER(Msg), C.c_int, C.POINTER(C.c_int)]),
+    "acg_collect_msgs": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Msg), C.c_int, C.POINTER(C.c_int)]),
     "acg_read_bits": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "acg_read_bits_all": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "acg_bit_capacity": (C.c_int, [C.c_void_p]),

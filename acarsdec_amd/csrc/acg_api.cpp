@@ -80,6 +80,9 @@ struct acg_ctx {
     unsigned int* d_msk_done = nullptr;     // workgroups-finished counter of the demodulator kernel
     AcgFrameRec* h_stage = nullptr;         // host staging for acg_collect_frames / acg_drain_frames
     size_t h_stage_cap = 0;
+    AcgMsgRec* d_msgs = nullptr;            // device + host staging for acg_collect_msgs / acg_drain_msgs
+    AcgMsgRec* h_msgs = nullptr;
+    size_t msgs_cap = 0;
     unsigned int* d_work = nullptr;     // FIR run dispensers, ACG_DISP_WORDS words per chunk slot
     bool stream_identity = true;        // channel c reads stream c
     unsigned short* d_crctab = nullptr; // [256] + syndromes [1936] (ACG_F_REPAIR)
@@ -150,6 +153,7 @@ static void free_all(acg_ctx* c)
     hipFree(c->d_taps); hipFree(c->d_stream_of); hipFree(c->d_groups); hipFree(c->d_group_ch); hipFree(c->d_gtaps); hipFree(c->d_dm_all); hipFree(c->d_st);
     hipFree(c->d_h); hipFree(c->d_txt); hipFree(c->d_frames); hipFree(c->d_frame_count);
     hipFree(c->d_stamp);
+    hipFree(c->d_msgs); std::free(c->h_msgs);
     hipFree(c->d_bits); hipFree(c->d_nbits); hipFree(c->d_stage); hipFree(c->d_work); hipFree(c->d_msk_done); std::free(c->h_stage); hipFree(c->d_crctab); hipFree(c->d_rep_upto);
     for (auto& p : c->fir_ev) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto& p : c->msk_ev) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
@@ -456,6 +460,10 @@ static int launch_fir(acg_ctx* c, const uint8_t* iq_dev, size_t pitch, int nbloc
     a.row_bytes = 2 * g.decim;
     a.work_counter = c->d_work + (size_t)ACG_DISP_WORDS * block0;     // one dispenser per chunk slot
     a.stream_identity = c->stream_identity ? 1 : 0;
+    // >= 8192 channels: both stages share every CU and the down-converter is by far the longer one (measured at 16 384
+    // channels: +5 % whole job; at 4096 channels the two stages are about equally long and the raise costs 15 %)
+    a.high_prio = (!c->fir_stream && g.nch >= 8192) ? 1 : 0;
+    if (const char* e = std::getenv("ACG_FIR_PRIO")) a.high_prio = std::atoi(e) ? 1 : 0;
     // few channels: the demodulator's serial chain is the critical path; three resident workgroups per CU
     // cost the down-converter ~5 % of its bandwidth and give the demodulator waves ~10 % (whole job +5 %)
     a.wg_per_cu = (c->msk_high_prio && !c->fir_stream) ? 3 : 0;
@@ -813,6 +821,85 @@ extern "C" int acg_drain_frames(acg_ctx* ctx, acg_frame* out, int max_frames, in
     unsigned int count = 0;
     HIPCHK(ctx, hipMemcpy(&count, ctx->d_frame_count, sizeof(count), hipMemcpyDeviceToHost));
     return fetch_frames(ctx, count, out, max_frames, nframes);
+}
+
+// ------------------------------------------------------------------------------------------
+// blocks [consumed, upto) of the ring through the device-side field split (blk.hip msg_split_kernel)
+static_assert(sizeof(AcgMsgRec) == sizeof(acg_msg), "device record and public record must have one layout");
+static int fetch_msgs(acg_ctx* ctx, unsigned int upto, acg_msg* out, int max_msgs, int* nmsgs)
+{
+    if (!ctx->d_crctab) return fail(ctx, ACG_ESTATE, "context created without ACG_F_REPAIR");
+    const unsigned int pending = upto - ctx->consumed;
+    int rc = ACG_OK;
+    unsigned int take = pending;
+    if (pending > ctx->frame_cap) {                               // the device lapped the host: oldest lost
+        ctx->consumed = upto - ctx->frame_cap;
+        take = ctx->frame_cap;
+        rc = ACG_EOVERFLOW;
+    }
+    if (take > ctx->msgs_cap) {
+        hipFree(ctx->d_msgs);
+        std::free(ctx->h_msgs);
+        ctx->d_msgs = nullptr;
+        ctx->h_msgs = nullptr;
+        ctx->msgs_cap = 0;
+        const size_t want = std::max<size_t>(take, 4096);
+        HIPCHK(ctx, hipMalloc(&ctx->d_msgs, want * sizeof(AcgMsgRec)));
+        ctx->h_msgs = (AcgMsgRec*)std::malloc(want * sizeof(AcgMsgRec));
+        if (!ctx->h_msgs) return fail(ctx, ACG_ENOMEM, "message staging");
+        ctx->msgs_cap = want;
+    }
+    if (take) {
+        if (acg_launch_msg_split(ctx->d_frames, ctx->frame_cap, ctx->consumed, take, ctx->d_msgs, ctx->copy_stream) != 0)
+            return fail(ctx, ACG_EHIP, "message split launch failed");
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_msgs, ctx->d_msgs, (size_t)take * sizeof(AcgMsgRec), hipMemcpyDeviceToHost, ctx->copy_stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
+    }
+    ctx->consumed = upto;
+    const AcgMsgRec* rec = ctx->h_msgs;
+    std::vector<unsigned int> order;
+    order.reserve(take);
+    for (unsigned int i = 0; i < take; ++i)
+        if (rec[i].valid) order.push_back(i);
+    std::sort(order.begin(), order.end(), [rec](unsigned int x, unsigned int y) {
+        return rec[x].chn != rec[y].chn ? rec[x].chn < rec[y].chn : rec[x].end_bit < rec[y].end_bit;
+    });
+    unsigned int kept = 0;
+    for (unsigned int i : order) {
+        if ((int)kept >= max_msgs) { rc = ACG_EOVERFLOW; break; }
+        acg_msg& m = out[kept++];
+        std::memcpy(&m, &rec[i], sizeof(m));
+        m.lvl = acg_host_level_db(rec[i].lvlsum, rec[i].bitcount);   // acars.c:351
+        m.reserved0 = 0;
+        m.reserved1 = 0;
+        m.reserved2 = 0;
+    }
+    *nmsgs = (int)kept;
+    if (rc != ACG_OK) return fail(ctx, rc, "message queue overflow");
+    return ACG_OK;
+}
+
+extern "C" int acg_collect_msgs(acg_ctx* ctx, int lag, acg_msg* out, int max_msgs, int* nmsgs)
+{
+    if (!ctx || !nmsgs || (max_msgs > 0 && !out) || lag < 0 || lag >= acg_ctx::NCALL - 1) return ACG_EINVAL;
+    *nmsgs = 0;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    if (ctx->call_seq <= (unsigned long long)lag) return ACG_OK;
+    const unsigned long long call = ctx->call_seq - 1 - (unsigned long long)lag;
+    const int slot = (int)(call % acg_ctx::NCALL);
+    HIPCHK(ctx, hipEventSynchronize(ctx->call_done[slot]));
+    return fetch_msgs(ctx, ctx->h_call_count[slot], out, max_msgs, nmsgs);
+}
+
+extern "C" int acg_drain_msgs(acg_ctx* ctx, acg_msg* out, int max_msgs, int* nmsgs)
+{
+    if (!ctx || !nmsgs || (max_msgs > 0 && !out)) return ACG_EINVAL;
+    *nmsgs = 0;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    unsigned int count = 0;
+    HIPCHK(ctx, hipMemcpy(&count, ctx->d_frame_count, sizeof(count), hipMemcpyDeviceToHost));
+    return fetch_msgs(ctx, count, out, max_msgs, nmsgs);
 }
 
 extern "C" int acg_bit_capacity(const acg_ctx* ctx) { return ctx ? ctx->bit_cap : 0; }

@@ -6,6 +6,7 @@
 
 #define ACG_WG_FIR 256          // FIR workgroup: 4 waves, one 64-window tile, taps split over waves
 #define ACG_TILE_WIN 64         // windows (12.5 kHz outputs) per FIR tile = one per lane
+#define ACG_MSG_TXT 242         // text bytes of a split message (== ACG_MSGTXTMAX of the public header)
 #define ACG_WG_MSK 64           // one MSK wave: 64/LPC channels (LPC lanes per channel); 1 or 4 waves per workgroup
 
 // Per-channel demodulator + framing state, resident in HBM across calls.
@@ -44,6 +45,30 @@ struct AcgFrameRec {
     unsigned char txt[256];     // 16-byte aligned, 16-byte multiples for vector copies
 };
 
+// One split message on the device: the public acg_msg (include/acarsdec_amd.h) field for field, with the two
+// operands of the level in place of the padding the host overwrites.
+struct AcgMsgRec {
+    int chn;
+    int err;
+    float lvl;                  // filled in on the host: 10*log10(lvlsum/bitcount), acars.c:351
+    int txt_len;
+    long long end_bit;
+    long long end_sample;
+    double lvlsum;              // (acg_msg: reserved)
+    int bitcount;               // (acg_msg: reserved)
+    char valid;                 // (acg_msg: reserved) 0 = dropped by the block repair
+    char mode;
+    char addr[8];
+    char ack;
+    char label[3];
+    char bid;
+    char no[5];
+    char fid[7];
+    char bs, be;
+    char down;
+    char txt[ACG_MSG_TXT];
+};
+
 struct FirArgs {
     const uint8_t* iq;          // [nstreams] rows
     size_t pitch;               // bytes between stream rows (multiple of 16)
@@ -72,6 +97,7 @@ struct FirArgs {
     float out_scale;            // power-of-two scale applied to |D| (1, 1/32768 soapy.c:241, 1/4 sdrplay.c:225)
     unsigned int* work_counter; // run dispenser of the dynamically scheduled kernels (ACG_DISP_WORDS words per launch in flight)
     int stream_identity;        // stream_of[ch] == ch for every channel: the row base needs no lookup
+    int high_prio;              // wave-private kernel: raise the wave priority (the demodulator shares its CUs and has slack)
 };
 
 // Run dispenser of one launch in flight: words [0], [1] = {tickets, finished} of the workgroup-granular
@@ -117,6 +143,7 @@ size_t acg_fir_lds_bytes(const FirArgs* a);
 int acg_launch_msk(const MskArgs* a, int lanes_per_channel, void* stream);
 int acg_launch_blk_repair(AcgFrameRec* frames, unsigned int cap, const unsigned int* count, unsigned int* done_upto,
                           const unsigned short* synd, const unsigned short* crctab, void* stream);
+int acg_launch_msg_split(const AcgFrameRec* frames, unsigned int cap, unsigned int first, unsigned int n, AcgMsgRec* out, void* stream);
 int acg_launch_sincos_selftest(const double* x, double* s, double* c, int n, void* stream);
 int acg_launch_div2_selftest(const double* n0, const double* n1, const double* d, double* out, int n, void* stream);
 int acg_launch_synth_iq(uint8_t* iq, size_t pitch, int nrows, int nout, int decim, const float* env,

@@ -96,6 +96,68 @@ __global__ void blk_repair_kernel(AcgFrameRec* frames, unsigned int cap, const u
     }
 }
 
+// SURVEY 8f.4 -- the field split of outputmsg() (output.c:486-560,566-568,623-631, the build without libacars) on the
+// device: processed blocks [first, first + n) of the queue -> fixed binary records (AcgMsgRec == acg_msg, see
+// include/acarsdec_amd.h), one thread per block.  valid = 0 marks blocks the repair dropped (acars.c:124-207) and
+// blocks the repair has not seen.  The level (a log10) is filled in on the host, like for acg_frame.
+__global__ void msg_split_kernel(const AcgFrameRec* frames, unsigned int cap, unsigned int first, unsigned int n, AcgMsgRec* out)
+{
+    const unsigned int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const AcgFrameRec* f = frames + ((first + q) % cap);
+    AcgMsgRec* m = out + q;
+    const unsigned char* t = f->txt;
+    const int len = f->len;
+    m->chn = f->chn;
+    m->err = f->err;
+    m->lvl = 0.f;
+    m->txt_len = 0;
+    m->end_bit = f->end_bit;
+    m->end_sample = f->end_sample;
+    m->lvlsum = f->lvlsum;
+    m->bitcount = f->bitcount;
+    m->valid = (f->status == 1 && len >= 13) ? 1 : 0;
+    for (int i = 0; i < 8; ++i) m->addr[i] = 0;
+    for (int i = 0; i < 5; ++i) m->no[i] = 0;
+    for (int i = 0; i < 7; ++i) m->fid[i] = 0;
+    m->label[2] = 0;
+    if (!m->valid) return;
+    int k = 0;
+    m->mode = (char)t[k++];
+    int j = 0;
+    for (int i = 0; i < 7; ++i, ++k)
+        if (t[k] != '.') m->addr[j++] = (char)t[k];                        // output.c:502-508
+    m->ack = t[k] == 0x15 ? '!' : (char)t[k];                              // NAK is not printable, output.c:511-514
+    ++k;
+    m->label[0] = (char)t[k++];
+    m->label[1] = t[k] == 0x7f ? 'd' : (char)t[k];                         // output.c:518-520
+    ++k;
+    m->bid = (char)t[k++];
+    m->down = (m->bid >= '0' && m->bid <= '9') ? 1 : 0;                    // IS_DOWNLINK_BLK, output.c:31
+    m->bs = (char)t[k++];
+    m->be = (char)t[len - 1];
+    if (m->bs != 0x03) {
+        if (m->down) {
+            int i;
+            for (i = 0; i < 4 && k < len - 1; ++i, ++k) m->no[i] = (char)t[k];      // output.c:547-550
+            for (i = 0; i < 6 && k < len - 1; ++i, ++k) m->fid[i] = (char)t[k];     // output.c:560-563
+        }
+        const int tl = len - k - 1;                                         // output.c:567
+        if (tl > 0) {
+            for (int i = 0; i < tl; ++i) m->txt[i] = (char)t[k + i];
+            m->txt_len = tl;
+        }
+    }
+}
+
+extern "C" int acg_launch_msg_split(const AcgFrameRec* frames, unsigned int cap, unsigned int first, unsigned int n,
+                                    AcgMsgRec* out, void* stream)
+{
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(msg_split_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, frames, cap, first, n, out);
+    return (int)hipGetLastError();
+}
+
 __global__ void blk_advance_kernel(unsigned int* done_upto, const unsigned int* count) { *done_upto = *count; }
 
 extern "C" int acg_launch_blk_repair(AcgFrameRec* frames, unsigned int cap, const unsigned int* count,

@@ -786,6 +786,9 @@ __device__ __forceinline__ void fird_body(const FirArgs& a, const uint8_t* __res
 {
     typedef FirD<CPR, UU, BB> F;
     constexpr unsigned int NONE = 0xffffffffu;
+    // beside demodulator waves (which have slack whenever this kernel is the longer stage) this stream wins the issue
+    // arbitration: the demodulator then fills the gaps instead of stretching the bandwidth-bound stage
+    if (a.high_prio) __builtin_amdgcn_s_setprio(2);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned char* my = fir_smem + wave * F::WAVE_LDS;

@@ -194,6 +194,13 @@ class Decoder:
         _chk(self.ctx, self.L.acg_collect_frames(self.ctx, lag, self._fbuf, self._fbuf_cap, C.byref(n)))
         return n.value, self._fbuf
 
+    def drain_msgs(self, max_msgs=4096):
+        """outputmsg()'s field split of every block completed since the last drain (needs repair=True): K.Msg records."""
+        buf = (K.Msg * max_msgs)()
+        n = C.c_int(0)
+        _chk(self.ctx, self.L.acg_drain_msgs(self.ctx, buf, max_msgs, C.byref(n)))
+        return [K.Msg.from_buffer_copy(buf[i]) for i in range(n.value)]
+
     def bits(self, ch):
         vo = np.zeros(self.bit_cap, dtype=np.float32)
         lvl = np.zeros(self.bit_cap, dtype=np.float32)

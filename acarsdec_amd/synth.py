@@ -240,3 +240,31 @@ def pad_blocks(x, block=1024, fill=0.0):
 def xorshift_bytes(seed, n):
     """Deterministic pseudo-random bytes (numpy PCG; the name records the role in SURVEY 8d)."""
     return np.random.default_rng(seed).integers(0, 256, size=n, dtype=np.uint8)
+
+
+def message_zoo(rng, n):
+    """n transmissions that exercise every branch of outputmsg()'s field split (output.c:486-560): uplinks and
+    downlinks, NAK and letter acknowledgements, labels ending in DEL, addresses with leading dots, empty texts (ETX
+    right behind the block id), texts shorter than message number + flight id, ETB terminated blocks."""
+    out = []
+    for i in range(n):
+        down = bool(rng.integers(0, 2))
+        bid = bytes([int(rng.integers(0x30, 0x3A))]) if down else bytes([int(rng.integers(0x41, 0x5B))])
+        ndots = int(rng.integers(1, 4))
+        addr = b"." * ndots + bytes(rng.integers(0x41, 0x5B, size=7 - ndots).astype(np.uint8).tolist())
+        ack = b"\x15" if rng.integers(0, 2) else bytes([int(rng.integers(0x41, 0x5B))])
+        label = bytes([int(rng.integers(0x30, 0x5B))]) + (b"\x7f" if rng.integers(0, 4) == 0 else bytes([int(rng.integers(0x30, 0x5B))]))
+        kind = i % 4
+        text = b"" if kind == 0 else random_text(rng, 1, 9) if kind == 1 else random_text(rng, 10, 40) if kind == 2 else random_text(rng, 40, 200)
+        out.append(acars_frame(text=text, mode=bytes([int(rng.choice(list(b"2EGx")))]), addr=addr, ack=ack, label=label, bid=bid,
+                               etb=bool(rng.integers(0, 3) == 0)))
+    return out
+
+
+def frames_audio(frames, rng, gap=(3000, 6000), lead=4000):
+    """12.5 kHz audio carrying the given transmissions one after the other (silence between them)."""
+    parts = [np.zeros(lead)]
+    for fr in frames:
+        parts.append(msk_audio(frame_bits(fr), phase0=float(rng.uniform(0, 2 * np.pi))))
+        parts.append(np.zeros(int(rng.integers(gap[0], gap[1]))))
+    return np.concatenate(parts)

@@ -87,6 +87,32 @@ typedef struct {
 	long long end_sample;         /* per-channel 12.5 kHz sample index of that bit (replaces tv) */
 } acg_frame;
 
+/* A message as outputmsg() splits it out of a processed block (acarsmsg_t, acarsdec.h:108-124; output.c:486-560,
+ * 566-568,623-631 in the build without libacars): the fixed binary record every sink (printmsg, buildjson, Netout*)
+ * formats from.  Strings are NUL terminated like the reference's; txt is txt_len bytes, not terminated.  The CLI's
+ * filters (-A airflt, label_filter) are not applied. */
+#define ACG_MSGTXTMAX   242
+typedef struct {
+	int chn;
+	int err;                      /* parity errors repaired (acars.c:156) */
+	float lvl;                    /* dB, acars.c:351 */
+	int txt_len;
+	long long end_bit, end_sample;   /* as in acg_frame */
+	double reserved0;
+	int reserved1;
+	char reserved2;
+	char mode;
+	char addr[8];                 /* aircraft registration without the leading dots */
+	char ack;                     /* NAK is reported as '!' (output.c:511-514) */
+	char label[3];                /* a DEL second character is reported as 'd' (output.c:518-520) */
+	char bid;                     /* block id; '0'..'9' = downlink (output.c:31) */
+	char no[5];                   /* message number, downlinks only */
+	char fid[7];                  /* flight id, downlinks only */
+	char bs, be;                  /* start / end of text characters (STX or ETX / ETX or ETB) */
+	char down;
+	char txt[ACG_MSGTXTMAX];
+} acg_msg;
+
 /* ---- lifetime ---------------------------------------------------------------------------- */
 int  acg_device_count(void);
 int  acg_create(acg_ctx **out, const acg_config *cfg);
@@ -160,6 +186,11 @@ int  acg_drain_frames(acg_ctx *ctx, acg_frame *out, int max_frames, int *nframes
  * ones and waits only for those older calls, so that the newest call(s) keep the GPU busy
  * (lag = 1: classic double buffering; lag = 0: wait for the last call only).  0 <= lag <= 6. */
 int  acg_collect_frames(acg_ctx *ctx, int lag, acg_frame *out, int max_frames, int *nframes);
+/* SURVEY 8f.4, the batch sink: like acg_drain_frames / acg_collect_frames, but every block is taken through
+ * outputmsg()'s field split on the device and handed over as a fixed binary record.  Needs ACG_F_REPAIR (outputmsg()
+ * receives repaired, parity-stripped blocks); blocks the repair drops are omitted.  Ordered by (chn, end_bit). */
+int  acg_drain_msgs(acg_ctx *ctx, acg_msg *out, int max_msgs, int *nmsgs);
+int  acg_collect_msgs(acg_ctx *ctx, int lag, acg_msg *out, int max_msgs, int *nmsgs);
 /* Per-bit records of the LAST process call for one channel (needs ACG_F_BITLOG):
  * vo = the value putbit() receives (msk.c:122-126), lvl = cabsf(v) (msk.c:110). */
 int  acg_read_bits(acg_ctx *ctx, int ch, float *vo, float *lvl, int max_bits, int *nbits);

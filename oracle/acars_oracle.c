@@ -696,3 +696,59 @@ int orc_blk_process(const orc_frame *in, orc_frame *out)
 		return 0;
 	return 1;
 }
+
+
+/* output.c:486-560: mode, address without dots, ACK (NAK printed as '!'), label (DEL printed as 'd'), block id,
+ * start / end of text; for downlinks (block id '0'..'9', output.c:31) message number and flight id; then the text
+ * (output.c:566-568,623-631).  The CLI's filters (airflt, label_filter) are not part of the split. */
+void orc_msg_split(const orc_frame *blk, orc_msg *out)
+{
+	int i, j, k;
+	memset(out, 0, sizeof(*out));
+	out->chn = blk->chn;
+	out->lvl = blk->lvl;
+	out->err = blk->err;
+	k = 0;
+	out->mode = (char)blk->txt[k];
+	k++;
+	for (i = 0, j = 0; i < 7; i++, k++) {
+		if (blk->txt[k] != '.') {
+			out->addr[j] = (char)blk->txt[k];
+			j++;
+		}
+	}
+	out->addr[j] = '\0';
+	out->ack = (char)blk->txt[k];
+	if (out->ack == 0x15)
+		out->ack = '!';
+	k++;
+	out->label[0] = (char)blk->txt[k];
+	k++;
+	out->label[1] = (char)blk->txt[k];
+	if (out->label[1] == 0x7f)
+		out->label[1] = 'd';
+	k++;
+	out->label[2] = '\0';
+	out->bid = (char)blk->txt[k];
+	k++;
+	out->down = (out->bid >= '0' && out->bid <= '9');
+	out->bs = (char)blk->txt[k];
+	k++;
+	out->be = (char)blk->txt[blk->len - 1];
+	if (out->bs != 0x03) {
+		int txt_len;
+		if (out->down) {
+			for (i = 0; i < 4 && k < blk->len - 1; i++, k++)
+				out->no[i] = (char)blk->txt[k];
+			out->no[i] = '\0';
+			for (i = 0; i < 6 && k < blk->len - 1; i++, k++)
+				out->fid[i] = (char)blk->txt[k];
+			out->fid[i] = '\0';
+		}
+		txt_len = blk->len - k - 1;
+		if (txt_len > 0) {
+			memcpy(out->txt, blk->txt + k, (size_t)txt_len);
+			out->txt_len = txt_len;
+		}
+	}
+}

@@ -115,4 +115,23 @@ int orc_blk_process(const orc_frame *in, orc_frame *out);
 #ifdef __cplusplus
 }
 #endif
+/* output.c:486-560,566-568,623-631 (the build without libacars): the fields outputmsg() splits a processed
+ * block into -- what every sink (printmsg, buildjson, Netout*) formats afterwards. */
+typedef struct {
+	int chn, err;
+	float lvl;
+	int txt_len;
+	char mode;
+	char addr[8];
+	char ack;
+	char label[3];
+	char bid;
+	char no[5];
+	char fid[7];
+	char bs, be;
+	char down;
+	char txt[256];
+} orc_msg;
+void orc_msg_split(const orc_frame *blk, orc_msg *out);
+
 #endif

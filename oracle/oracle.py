@@ -223,6 +223,25 @@ def blk_process(frame):
     return out if lib().orc_blk_process(C.byref(frame), C.byref(out)) else None
 
 
+class OrcMsg(C.Structure):
+    _fields_ = [("chn", C.c_int), ("err", C.c_int), ("lvl", C.c_float), ("txt_len", C.c_int), ("mode", C.c_char),
+                ("addr", C.c_char * 8), ("ack", C.c_char), ("label", C.c_char * 3), ("bid", C.c_char), ("no", C.c_char * 5),
+                ("fid", C.c_char * 7), ("bs", C.c_char), ("be", C.c_char), ("down", C.c_char), ("txt", C.c_ubyte * 256)]
+
+
+def msg_split(frame):
+    """output.c:486-560 on a processed block (blk_process output): the fields every sink formats."""
+    out = OrcMsg()
+    lib().orc_msg_split(C.byref(frame), C.byref(out))
+    return out
+
+
+def msg_tuple(m):
+    """comparable view of a split message (OrcMsg or the library's acg_msg)"""
+    return (int(m.chn), int(m.err), bytes(m.mode), bytes(m.addr), bytes(m.ack), bytes(m.label), bytes(m.bid), bytes(m.no),
+            bytes(m.fid), bytes(m.bs), bytes(m.be), m.down not in (b"\x00", 0), bytes(m.txt[: m.txt_len]))
+
+
 def crc_ccitt(data, crc=0):
     for b in bytes(data):
         crc = lib().orc_crc_update(crc, b)

@@ -67,3 +67,28 @@ def soft_from_v(vr, vi, MskS):
     vo = np.where(MskS & 1, ni, nr)
     vo = np.where(MskS & 2, -vo, vo).astype(np.float32)
     return vo, lvl
+
+
+def msg_fields_from_json(j):
+    """the reference program's JSON line (output.c:227-324) reduced to the fields of outputmsg()'s split"""
+    return dict(chn=j["channel"], err=j["error"], mode=j["mode"], label=j["label"], bid=j.get("block_id", ""), ack=j.get("ack"),
+                tail=j.get("tail"), flight=j.get("flight"), msgno=j.get("msgno"), text=j.get("text", ""), end=j.get("end", False),
+                level="%2.1f" % j["level"])
+
+
+def msg_fields_from_record(m):
+    """the same view of an oracle OrcMsg / library acg_msg record"""
+    down = m.down not in (b"\x00", 0)
+    return dict(chn=int(m.chn), err=int(m.err), mode=m.mode.decode("latin1"), label=m.label.decode("latin1"), bid=m.bid.decode("latin1"),
+                ack=False if m.ack == b"!" else m.ack.decode("latin1"), tail=m.addr.decode("latin1"),
+                flight=m.fid.decode("latin1") if down else None, msgno=m.no.decode("latin1") if down else None,
+                text=bytes(m.txt[: m.txt_len]).decode("latin1"), end=(m.be == b"\x17"), level="%2.1f" % m.lvl)
+
+
+@pytest.fixture(scope="session")
+def msgsplit_golden():
+    import json
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    pcm = np.load(os.path.join(here, "msgsplit_pcm16.npz"))["pcm"]
+    with open(os.path.join(here, "msgsplit_golden.json")) as f:
+        return pcm, json.load(f)

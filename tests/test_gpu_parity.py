@@ -374,6 +374,41 @@ def test_shared_reciprocal_normalisation_is_ieee_division():
     assert np.array_equal(out[:, 6].view(np.uint64), out[:, 2].view(np.uint64)) and np.array_equal(out[:, 2], clk / sden)
 
 
+def test_device_message_split_matches_reference_json_and_oracle(D, O, msgsplit_golden):
+    """the batch sink.  The golden recording (transmissions covering every branch of outputmsg()'s
+    field split) through demodulator + framing + block repair + field split, all on the device: the fixed binary
+    records equal the JSON the unmodified reference program printed, field for field, and the oracle's split."""
+    from conftest import msg_fields_from_json, msg_fields_from_record
+    pcm, want = msgsplit_golden
+    x = pcm.astype(np.float32) / 32768.0
+    chunk = 4096
+    pad = (-x.size) % chunk
+    x = np.concatenate([x, np.zeros(pad, dtype=np.float32)])
+    nch = 3                                           # the same recording on three channels
+    dec = D.Decoder(nch, decim=8, ntaps=8, max_blocks=chunk // 1024, repair=True, bitlog=False)
+    msgs = []
+    for s in range(0, x.size, chunk):
+        dec.demod_msk(np.tile(x[s:s + chunk], (nch, 1)))
+        msgs += dec.drain_msgs()
+    assert len(msgs) == nch * len(want)
+    for c in range(nch):
+        got = [msg_fields_from_record(m) for m in msgs if m.chn == c]
+        ref = [dict(msg_fields_from_json(j), chn=c) for j in want]
+        assert got == ref, c
+    ch = O.Channel(0, max_frames=512)
+    ch.demod(x)
+    orc = [O.msg_tuple(O.msg_split(b)) for b in (O.blk_process(f) for f in ch.frames) if b is not None]
+    assert [O.msg_tuple(m) for m in msgs if m.chn == 0] == orc
+    dec.close()
+    # without ACG_F_REPAIR the sink refuses (outputmsg() only ever sees repaired blocks)
+    from acarsdec_amd import _capi as K
+    dec = D.Decoder(1, decim=8, ntaps=8, max_blocks=1)
+    with pytest.raises(K.AcgError) as e:
+        dec.drain_msgs()
+    assert e.value.code == K.ESTATE
+    dec.close()
+
+
 def assert_state_close(got, want, what):
     """The loop's continuous state against the reference's.  The device differs from glibc only in the last bit of
     the mixer's f64 sin/cos (< 1 ulp, and only the float-rounded product is kept, msk.c:90): a product moves by one

@@ -302,3 +302,31 @@ print(json.dumps(out))
     for s, fc in zip(sets, ref_fc):
         fr = [(int(1000000 * float(f) + 6250) // 12500) * 12500 for f in s]
         assert O.choose_fc(fr, 160) == fc, (s, fc)
+
+
+def test_message_split_against_live_reference_program(tmp_path):
+    """orc_msg_split (output.c:486-560) pinned to the reference program run live on a fresh random recording:
+    300 transmissions, JSON output (-o 4), every field."""
+    import json
+    import subprocess
+    import wave
+    from conftest import msg_fields_from_json, msg_fields_from_record
+    from acarsdec_amd import synth as S
+    exe = os.path.join(os.path.dirname(O.ref_path()), "acarsdec_cpu")
+    if not os.path.exists(exe):
+        pytest.skip("reference program not built")
+    rng = np.random.default_rng(777)
+    a = S.frames_audio(S.message_zoo(rng, 300), rng)
+    pcm = np.rint(np.clip(0.5 * a, -1, 1) * 20000).astype(np.int16)
+    p = str(tmp_path / "zoo.wav")
+    with wave.open(p, "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(12500)
+        w.writeframes(pcm.tobytes())
+    r = subprocess.run([exe, "-o", "4", "-f", p], capture_output=True, text=True)
+    want = [msg_fields_from_json(json.loads(l)) for l in r.stdout.splitlines() if l.startswith("{")]
+    ch = O.Channel(0, max_frames=1024)
+    ch.demod(pcm.astype(np.float32) / 32768.0)
+    got = [msg_fields_from_record(O.msg_split(b)) for b in (O.blk_process(f) for f in ch.frames) if b is not None]
+    assert len(want) >= 280 and got == want
