@@ -1105,6 +1105,282 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_fmt_kernel(const FirArgs a,
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The wave-private streaming kernel for the other front ends' sample formats (4 bytes per sample; split planes: two
+// 16-byte chunks -- 8 I and 8 Q samples -- per step).  Same structure as fir_u8_direct_kernel: the input never passes
+// through LDS, wave-loads are issued in bursts U - B positions ahead, the taps of a lane's column come from a per-wave
+// LDS copy of the channel's tap table with replicated columns, per-chunk partial sums are transposed through a per-wave
+// LDS array, work is handed out per wave by the sharded ticket dispenser.  What the format changes:
+//   * a window is CPR chunks per plane (M = 200 interleaved int16 or real f32: 50; Airspy at 6 / 10 Msps: 120 / 200),
+//     so a tile is W = 32, 16 or 8 windows (W * CPR chunks = a whole number of wave-loads) and S = 64 / W adjacent lanes
+//     add up the partial sums of one window -- E = CPR / S consecutive entries each -- and meet through S - 1 lane
+//     exchanges;
+//   * the arithmetic per chunk: 4 complex samples (CS16), 4 real samples against complex taps (F32R: half the
+//     multiply-adds), 8 complex samples from two planes (SPLIT); the power-of-two output scale is applied to |D|.
+template <int FMT, int CPR, int W>
+struct FirX {
+    static constexpr int NPL = (FMT == FMT_SPLIT) ? 4 : 2;             // 16-byte tap planes per column (8 or 4 taps)
+    static constexpr int SPC = (FMT == FMT_SPLIT) ? 8 : 4;             // samples (taps) per column
+    static constexpr int NLD = (FMT == FMT_SPLIT) ? 2 : 1;             // wave-loads per step
+    static constexpr int LT = W * CPR / 64;                            // steps per tile
+    static constexpr int S = 64 / W;                                   // lanes per window in the reduction
+    static constexpr int E = CPR / S;                                  // partial sums per lane
+    static constexpr int EP = (E & 1) ? E : E + 1;                     // odd lane stride: conflict-free reads
+    static constexpr int LR = FIRD_R * LT;                             // steps per run
+    static constexpr int U = (LR % 10 == 0) ? 10 : 12;
+    static constexpr int B = U / 2;
+    static constexpr int TS = CPR + 63;
+    static constexpr int NPASS = (CPR + 63) / 64;                      // tap-table columns per lane
+    static constexpr int TAB_BYTES = NPL * TS * 16;
+    static constexpr int P_BYTES = 64 * EP * 8;
+    static constexpr int WAVE_LDS = TAB_BYTES + P_BYTES;
+    static constexpr unsigned int TILE_BYTES = (unsigned int)W * CPR * 16u;     // per plane
+    static_assert((W * CPR) % 64 == 0 && CPR % S == 0 && LR % U == 0 && LR % B == 0 && B <= U, "tile geometry");
+};
+
+template <int FMT, int CPR, int W, int TILE>
+__device__ __forceinline__ void firx_tile(u4v_t* st /* [NLD][U] */, __amdgpu_buffer_rsrc_t cur0, __amdgpu_buffer_rsrc_t cur1,
+                                          __amdgpu_buffer_rsrc_t nxt0, __amdgpu_buffer_rsrc_t nxt1, unsigned int voff, const float4* Tl,
+                                          f2* Pw, const f2* Pr, float* __restrict__ dm_out, int lane, float out_scale)
+{
+    typedef FirX<FMT, CPR, W> F;
+    float4 w[F::NPL], nw[F::NPL];
+#pragma unroll
+    for (int k = 0; k < F::NPL; ++k) w[k] = Tl[k * F::TS];                 // step 0: column of lane 0 is 0
+#pragma unroll
+    for (int q = 0; q < F::LT; ++q) {
+        __builtin_amdgcn_sched_barrier(0);
+        const int p = TILE * F::LT + q;                                    // run position consumed by this step
+        u4v_t d[F::NLD];
+#pragma unroll
+        for (int l = 0; l < F::NLD; ++l) d[l] = st[l * F::U + p % F::U];
+        if (p % F::B == 0) {
+#pragma unroll
+            for (int b = 0; b < F::B; ++b) {
+                const int pos = p + F::U - F::B + b;
+                if (pos < F::LR) {
+                    st[pos % F::U] = fird_load(cur0, voff, (unsigned int)pos * 1024u);
+                    if (F::NLD == 2) st[F::U + pos % F::U] = fird_load(cur1, voff, (unsigned int)pos * 1024u);
+                } else {
+                    st[pos % F::U] = fird_load(nxt0, voff, (unsigned int)(pos - F::LR) * 1024u);
+                    if (F::NLD == 2) st[F::U + pos % F::U] = fird_load(nxt1, voff, (unsigned int)(pos - F::LR) * 1024u);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < F::NPL; ++k) nw[k] = w[k];
+        if (q + 1 < F::LT) {
+            const int c1 = ((q + 1) * 64) % CPR;
+#pragma unroll
+            for (int k = 0; k < F::NPL; ++k) nw[k] = Tl[k * F::TS + c1];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float wf[4 * F::NPL];
+#pragma unroll
+        for (int k = 0; k < F::NPL; ++k) { wf[4 * k] = w[k].x; wf[4 * k + 1] = w[k].y; wf[4 * k + 2] = w[k].z; wf[4 * k + 3] = w[k].w; }
+        f2 accA = {0.f, 0.f}, accB = {0.f, 0.f};
+        f2 part;
+        if (FMT == FMT_CS16) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f2 tt;
+                tt.x = (float)(short)(d[0][j] & 0xffffu);                  // soapy.c:238
+                tt.y = (float)((int)d[0][j] >> 16);                        // soapy.c:239
+                const f2 wv = {wf[2 * j], wf[2 * j + 1]};
+                const f2 ws = {wf[2 * j + 1], wf[2 * j]};
+                accA = __builtin_elementwise_fma(tt, wv, accA);
+                accB = __builtin_elementwise_fma(tt, ws, accB);
+            }
+            part = {accA.x - accA.y, accB.x + accB.y};
+        } else if (FMT == FMT_SPLIT) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned int wi_ = d[0][j >> 1], wq_ = d[F::NLD - 1][j >> 1];
+                f2 tt;
+                tt.x = (j & 1) ? (float)((int)wi_ >> 16) : (float)(short)(wi_ & 0xffffu);     // sdrplay.c:219
+                tt.y = (j & 1) ? (float)((int)wq_ >> 16) : (float)(short)(wq_ & 0xffffu);     // sdrplay.c:220
+                const f2 wv = {wf[2 * j], wf[2 * j + 1]};
+                const f2 ws = {wf[2 * j + 1], wf[2 * j]};
+                accA = __builtin_elementwise_fma(tt, wv, accA);
+                accB = __builtin_elementwise_fma(tt, ws, accB);
+            }
+            part = {accA.x - accA.y, accB.x + accB.y};
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float sv = __uint_as_float(d[0][j]);
+                const f2 tt = {sv, sv};                                    // air.c:315-316: wf[i] * S
+                const f2 wv = {wf[2 * j], wf[2 * j + 1]};
+                accA = __builtin_elementwise_fma(tt, wv, accA);
+            }
+            part = accA;
+        }
+        if (F::EP == F::E) {
+            Pw[q * 64] = part;
+        } else {
+            const unsigned int i = (unsigned int)(q * 64 + lane);
+            const unsigned int r = (i * ((65536u + F::E - 1) / F::E)) >> 16;           // i / E for i < 64 * E <= 4096
+            Pw[q * 64 + (int)r] = part;
+        }
+#pragma unroll
+        for (int k = 0; k < F::NPL; ++k) w[k] = nw[k];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // lane l adds entries l * E .. l * E + E - 1 (window l / S, its (l % S)-th part); S adjacent lanes meet
+    f2 D = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < F::E; ++j) D = D + Pr[j];
+#pragma unroll
+    for (int m = 1; m < F::S; m <<= 1) {
+        D.x += __shfl_xor(D.x, m);
+        D.y += __shfl_xor(D.y, m);
+    }
+    // power-of-two output scale (1/32768 soapy.c:241, 1/4 sdrplay.c:225): exact, commutes with cabsf
+    if (lane % F::S == 0) dm_out[lane / F::S] = cabs_like_glibc(D.x, D.y) * out_scale;
+}
+
+template <int FMT, int CPR, int W>
+__global__ __launch_bounds__(ACG_WG_FIR) void fir_fmt_direct_kernel(const FirArgs a, const uint8_t* __restrict__ in_base,
+                                                                     const float* __restrict__ taps_base,
+                                                                     const int* __restrict__ stream_of, float* __restrict__ dm_base)
+{
+    typedef FirX<FMT, CPR, W> F;
+    constexpr unsigned int NONE = 0xffffffffu;
+    if (a.high_prio) __builtin_amdgcn_s_setprio(2);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned char* my = fir_smem + wave * F::WAVE_LDS;
+    float4* T = (float4*)my;
+    f2* P = (f2*)(my + F::TAB_BYTES);
+    const float4* Tl = T + lane;
+    f2* Pw = P + lane;
+    const f2* Pr = P + lane * F::EP;
+
+    const unsigned int ntile = (unsigned int)a.nwin / W;                            // whole tiles only (launcher)
+    const unsigned int runs_per_ch = ntile / FIRD_R;
+    const unsigned int nrun = (unsigned int)a.nch * runs_per_ch;
+    const unsigned int nwaves = gridDim.x * (ACG_WG_FIR / 64);
+    const unsigned int wg = blockIdx.x * (ACG_WG_FIR / 64) + (unsigned int)wave;
+    unsigned int* ctr = a.work_counter;
+    constexpr unsigned int run_bytes = FIRD_R * F::TILE_BYTES;
+    const unsigned int voff = (unsigned int)lane << 4;
+    const int nck = a.ntaps_pad / F::SPC;                                           // tap columns that carry taps
+
+    auto shard_runs = [&](unsigned int s) { return (nrun + ACG_DISP_SHARDS - 1 - s) / ACG_DISP_SHARDS; };
+    auto shard_static = [&](unsigned int s) { return (nwaves + ACG_DISP_SHARDS - 1 - s) / ACG_DISP_SHARDS; };
+    auto run_of_ticket = [&](unsigned int s, unsigned int t) -> unsigned int {
+        const unsigned long long k = (unsigned long long)shard_static(s) + t;
+        return k < shard_runs(s) ? (unsigned int)k * ACG_DISP_SHARDS + s : NONE;
+    };
+    auto probe = [&](unsigned int& s) -> unsigned int {
+        for (int k = 0; k < ACG_DISP_SHARDS; ++k) {
+            unsigned int t = 0;
+            if (lane == 0) t = __hip_atomic_fetch_add(ctr + s * ACG_DISP_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+            const unsigned int r = run_of_ticket(s, t);
+            if (r != NONE) return r;
+            s = (s + 1 == ACG_DISP_SHARDS) ? 0 : s + 1;
+        }
+        return NONE;
+    };
+    auto sign_off = [&]() {
+        if (lane == 0) {
+            const unsigned int d = atomicAdd(ctr + ACG_DISP_SHARDS * ACG_DISP_STRIDE, 1u);
+            if (d == nwaves - 1) {
+#pragma unroll
+                for (int k = 0; k <= ACG_DISP_SHARDS; ++k)
+                    __hip_atomic_store(ctr + k * ACG_DISP_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+    auto run_base = [&](unsigned int run, unsigned int& ch, unsigned int& t0) -> const uint8_t* {
+        ch = run / runs_per_ch;
+        t0 = (run - ch * runs_per_ch) * FIRD_R;
+        return in_base + (size_t)stream_of[ch] * a.pitch + (size_t)t0 * F::TILE_BYTES;
+    };
+    // taps of channel ch: lane takes columns lane, lane + 64, ... (16 * NPL bytes each)
+    auto fetch_taps = [&](unsigned int ch, float4 (&tp)[F::NPASS][F::NPL]) {
+#pragma unroll
+        for (int ps = 0; ps < F::NPASS; ++ps) {
+            const int col = lane + 64 * ps;
+            const float4* src = (const float4*)(taps_base + (size_t)ch * a.ntaps_pad * 2) + (col < nck ? col : 0) * F::NPL;
+#pragma unroll
+            for (int k = 0; k < F::NPL; ++k) tp[ps][k] = src[k];
+        }
+    };
+    auto write_taps = [&](const float4 (&tp)[F::NPASS][F::NPL]) {
+#pragma unroll
+        for (int ps = 0; ps < F::NPASS; ++ps) {
+            const int col = lane + 64 * ps;
+            const bool on = col < nck;
+#pragma unroll
+            for (int rep = 0; rep * CPR < F::TS; ++rep) {
+                const int u = col + rep * CPR;
+                if (col < CPR && u < F::TS) {
+#pragma unroll
+                    for (int k = 0; k < F::NPL; ++k) T[k * F::TS + u] = on ? tp[ps][k] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        }
+    };
+
+    unsigned int s = wg % ACG_DISP_SHARDS;
+    unsigned int run = wg < nrun ? wg : NONE;
+    if (run == NONE) {
+        s = (s + 1 == ACG_DISP_SHARDS) ? 0 : s + 1;
+        run = probe(s);
+    }
+    if (run == NONE) { sign_off(); return; }
+
+    unsigned int ch, t0;
+    const uint8_t* base = run_base(run, ch, t0);
+    {
+        float4 tp[F::NPASS][F::NPL];
+        fetch_taps(ch, tp);
+        write_taps(tp);
+    }
+    __amdgpu_buffer_rsrc_t cur0 = fird_rsrc(base, run_bytes);
+    __amdgpu_buffer_rsrc_t cur1 = fird_rsrc(base + (F::NLD == 2 ? a.plane : 0), run_bytes);
+    u4v_t st[F::NLD * F::U];
+#pragma unroll
+    for (int i = 0; i < F::U - F::B; ++i) {
+        st[i] = fird_load(cur0, voff, (unsigned int)i * 1024u);
+        if (F::NLD == 2) st[F::U + i] = fird_load(cur1, voff, (unsigned int)i * 1024u);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    for (;;) {
+        unsigned int tk;
+        if (lane == 0) ticket_request(ctr + s * ACG_DISP_STRIDE, tk);
+        float* __restrict__ dm_out = dm_base + (size_t)ch * a.dm_pitch + (size_t)t0 * W;
+        static_assert(FIRD_R == 2, "the run is unrolled by hand: first tile, last tile");
+        firx_tile<FMT, CPR, W, 0>(st, cur0, cur1, cur0, cur1, voff, Tl, Pw, Pr, dm_out, lane, a.out_scale);
+        unsigned int nrun_ = run_of_ticket(s, ticket_take<F::NLD * F::U + 1>(tk));
+        if (nrun_ == NONE) {
+            s = (s + 1 == ACG_DISP_SHARDS) ? 0 : s + 1;
+            nrun_ = probe(s);
+        }
+        const bool has_next = nrun_ != NONE;
+        unsigned int nch_ = ch, nt0 = t0;
+        const uint8_t* nbase = base;
+        if (has_next) nbase = run_base(nrun_, nch_, nt0);
+        const __amdgpu_buffer_rsrc_t nxt0 = fird_rsrc(nbase, has_next ? run_bytes : 0u);
+        const __amdgpu_buffer_rsrc_t nxt1 = fird_rsrc(nbase + (F::NLD == 2 ? a.plane : 0), has_next ? run_bytes : 0u);
+        float4 tp[F::NPASS][F::NPL];
+        fetch_taps(nch_, tp);
+        firx_tile<FMT, CPR, W, 1>(st, cur0, cur1, nxt0, nxt1, voff, Tl, Pw, Pr, dm_out + W, lane, a.out_scale);
+        if (!has_next) break;
+        write_taps(tp);
+        run = nrun_;
+        ch = nch_;
+        t0 = nt0;
+        base = nbase;
+        cur0 = nxt0;
+        cur1 = nxt1;
+    }
+    sign_off();
+}
+
 // Launch-side state is per DEVICE (function attributes belong to the device's code object; the CU count is
 // the device's): a process may hold contexts on several GPUs.
 #define FIR_MAXDEV 64
@@ -1142,6 +1418,11 @@ static int fir_device(FirDev** out)
             {(const void*)fir_u8_direct_kernel<25, 25, 5>, 4 * FirD<25>::WAVE_LDS},
             {(const void*)fir_u8_direct_kernel<25, 25, 10>, 4 * FirD<25>::WAVE_LDS},
             {(const void*)fir_u8_direct_kernel<25, 10, 10>, 4 * FirD<25>::WAVE_LDS},
+#define FIRX_ATTR(F_, C_, W_) {(const void*)fir_fmt_direct_kernel<F_, C_, W_>, 4 * FirX<F_, C_, W_>::WAVE_LDS},
+            FIRX_ATTR(FMT_CS16, 40, 32) FIRX_ATTR(FMT_CS16, 48, 32) FIRX_ATTR(FMT_CS16, 50, 32)
+            FIRX_ATTR(FMT_F32R, 50, 32) FIRX_ATTR(FMT_F32R, 60, 16) FIRX_ATTR(FMT_F32R, 120, 8) FIRX_ATTR(FMT_F32R, 200, 8)
+            FIRX_ATTR(FMT_SPLIT, 20, 64)
+#undef FIRX_ATTR
         };
         for (const auto& at : attrs) {
             e = hipFuncSetAttribute(at.f, hipFuncAttributeMaxDynamicSharedMemorySize, at.bytes);
@@ -1161,12 +1442,42 @@ static int env_int(const char* name, int dflt)
     return v ? atoi(v) : dflt;
 }
 
+template <int FMT, int CPR, int W>
+static int launch_fmt_direct(const FirArgs* a, int num_cu, hipStream_t stream)
+{
+    typedef FirX<FMT, CPR, W> F;
+    const size_t lds = (size_t)(ACG_WG_FIR / 64) * F::WAVE_LDS;
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 2) per_cu = 2;
+    if (per_cu < 1) return (int)hipErrorInvalidValue;
+    per_cu = env_int("ACG_FIR_WG_PER_CU", per_cu);
+    const long long nrun = (long long)a->nch * (a->nwin / W / FIRD_R);
+    long long grid = (long long)(a->ncu > 0 ? a->ncu : num_cu) * per_cu;
+    const long long need = (nrun + ACG_WG_FIR / 64 - 1) / (ACG_WG_FIR / 64);
+    if (grid > need) grid = need;
+    hipLaunchKernelGGL((fir_fmt_direct_kernel<FMT, CPR, W>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds, stream, *a, a->iq, a->taps,
+                       a->stream_of, a->dm);
+    return (int)hipGetLastError();
+}
+
 extern "C" int acg_launch_fir_fmt(const FirArgs* a, int fmt, void* stream)
 {
     const size_t lds = (size_t)ACG_TILE_WIN * a->row_stride + 4 * 64 * sizeof(float4);
     FirDev* fd = nullptr;
     if (int e = fir_device(&fd)) return e;
     const int num_cu = fd->num_cu;
+    // the wave-private streaming kernel where it is instantiated for the window length and the launch is whole runs
+    // (ACG_FIR_VARIANT=3 forces the workgroup-granular kernel below)
+    if (env_int("ACG_FIR_VARIANT", 5) >= 5 && a->nwin > 0 && (long long)a->nch * a->nwin < (1ll << 31)) {
+        const int cprw = a->cpr_total;                              // 16-byte chunks per window (per plane for split int16)
+#define FIRX_TRY(F_, C_, W_) \
+        if (fmt == F_ && (F_ == FMT_SPLIT ? cprw / 2 : cprw) == C_ && a->nwin % (W_ * FIRD_R) == 0) \
+            return launch_fmt_direct<F_, C_, W_>(a, num_cu, (hipStream_t)stream);
+        FIRX_TRY(FMT_CS16, 40, 32) FIRX_TRY(FMT_CS16, 48, 32) FIRX_TRY(FMT_CS16, 50, 32)
+        FIRX_TRY(FMT_F32R, 50, 32) FIRX_TRY(FMT_F32R, 60, 16) FIRX_TRY(FMT_F32R, 120, 8) FIRX_TRY(FMT_F32R, 200, 8)
+        FIRX_TRY(FMT_SPLIT, 20, 64)
+#undef FIRX_TRY
+    }
     if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 4) per_cu = 4;
