@@ -413,8 +413,9 @@ def assert_state_close(got, want, what):
     """The loop's continuous state against the reference's.  The device differs from glibc only in the last bit of
     the mixer's f64 sin/cos (< 1 ulp, and only the float-rounded product is kept, msk.c:90): a product moves by one
     f32 ulp about once in 2^29 samples, which the PLL (a contraction, msk.c:130) forgets within a few bits.  So the
-    state agrees far below the soft-symbol tolerance: MskDf 1e-6, MskClk (f32, up to 3*pi/2: ulp 4.8e-7) and
-    MskPhi (mod 2*pi) 1e-5.  The largest deviation seen is appended to gpurun_out/state_deviation.txt."""
+    state agrees far below the soft-symbol tolerance: MskDf 1e-9, MskClk (f32, up to 3*pi/2: two ulps = 1e-6) and
+    MskPhi (mod 2*pi) 1e-9.  Every deviation seen so far is exactly 0 (they are appended to
+    gpurun_out/state_deviation.txt)."""
     ddf = abs(got["MskDf"] - want["MskDf"])
     dclk = abs(got["MskClk"] - want["MskClk"])
     dphi = abs(got["MskPhi"] - want["MskPhi"])
@@ -425,7 +426,7 @@ def assert_state_close(got, want, what):
             f.write("%s dDf=%.3e dClk=%.3e dPhi=%.3e\n" % (what, ddf, dclk, dphi))
     except OSError:
         pass
-    assert ddf < 1e-6 and dclk < 1e-5 and dphi < 1e-5, (what, ddf, dclk, dphi)
+    assert ddf < 1e-9 and dclk < 1e-6 and dphi < 1e-9, (what, ddf, dclk, dphi)
 
 
 def test_msk_matches_oracle_noise_and_silence(D, O):
