@@ -98,6 +98,7 @@ struct FirArgs {
     unsigned int* work_counter; // run dispenser of the dynamically scheduled kernels (ACG_DISP_WORDS words per launch in flight)
     int stream_identity;        // stream_of[ch] == ch for every channel: the row base needs no lookup
     int high_prio;              // wave-private kernel: raise the wave priority (the demodulator shares its CUs and has slack)
+    int run_pairs;              // wave-private kernel: two-tile bodies per dispensed run (set by the launcher)
 };
 
 // Run dispenser of one launch in flight: words [0], [1] = {tickets, finished} of the workgroup-granular

@@ -798,14 +798,18 @@ __device__ __forceinline__ void fird_body(const FirArgs& a, const uint8_t* __res
     f2* Pw = P + lane;                                             // + 64 q entries
     const f2* Pr = P + lane * F::PW;
 
+    // A run is `pairs` consecutive two-tile bodies of one channel (launcher: 1 for small launches, up to 8 for large
+    // ones, so that every wave still gets ~32 runs): the per-run work (ticket, row lookup, tap table) is paid once per run.
+    const unsigned int pairs = (unsigned int)a.run_pairs;
     const unsigned int ntile = (unsigned int)a.nwin / ACG_TILE_WIN;                 // whole tiles only (launcher)
-    const unsigned int runs_per_ch = ntile / FIRD_R;                                // ntile % FIRD_R == 0 (launcher)
+    const unsigned int runs_per_ch = ntile / (FIRD_R * pairs);                      // ntile % (FIRD_R * pairs) == 0 (launcher)
     const unsigned int nrun = (unsigned int)a.nch * runs_per_ch;
-    const unsigned int nwaves = gridDim.x * (ACG_WG_FIR / 64);
-    const unsigned int wg = blockIdx.x * (ACG_WG_FIR / 64) + (unsigned int)wave;
+    const unsigned int wpg = blockDim.x >> 6;                                       // the waves of a workgroup never talk to each other
+    const unsigned int nwaves = gridDim.x * wpg;
+    const unsigned int wg = blockIdx.x * wpg + (unsigned int)wave;
     unsigned int* ctr = a.work_counter;
     constexpr unsigned int tile_bytes = (unsigned int)CPR * 1024u;
-    constexpr unsigned int run_bytes = FIRD_R * tile_bytes;
+    constexpr unsigned int run_bytes = FIRD_R * tile_bytes;                         // bytes of one two-tile body
     const unsigned int voff = (unsigned int)lane << 4;
     const int nck = a.ntaps_pad >> 3;                                               // tap columns that carry taps
 
@@ -842,7 +846,7 @@ __device__ __forceinline__ void fird_body(const FirArgs& a, const uint8_t* __res
     };
     auto run_base = [&](unsigned int run, unsigned int& ch, unsigned int& t0) -> const uint8_t* {
         ch = run / runs_per_ch;
-        t0 = (run - ch * runs_per_ch) * FIRD_R;
+        t0 = (run - ch * runs_per_ch) * FIRD_R * pairs;
         const size_t row = (size_t)(a.stream_identity ? (int)ch : stream_of[ch]) * a.pitch;
         return iq_base + row + (size_t)t0 * tile_bytes;
     };
@@ -889,33 +893,41 @@ __device__ __forceinline__ void fird_body(const FirArgs& a, const uint8_t* __res
     }
 
     for (;;) {
-        // ask for the run after this one now; the answer is looked at a tile later
+        // ask for the run after this one now; the answer is looked at in the run's last body, at least a tile later
         unsigned int tk;
         if (lane == 0) ticket_request(ctr + s * ACG_DISP_STRIDE, tk);
         float* __restrict__ dm_out = dm_base + (size_t)ch * a.dm_pitch + (size_t)t0 * ACG_TILE_WIN;
-        static_assert(FIRD_R == 2, "the run is unrolled by hand: first tile, last tile");
-        fird_tile<CPR, UU, BB, 0>(st, cur, cur, voff, Tl, Pw, Pr, dm_out, lane);
-        // last tile of the run: where does the stream go next?  (U loads and a store are in flight, all younger than the ticket)
-        unsigned int nrun_ = run_of_ticket(s, ticket_take<F::U + 1>(tk));   // + the dm store of the first tile
-        if (nrun_ == NONE) {
-            s = (s + 1 == ACG_DISP_SHARDS) ? 0 : s + 1;
-            nrun_ = probe(s);
-        }
-        const bool has_next = nrun_ != NONE;
-        unsigned int nch_ = ch, nt0 = t0;
-        const uint8_t* nbase = base;
-        if (has_next) nbase = run_base(nrun_, nch_, nt0);
-        const __amdgpu_buffer_rsrc_t nxt = fird_rsrc(nbase, has_next ? run_bytes : 0u);
+        static_assert(FIRD_R == 2, "a body is unrolled by hand: first tile, second tile");
+        bool has_next = true;
+        unsigned int nrun_ = NONE, nch_ = ch, nt0 = t0;
         float4 tp[4];
-        fetch_taps(nch_, tp);
-        fird_tile<CPR, UU, BB, 1>(st, cur, nxt, voff, Tl, Pw, Pr, dm_out + ACG_TILE_WIN, lane);
+        for (unsigned int j = 0; j < pairs; ++j) {
+            fird_tile<CPR, UU, BB, 0>(st, cur, cur, voff, Tl, Pw, Pr, dm_out, lane);
+            // second tile of the body: where does the stream go next?
+            const uint8_t* nbase = base + run_bytes;                // the next body of this run ...
+            if (j + 1 == pairs) {                                   // ... or the first body of the next run
+                // (U loads and a store are in flight, all younger than the ticket)
+                nrun_ = run_of_ticket(s, ticket_take<F::U + 1>(tk));
+                if (nrun_ == NONE) {
+                    s = (s + 1 == ACG_DISP_SHARDS) ? 0 : s + 1;
+                    nrun_ = probe(s);
+                }
+                has_next = nrun_ != NONE;
+                nbase = base;
+                if (has_next) nbase = run_base(nrun_, nch_, nt0);
+                fetch_taps(nch_, tp);
+            }
+            const __amdgpu_buffer_rsrc_t nxt = fird_rsrc(nbase, has_next ? run_bytes : 0u);
+            fird_tile<CPR, UU, BB, 1>(st, cur, nxt, voff, Tl, Pw, Pr, dm_out + ACG_TILE_WIN, lane);
+            dm_out += FIRD_R * ACG_TILE_WIN;
+            base = nbase;
+            cur = nxt;
+        }
         if (!has_next) break;
         write_taps(tp);
         run = nrun_;
         ch = nch_;
         t0 = nt0;
-        base = nbase;
-        cur = nxt;
     }
     sign_off();
 }
@@ -1532,15 +1544,30 @@ extern "C" size_t acg_fir_lds_bytes(const FirArgs* a)
 template <int CPR, int UU = 0, int BB = 0>
 static int launch_direct(const FirArgs* a, int num_cu, hipStream_t stream)
 {
-    const size_t lds = (size_t)(ACG_WG_FIR / 64) * FirD<CPR>::WAVE_LDS;
+    // The waves of a workgroup are independent, so the workgroup size only decides in what pieces LDS is handed out
+    // (ACG_FIR_WAVES_PER_WG = 1, 2, 4).  Four measured best alone (+5 % over single-wave workgroups at 16 384
+    // channels) and within noise of the others beside the demodulator.  At most 8 waves per CU (2 per SIMD).
+    int wpg = env_int("ACG_FIR_WAVES_PER_WG", 4);
+    if (wpg != 1 && wpg != 2 && wpg != 4) wpg = 4;
+    const size_t lds = (size_t)wpg * FirD<CPR>::WAVE_LDS;
     int per_cu = (int)((160 * 1024) / lds);
-    if (per_cu > 2) per_cu = 2;
+    if (per_cu > 8 / wpg) per_cu = 8 / wpg;
     per_cu = env_int("ACG_FIR_WG_PER_CU", per_cu);
-    const long long nrun = (long long)a->nch * (a->nwin / ACG_TILE_WIN / FIRD_R);
     long long grid = (long long)(a->ncu > 0 ? a->ncu : num_cu) * per_cu;
-    const long long need = (nrun + ACG_WG_FIR / 64 - 1) / (ACG_WG_FIR / 64);
+    // two-tile bodies per run: as many (1, 2, 4, 8) as leave every resident wave ~32 runs (the tail of the launch is
+    // one run long) and divide the bodies of a channel
+    const long long bodies_per_ch = a->nwin / ACG_TILE_WIN / FIRD_R;
+    const long long bodies = (long long)a->nch * bodies_per_ch;
+    int pairs = 1;
+    while (pairs < 8 && bodies_per_ch % (2 * pairs) == 0 && bodies / (2 * pairs) >= 32 * grid * wpg) pairs *= 2;
+    pairs = env_int("ACG_FIR_RUN_PAIRS", pairs);
+    if (pairs < 1 || bodies_per_ch % pairs) pairs = 1;
+    const long long nrun = bodies / pairs;
+    const long long need = (nrun + wpg - 1) / wpg;
     if (grid > need) grid = need;
-    hipLaunchKernelGGL((fir_u8_direct_kernel<CPR, UU, BB>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds, stream, *a, a->iq, a->taps,
+    FirArgs b = *a;
+    b.run_pairs = pairs;
+    hipLaunchKernelGGL((fir_u8_direct_kernel<CPR, UU, BB>), dim3((unsigned int)grid), dim3(64 * wpg), lds, stream, b, a->iq, a->taps,
                        a->stream_of, a->dm);
     return (int)hipGetLastError();
 }
