@@ -443,7 +443,7 @@ static void begin_dm(acg_ctx* ctx)
     ctx->gbase = ctx->dm_par * ctx->cfg.max_blocks;
 }
 
-static int launch_fir(acg_ctx* c, const uint8_t* iq_dev, size_t pitch, int nblocks, hipStream_t s, int block0 = 0)
+static int launch_fir(acg_ctx* c, const uint8_t* iq_dev, size_t pitch, int nblocks, hipStream_t s, int block0 = 0, bool with_demod = true)
 {
     const acg_config& g = c->cfg;
     FirArgs a{};
@@ -464,6 +464,7 @@ static int launch_fir(acg_ctx* c, const uint8_t* iq_dev, size_t pitch, int nbloc
     // channels: +5 % whole job; at 4096 channels the two stages are about equally long and the raise costs 15 %)
     a.high_prio = (!c->fir_stream && g.nch >= 8192) ? 1 : 0;
     if (const char* e = std::getenv("ACG_FIR_PRIO")) a.high_prio = std::atoi(e) ? 1 : 0;
+    a.shares_cus = (with_demod && !c->fir_stream) ? 1 : 0;
     // few channels: the demodulator's serial chain is the critical path; three resident workgroups per CU
     // cost the down-converter ~5 % of its bandwidth and give the demodulator waves ~10 % (whole job +5 %)
     a.wg_per_cu = (c->msk_high_prio && !c->fir_stream) ? 3 : 0;
@@ -582,7 +583,7 @@ extern "C" int acg_fir_only_dev(acg_ctx* ctx, const uint8_t* iq_dev, size_t pitc
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : ctx->stream;
     begin_dm(ctx);
     if ((r = guard_wait(ctx, s, 0, nblocks)) != ACG_OK) return r;
-    r = launch_fir(ctx, iq_dev, pitch_bytes, nblocks, s);
+    r = launch_fir(ctx, iq_dev, pitch_bytes, nblocks, s, 0, false);
     if (r == ACG_OK) ctx->last_len = nblocks * ACG_BLOCK;
     return r;
 }

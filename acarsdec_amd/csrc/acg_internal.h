@@ -99,6 +99,7 @@ struct FirArgs {
     int stream_identity;        // stream_of[ch] == ch for every channel: the row base needs no lookup
     int high_prio;              // wave-private kernel: raise the wave priority (the demodulator shares its CUs and has slack)
     int run_pairs;              // wave-private kernel: two-tile bodies per dispensed run (set by the launcher)
+    int shares_cus;             // demodulator workgroups run on the same CUs (no CU partition): leave them LDS
 };
 
 // Run dispenser of one launch in flight: words [0], [1] = {tickets, finished} of the workgroup-granular

@@ -1547,11 +1547,15 @@ static int launch_direct(const FirArgs* a, int num_cu, hipStream_t stream)
     // The waves of a workgroup are independent, so the workgroup size only decides in what pieces LDS is handed out
     // (ACG_FIR_WAVES_PER_WG = 1, 2, 4).  Four measured best alone (+5 % over single-wave workgroups at 16 384
     // channels) and within noise of the others beside the demodulator.  At most 8 waves per CU (2 per SIMD).
-    int wpg = env_int("ACG_FIR_WAVES_PER_WG", 4);
+    // Beside demodulator workgroups on the same CUs (no CU partition: > 2048 channels) single-wave workgroups, seven per
+    // CU: the demodulator's LDS (28 KiB per CU at 16 384 channels) then fits next to them instead of keeping a whole
+    // 4-wave workgroup out (+13 % whole job at 4096 channels, +2 % at 16 384).
+    int wpg = env_int("ACG_FIR_WAVES_PER_WG", a->shares_cus ? 1 : 4);
     if (wpg != 1 && wpg != 2 && wpg != 4) wpg = 4;
     const size_t lds = (size_t)wpg * FirD<CPR>::WAVE_LDS;
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 8 / wpg) per_cu = 8 / wpg;
+    if (a->shares_cus && wpg == 1 && per_cu > 7) per_cu = 7;
     per_cu = env_int("ACG_FIR_WG_PER_CU", per_cu);
     long long grid = (long long)(a->ncu > 0 ? a->ncu : num_cu) * per_cu;
     // two-tile bodies per run: as many (1, 2, 4, 8) as leave every resident wave ~32 runs (the tail of the launch is
