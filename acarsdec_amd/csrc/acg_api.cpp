@@ -247,7 +247,15 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
     c->timing_mode = (cfg->flags & ACG_F_TIMING) ? 1 : 0;
     // few channels: the demodulator's serial chain is the critical path -> give its waves CUs of their own
     // (one wave per SIMD), the down-converter keeps the rest (it is HBM-bound and loses nothing)
-    if (cfg->nch <= 2048) c->msk_cus_default = std::max(1, std::min(64, (cfg->nch * c->msk_lpc / 64 + 3) / 4));
+    // Measured (profiles/r02_experiments/bench_variants.txt): the job gets faster as the demodulator's share grows past
+    // the one-wave-per-SIMD minimum n -- 1024 channels (n = 32): 32 CUs 1.13 M, 64: 1.16, 80: 1.17, 96: 1.18 channel*Msps
+    // while the down-converter still reaches 0.75 of the HBM spec on the other 176; 2048 channels (n = 64): 64 CUs 2.03 M,
+    // 128: 2.18 (the demodulator is the longer stage there, and it is bound by the shader clock, which a narrower
+    // streaming stage leaves higher).  So: 2.5 n, at most half the chip.
+    if (cfg->nch <= 2048) {
+        const int need = std::max(1, (cfg->nch * c->msk_lpc / 64 + 3) / 4);
+        c->msk_cus_default = std::min(128, (5 * need + 1) / 2);
+    }
     if (const char* e = std::getenv("ACG_MSK_PRIO")) c->msk_high_prio = std::atoi(e) ? 1 : 0;
     if (const char* e = std::getenv("ACG_MSK_LPC")) {
         const int v = std::atoi(e);

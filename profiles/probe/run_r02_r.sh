@@ -1,0 +1,26 @@
+#!/bin/bash
+O=gpurun_out/r02d
+mkdir -p $O
+export TMPDIR=/tmp
+run() { # label, env..., -- args
+  label=$1; shift
+  envs=()
+  while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
+  env "${envs[@]}" timeout 600 python bench.py --no-cpu-baseline --also none --steps 10 --warmup 2 --check-channels 8 "$@" > $O/$label.json 2> $O/$label.err
+  python - "$label" <<'PY'
+import json, sys
+l = sys.argv[1]
+try:
+    d = json.loads([x for x in open("gpurun_out/r02d/%s.json" % l) if x.startswith("{")][-1])
+    print("%-28s value %9.0f ms/step %8.3f fir_frac %.3f whole %.3f fir_ms %.3f msk_ms %.3f" % (l, d["value"], d["ms_per_step"], d["roofline"]["frac"], d["whole_job_frac_of_hbm"], d["kernels"]["fir_ms_per_step"], d["kernels"]["msk_ms_per_step"]))
+except Exception as e:
+    print(l, "FAILED", e, open("gpurun_out/r02d/%s.err" % l).read()[-300:])
+PY
+}
+run r_head_cb8 -- --config throughput
+run r_head_cb16 -- --config throughput --call-blocks 16
+run r_head_cb4 -- --config throughput --call-blocks 4
+run r_head_cb16_msk28 ACG_MSK_CUS=28 -- --config throughput --call-blocks 16
+run r_head_cb8_msk36 ACG_MSK_CUS=36 -- --config throughput
+run r_wide_cb4 -- --config wide --call-blocks 4
+run r_stress_cb16 -- --config stress --call-blocks 16
