@@ -243,7 +243,7 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
     // demodulator of call i entirely (0 = whole calls).
     c->pipe_blocks = cfg->nch <= 1024 ? 0 : 4;
     if (const char* e = std::getenv("ACG_PIPE_BLOCKS")) c->pipe_blocks = std::max(0, std::atoi(e));
-    c->msk_high_prio = cfg->nch <= 2048 ? 1 : 0;
+    c->msk_high_prio = cfg->nch <= 8192 ? 1 : 0;   // <= 8192: its chain is the longer stage (neutral at 4096, +7 % at 8192)
     c->timing_mode = (cfg->flags & ACG_F_TIMING) ? 1 : 0;
     // few channels: the demodulator's serial chain is the critical path -> give its waves CUs of their own
     // (one wave per SIMD), the down-converter keeps the rest (it is HBM-bound and loses nothing)
@@ -468,14 +468,15 @@ static int launch_fir(acg_ctx* c, const uint8_t* iq_dev, size_t pitch, int nbloc
     a.row_bytes = 2 * g.decim;
     a.work_counter = c->d_work + (size_t)ACG_DISP_WORDS * block0;     // one dispenser per chunk slot
     a.stream_identity = c->stream_identity ? 1 : 0;
-    // >= 8192 channels: both stages share every CU and the down-converter is by far the longer one (measured at 16 384
-    // channels: +5 % whole job; at 4096 channels the two stages are about equally long and the raise costs 15 %)
-    a.high_prio = (!c->fir_stream && g.nch >= 8192) ? 1 : 0;
+    // >= 16 384 channels: both stages share every CU and the down-converter is by far the longer one (+3..5 % whole job
+    // at 16 384 channels).  Below that the starved demodulator becomes the longer stage: 8192 channels lose 7 % with the
+    // raise, 4096 channels 15 % (profiles/r02_experiments/bench_variants.txt, "v_" rows).
+    a.high_prio = (!c->fir_stream && g.nch >= 16384) ? 1 : 0;
     if (const char* e = std::getenv("ACG_FIR_PRIO")) a.high_prio = std::atoi(e) ? 1 : 0;
     a.shares_cus = (with_demod && !c->fir_stream) ? 1 : 0;
     // few channels: the demodulator's serial chain is the critical path; three resident workgroups per CU
     // cost the down-converter ~5 % of its bandwidth and give the demodulator waves ~10 % (whole job +5 %)
-    a.wg_per_cu = (c->msk_high_prio && !c->fir_stream) ? 3 : 0;
+    a.wg_per_cu = (g.nch <= 2048 && c->msk_high_prio && !c->fir_stream) ? 3 : 0;
     if (const char* e = std::getenv("ACG_FIR_WG_HINT")) a.wg_per_cu = std::atoi(e);
     a.ncu = (s == c->fir_stream) ? c->fir_ncu : 0;
     const bool timing = c->timing_mode != 0;

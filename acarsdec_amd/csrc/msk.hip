@@ -268,12 +268,17 @@ __device__ __forceinline__ double wrap_2pi(double p)
 #define STAMP(k) do { } while (0)
 #endif
 
-template <int LPC, int WPG>
+// VEC: the launch's dm rows are 16-byte aligned and len is a multiple of 4 (every in_callback launch): the refill reads
+// 16 bytes per load instead of four clamped words.
+template <int LPC, int WPG, bool VEC>
 __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
 {
     constexpr int CPW = 64 / LPC;                  // channels per wave
     constexpr int SPL = (6 + LPC - 1) / LPC;       // mixer samples per lane per bit period
-    constexpr int WB = 32;                         // dm samples per refill block
+    // dm samples per refill block = how far ahead of its use a block is requested (64 samples = 12 bit periods ~ 10 us:
+    // with 32, a demodulator whose dm comes from HBM beside the streaming down-converter -- calls too large for the
+    // last-level cache -- waited for its refills: 1024 channels, 36 callbacks per call: 1.04 us per bit instead of 0.89)
+    constexpr int WB = LPC >= 4 ? 64 : 32;
     constexpr int SPB = WB / LPC;                  // dm samples per lane per refill
     constexpr int WSTR = 2 * WB + 1;               // odd row stride: conflict-free across channel slots
     // inb[] of the wave's channels, every sample stored twice (k and k+FLEN) so that the 11 taps of
@@ -330,12 +335,24 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
     // on the spot, which would put the whole HBM round trip back on the per-bit chain.  Samples at or
     // beyond len are never consumed, so out-of-range indices are simply clamped into the row.
     const int lim = a.len > 0 ? a.len - 1 : 0;
+    const int lim4 = a.len >= 4 ? a.len - 4 : 0;
+    typedef float f4v __attribute__((ext_vector_type(4)));
     auto fetch_block = [&](int blk) {
         const int base = blk * WB + g * SPB;
+        if constexpr (VEC) {
+            static_assert(SPB % 4 == 0, "refill share of a lane");
 #pragma unroll
-        for (int q = 0; q < SPB; ++q) {
-            const int i = base + q;
-            pend[q] = dm[i < lim ? i : lim];
+            for (int q = 0; q < SPB; q += 4) {
+                const int i = base + q;                    // multiple of 4, like len: a group of 4 never straddles len
+                const f4v v = *(const f4v*)(dm + (i < lim4 ? i : lim4));
+                pend[q] = v.x; pend[q + 1] = v.y; pend[q + 2] = v.z; pend[q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < SPB; ++q) {
+                const int i = base + q;
+                pend[q] = dm[i < lim ? i : lim];
+            }
         }
     };
     auto store_block = [&](int blk) {
@@ -659,14 +676,18 @@ extern "C" int acg_launch_msk(const MskArgs* a, int lpc, void* stream)
     const unsigned int grid = (waves + wpg - 1) / wpg;
     const dim3 blk(64 * wpg);
     hipStream_t s = (hipStream_t)stream;
+    const bool vec = ((uintptr_t)a->dm % 16 == 0) && (a->dm_pitch % 4 == 0) && (a->len % 4 == 0) && !getenv("ACG_MSK_NOVEC");
+#define MSK_LAUNCH(L_, W_) do { if (vec) hipLaunchKernelGGL((msk_demod_kernel<L_, W_, true>), dim3(grid), blk, 0, s, *a); \
+                                else hipLaunchKernelGGL((msk_demod_kernel<L_, W_, false>), dim3(grid), blk, 0, s, *a); } while (0)
     switch (lpc * 16 + wpg) {
-    case 1 * 16 + 1: hipLaunchKernelGGL((msk_demod_kernel<1, 1>), dim3(grid), blk, 0, s, *a); break;
-    case 2 * 16 + 1: hipLaunchKernelGGL((msk_demod_kernel<2, 1>), dim3(grid), blk, 0, s, *a); break;
-    case 4 * 16 + 1: hipLaunchKernelGGL((msk_demod_kernel<4, 1>), dim3(grid), blk, 0, s, *a); break;
-    case 8 * 16 + 1: hipLaunchKernelGGL((msk_demod_kernel<8, 1>), dim3(grid), blk, 0, s, *a); break;
-    case 4 * 16 + 4: hipLaunchKernelGGL((msk_demod_kernel<4, 4>), dim3(grid), blk, 0, s, *a); break;
-    case 8 * 16 + 4: hipLaunchKernelGGL((msk_demod_kernel<8, 4>), dim3(grid), blk, 0, s, *a); break;
+    case 1 * 16 + 1: MSK_LAUNCH(1, 1); break;
+    case 2 * 16 + 1: MSK_LAUNCH(2, 1); break;
+    case 4 * 16 + 1: MSK_LAUNCH(4, 1); break;
+    case 8 * 16 + 1: MSK_LAUNCH(8, 1); break;
+    case 4 * 16 + 4: MSK_LAUNCH(4, 4); break;
+    case 8 * 16 + 4: MSK_LAUNCH(8, 4); break;
     default: return (int)hipErrorInvalidValue;
     }
+#undef MSK_LAUNCH
     return (int)hipGetLastError();
 }

@@ -26,3 +26,5 @@ timeout 300 python profiles/probe/msk_phase_stamps.py 1024 8 > $O/r02_probe_msk_
 timeout 120 ./profiles/probe/front_probe 16 > $O/r02_probe_front.txt 2>&1
 grep -h "fir_u8\|msk_demod" $O/r02_*_stats.txt | cut -c1-64,66-140
 grep -h "fir_u8" $O/r02_*_fetch.txt $O/r02_*_write.txt | grep SIZE | cut -c1-40,64-120
+timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -4 > $O/r02_pytest_gpu.txt; cat $O/r02_pytest_gpu.txt
+[ -x ./profiles/probe/valu_beside_loads_probe ] && timeout 120 ./profiles/probe/valu_beside_loads_probe > $O/r02_probe_valu_beside_loads.txt 2>&1
