@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libacarsdec_amd.so")
+# ACARSDEC_AMD_LIB: measurement aid (A/B timing of two builds on one box, the stamp build); the product is the in-tree path
+LIB_PATH = os.environ.get("ACARSDEC_AMD_LIB") or os.path.join(HERE, "lib", "libacarsdec_amd.so")
 
 OK, EINVAL, ENOMEM, EHIP, ENODEV, EOVERFLOW, ESTATE = 0, -1, -2, -3, -4, -5, -6
 F_BITLOG, F_TIMING, F_REPAIR = 1, 2, 4

@@ -218,7 +218,7 @@ __device__ __forceinline__ double div1_rcp(double n, double d)
 // sqrt(x), correctly rounded, for x = 0 or x in [1e-100, 1e100]: the compiler's own expansion (rsq, one coupled
 // Newton step on (g, h) = (sqrt, 1 / (2 sqrt)), two remainder steps) without the exponent scaling it wraps around
 // it for arguments below 2^-767.  |v|^2 (msk.c:110 through cabsf) is a sum of two squares of floats.
-__device__ __forceinline__ double sqrt_rn_midrange(double x)
+__device__ __forceinline__ double sqrt_rn_positive(double x)
 {
     const double y = __builtin_amdgcn_rsq(x);
     double g = x * y, h = 0.5 * y;
@@ -227,7 +227,21 @@ __device__ __forceinline__ double sqrt_rn_midrange(double x)
     h = __builtin_fma(h, r, h);
     g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
     g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
-    return x == 0.0 ? x : g;
+    return g;
+}
+
+__device__ __forceinline__ double sqrt_rn_midrange(double x)
+{
+    return x == 0.0 ? x : sqrt_rn_positive(x);
+}
+
+// (float)sqrt(x) for x = a*a + b*b of two floats: such an x is 0 or >= 2^-298, and everything below 2^-300 has the float
+// square root 0 -- so the zero case is one v_max_f64 (sqrt(1e-300) = 1e-150 -> 0.0f) instead of compare + two selects,
+// or worse a branch around the Newton steps: any branch inside the bit decision splits its basic block, and each split
+// measured ~3 % per bit (the scheduler fills latency slots only within a block)
+__device__ __forceinline__ float sqrtf_of_sum_of_squares(double x)
+{
+    return (float)sqrt_rn_positive(__builtin_fmax(x, 1e-300));
 }
 
 // msk.c:83 `if (p >= 2*M_PI) p -= 2*M_PI;` as compare + one select + one fma: fma(-1, 2pi, p) is p - 2pi
@@ -268,7 +282,7 @@ __device__ __forceinline__ double wrap_2pi(double p)
 #define STAMP(k) do { } while (0)
 #endif
 
-// VEC: the launch's dm rows are 16-byte aligned and len is a multiple of 4 (every in_callback launch): the refill reads
+// VEC: the launch's dm rows are 16-byte aligned and len is a multiple of 32 (every in_callback launch): the refill reads
 // 16 bytes per load instead of four clamped words.
 template <int LPC, int WPG, bool VEC>
 __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
@@ -280,19 +294,25 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
     // last-level cache -- waited for its refills: 1024 channels, 36 callbacks per call: 1.04 us per bit instead of 0.89)
     constexpr int WB = LPC >= 4 ? 64 : 32;
     constexpr int SPB = WB / LPC;                  // dm samples per lane per refill
-    constexpr int WSTR = 2 * WB + 1;               // odd row stride: conflict-free across channel slots
+    constexpr int WSTR = 2 * WB + 4;               // rows stay 16-byte aligned (b128 refill stores); 4 mod 32 banks apart
     // inb[] of the wave's channels, every sample stored twice (k and k+FLEN) so that the 11 taps of
     // the matched filter are always 11 consecutive rows starting at idx: no wrap, constant offsets
-    __shared__ float2 ring_all[WPG][2 * FLEN][CPW];
-    __shared__ float win_all[WPG][CPW][WSTR];      // sliding window of dm: blocks j and j+1
-    __shared__ float hs[FLEN * MFLTOVER + 1];
+    // one struct = one layout: h[] first, so that its 11 reads h[o + 12 j] are immediate offsets (< 1 KiB) from the one
+    // address o * 4 (placed after the ring, every pair of reads needed its own base register)
+    struct alignas(16) Lds {
+        float hs[(FLEN * MFLTOVER + 1 + 3) & ~3];
+        float2 ring_all[WPG][3 * FLEN + 1][CPW];   // rows 0..21: inb[] twice; rows 22 and 33: where lanes without a sample write
+        float win_all[WPG][CPW][WSTR];             // sliding window of dm: blocks j and j+1
+    };
+    __shared__ Lds lds;
+    float* hs = lds.hs;
 
     for (int i = threadIdx.x; i < FLEN * MFLTOVER + 1; i += 64 * WPG) hs[i] = a.h[i];
 
     const int wv = threadIdx.x >> 6;               // the waves of a workgroup never talk to each other
     const int tid = threadIdx.x & 63;
-    float2 (*ring)[CPW] = ring_all[wv];
-    float (*win)[WSTR] = win_all[wv];
+    float2 (*ring)[CPW] = lds.ring_all[wv];
+    float (*win)[WSTR] = lds.win_all[wv];
     const int slot = tid / LPC;                    // channel slot inside the wave
     const int g = tid - slot * LPC;                // lane inside the group
     const bool leader = g == 0;
@@ -319,7 +339,10 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
     const float* __restrict__ dm = a.dm + (size_t)chc * a.dm_pitch;
     unsigned char* txt = a.txt + (size_t)chc * 256;
     // every lane of a group stores the (identical) bit record and text byte: no exec-mask branches on the per-bit path
-    float2* bits = a.bits ? a.bits + (size_t)chc * a.bit_cap : nullptr;
+    // no bit log: the record goes to one scratch slot in the tail of the text buffer (bytes 248..255; blen <= 241).  A
+    // store that is always there keeps the bit decision one basic block (a branch around it cost 2.7 % per bit)
+    float2* bits = a.bits ? a.bits + (size_t)chc * a.bit_cap : (float2*)(txt + 248);
+    const int bit_cap = a.bits ? a.bit_cap : 1;
     const int len = active ? a.len : 0;
     int nb = (a.bit_append && active) ? a.nbits_out[ch] : 0;
     int n = 0;
@@ -335,16 +358,17 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
     // on the spot, which would put the whole HBM round trip back on the per-bit chain.  Samples at or
     // beyond len are never consumed, so out-of-range indices are simply clamped into the row.
     const int lim = a.len > 0 ? a.len - 1 : 0;
-    const int lim4 = a.len >= 4 ? a.len - 4 : 0;
+    const int limv = a.len >= SPB ? a.len - SPB : 0;
     typedef float f4v __attribute__((ext_vector_type(4)));
     auto fetch_block = [&](int blk) {
         const int base = blk * WB + g * SPB;
         if constexpr (VEC) {
-            static_assert(SPB % 4 == 0, "refill share of a lane");
+            static_assert(SPB % 4 == 0 && SPB <= 32, "refill share of a lane");
+            // len is a multiple of 32 (VEC): a lane's share of a block never straddles len, so one clamp of its start does
+            const f4v* src = (const f4v*)(dm + (base < limv ? base : limv));
 #pragma unroll
             for (int q = 0; q < SPB; q += 4) {
-                const int i = base + q;                    // multiple of 4, like len: a group of 4 never straddles len
-                const f4v v = *(const f4v*)(dm + (i < lim4 ? i : lim4));
+                const f4v v = src[q / 4];
                 pend[q] = v.x; pend[q + 1] = v.y; pend[q + 2] = v.z; pend[q + 3] = v.w;
             }
         } else {
@@ -355,10 +379,12 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
             }
         }
     };
+    // one LDS address per lane, formed once: the two halves of the window are immediate offsets from it
+    f4v* const wrow = (f4v*)&win[slot][g * SPB];
     auto store_block = [&](int blk) {
-        float* w = &win[slot][(blk & 1) * WB + g * SPB];
+        f4v* w = wrow + (blk & 1) * (WB / 4);
 #pragma unroll
-        for (int q = 0; q < SPB; ++q) w[q] = pend[q];
+        for (int q = 0; q < SPB; q += 4) w[q / 4] = f4v{pend[q], pend[q + 1], pend[q + 2], pend[q + 3]};
     };
     fetch_block(0);
     store_block(0);
@@ -366,6 +392,7 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
     store_block(1);
     fetch_block(2);
     int pend_blk = 2;
+    int refill_at = WB;                            // = (pend_blk - 1) * WB: consumption enters the newest block of the window
     __syncthreads();
 
     // few channels: this serial chain is the critical path of the whole job -> win issue arbitration;
@@ -381,9 +408,10 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
         ++stamp_iters;
 #endif
         // ---- window upkeep (rare: once per 32 samples per channel)
-        if (n >= (pend_blk - 1) * WB && n < len) {
+        if (n >= refill_at && n < len) {
             store_block(pend_blk);
             ++pend_blk;
+            refill_at += WB;
             fetch_block(pend_blk);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -398,6 +426,8 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
         const double s = K_VCO + L.df;                                     // msk.c:81
         const double thr = K_3PI2 - s / 2;                                 // msk.c:96
         double myp[SPL];
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) myp[j] = p;
         int cnt = 0;
         bool fired = false;
         // Common case first: a bit period is 5 or 6 samples (the clock advances ~0.905 rad per
@@ -415,7 +445,9 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
             c4 = (float)((double)c4 + s);
             pq[u] = p4;
         }
-        const bool quick = (s > 0) && !((double)c4 >= thr) && (n + 4 <= len);
+        // (six samples left in the buffer: the last few samples of a call go through the one-sample pass, so that the
+        //  fifth step below needs no end-of-buffer predicate on the serial phase / clock chains: 3.5 % per bit)
+        const bool quick = (s > 0) && !((double)c4 >= thr) && (n + 6 <= len);
         if (n < len && quick) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
@@ -423,9 +455,21 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
                 p = p4;
                 L.clk = c4;
                 cnt = 4;
+                {
+                    // the fifth sample always belongs to the period (six samples are left in the buffer)
+                    double pn = p + s;                                     // msk.c:82-83
+                    pn = wrap_2pi(pn);
+                    const float cn = (float)((double)L.clk + s);           // msk.c:95
+                    p = pn;
+                    L.clk = cn;
+                    cnt = 5;
+                    fired = (double)cn >= thr;
+                    if ((4 % LPC) == g) myp[4 / LPC] = pn;
+                }
 #pragma unroll
-                for (int u = 4; u < 6; ++u) {
-                    const bool go = !fired && (n + u < len);
+                for (int u = 5; u < 6; ++u) {
+                    const bool go = !fired;
+
                     double pn = p + s;                                     // msk.c:82-83
                     pn = wrap_2pi(pn);
                     const float cn = (float)((double)L.clk + s);           // msk.c:95
@@ -461,13 +505,19 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
         int o = (int)(MFLTOVER * (div1_rcp((double)clk_f, s) + 0.5));           // msk.c:103
         if (o > MFLTOVER) o = MFLTOVER;
         if (o < 0) o = 0;          // memory safety only: the reference indexes h[] out of bounds here
-        float hv[FLEN];
         typedef float f2v __attribute__((ext_vector_type(2)));
+        // (broadcasting the odd taps out of the high word of their ds_read2 pair with v_pk_mul_f32 op_sel saves five
+        //  v_mov per bit and measured 2 % SLOWER: the moves fill the latency slots of the serial v_pk_add chain)
+#define MSK_TAP(j, x) (f2v{(j & 1) ? hv2[j / 2].y : hv2[j / 2].x, (j & 1) ? hv2[j / 2].y : hv2[j / 2].x} * x)
+        f2v hv2[(FLEN + 1) / 2];                                           // (h[o + 12 j], h[o + 12 (j + 1)]), j even
         f2v acc = {0.f, 0.f};
         {
             const float* hp = &hs[o];
 #pragma unroll
-            for (int j = 0; j < FLEN; ++j) hv[j] = hp[j * MFLTOVER];
+            for (int j = 0; j < FLEN; j += 2) {
+                hv2[j / 2].x = hp[j * MFLTOVER];
+                hv2[j / 2].y = hp[j + 1 < FLEN ? (j + 1) * MFLTOVER : j * MFLTOVER + 1];    // (last pair: the neighbour rides along unused)
+            }
         }
         float2 xo[5];
         {
@@ -480,12 +530,16 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
 #pragma unroll
         for (int j = 0; j < SPL; ++j) {
             const int u = g + j * LPC;
-            if (u < cnt) {
+            {
+                // every lane runs the sin/cos (lanes without a sample of this period on a phase that is lying around) and
+                // only the ring row differs: no branch around the mixer, so it schedules as one block with the tap-phase
+                // divide and the first filter taps around it (0.8 % per bit)
                 double sn, cs;
                 sincos_2pi(myp[j], &sn, &cs);
                 const double in = (double)in_cur[j];
                 unsigned int k = idx + (unsigned int)u;
                 if (k >= FLEN) k -= FLEN;
+                if (u >= cnt) k = 2 * FLEN;
                 const float2 x = make_float2((float)(in * cs), (float)(in * (-sn)));
                 ring[k][slot] = x;
                 ring[k + FLEN][slot] = x;
@@ -498,8 +552,7 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
             const f2v x = {xo[j].x, xo[j].y};
-            const f2v hh = {hv[j], hv[j]};
-            acc = acc + hh * x;
+            acc = acc + MSK_TAP(j, x);
         }
         // one wave per block: LDS operations of a wave execute in order, so the reads below see the
         // writes above; only the compiler has to be told not to move them
@@ -521,8 +574,7 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
 #pragma unroll
                 for (int j = 5; j < FLEN; ++j) {
                     const f2v x = {xs[j - 5].x, xs[j - 5].y};
-                    const f2v hh = {hv[j], hv[j]};
-                    acc = acc + hh * x;
+                    acc = acc + MSK_TAP(j, x);
                 }
             }
             float vr = acc.x, vi = acc.y;
@@ -531,7 +583,7 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
 #endif
             STAMP(3);                                                      // C1: tap phase (f64 divide), ring + h reads, matched filter
             // normalise, msk.c:110-113
-            const float lvl = (float)sqrt_rn_midrange((double)vr * (double)vr + (double)vi * (double)vi);   // cabsf, see fir.hip
+            const float lvl = sqrtf_of_sum_of_squares((double)vr * (double)vr + (double)vi * (double)vi);   // cabsf, see fir.hip
             const double d = (double)lvl + 1e-8;
             // two IEEE quotients over one denominator: the compiler's own f64 division is rcp + two Newton steps on the
             // reciprocal, q0 = n * r, one remainder step q = fma(fma(-d, q0, n), r, q0), wrapped in div_scale / div_fixup
@@ -558,7 +610,7 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
             const unsigned int flip = ((vo >= 0) == odd) ? 0x80000000u : 0u;
             const double dphi = (double)__uint_as_float(__float_as_uint(ot) ^ flip);
             const float sv = __uint_as_float(__float_as_uint(vo) ^ ((L.S & 2u) << 30));   // msk.c:122-126
-            if (bits) bits[nb < a.bit_cap ? nb : a.bit_cap - 1] = make_float2(sv, lvl);     // (bits is wave-uniform; on overflow the last record is the newest bit)
+            bits[nb < bit_cap ? nb : bit_cap - 1] = make_float2(sv, lvl);                  // (no bit log: one scratch record in the text buffer's tail)
             ++nb;
             // putbit, msk.c:53-63
             L.outbits = (L.outbits >> 1) & 0x7fu;
@@ -585,6 +637,8 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
             L.S++;
             STAMP(5);                                                      // C3: decision, bit record, putbit, framing FSM
             // PLL filter, msk.c:130 (float constants promoted to double)
+            // (forming the products ahead -- 0.52 * MskDf at the top of the pass, the dphi term before decodeAcars -- and
+            //  1 / s for the tap phase as soon as s exists: no measurable difference, the chain is bound by issue, not latency)
             L.df = (double)0.52f * L.df + (1.0 - (double)0.52f) * (double)38e-4f * dphi;
 #ifdef ACG_MSK_STAMP
             asm volatile("" : "+v"(L.df));
@@ -676,7 +730,7 @@ extern "C" int acg_launch_msk(const MskArgs* a, int lpc, void* stream)
     const unsigned int grid = (waves + wpg - 1) / wpg;
     const dim3 blk(64 * wpg);
     hipStream_t s = (hipStream_t)stream;
-    const bool vec = ((uintptr_t)a->dm % 16 == 0) && (a->dm_pitch % 4 == 0) && (a->len % 4 == 0) && !getenv("ACG_MSK_NOVEC");
+    const bool vec = ((uintptr_t)a->dm % 16 == 0) && (a->dm_pitch % 4 == 0) && (a->len % 32 == 0) && !getenv("ACG_MSK_NOVEC");
 #define MSK_LAUNCH(L_, W_) do { if (vec) hipLaunchKernelGGL((msk_demod_kernel<L_, W_, true>), dim3(grid), blk, 0, s, *a); \
                                 else hipLaunchKernelGGL((msk_demod_kernel<L_, W_, false>), dim3(grid), blk, 0, s, *a); } while (0)
     switch (lpc * 16 + wpg) {
