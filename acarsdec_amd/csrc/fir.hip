@@ -15,6 +15,7 @@
 //   * the 4 waves split the tap range; partial sums meet in LDS; wave 0 takes |D| and writes 64
 //     consecutive floats of dm.
 #include <hip/hip_runtime.h>
+#include <cstdio>
 #include <stdlib.h>
 #include <type_traits>
 #include "acg_internal.h"
@@ -722,9 +723,15 @@ __device__ __forceinline__ unsigned int ticket_take(unsigned int& ticket)
 // random, and the result changes with every edit.  Inside a step: first the memory instructions whose results are
 // needed LATER (every B-th step the burst of B wave-loads U - B positions ahead, the next step's taps from LDS), then
 // this step's arithmetic on data that arrived long ago.
-template <int CPR, int UU, int BB, int TILE>
+// FOLD: sum (x - 127.37)(w) = sum x w - 127.37 (1 + j) sum w.  The second term is a constant of the channel (dc, formed
+// when the tap table is loaded), so the eight v_pk_add_f32 per 16 input bytes that subtract 127.37 from every sample
+// (a fifth of the loop's vector instructions) become one subtraction per window.  x - 127.37f is exact in f32 either
+// way; what changes is the order of the roundings in the sum, at the 1e-7 level of full scale like any re-association
+// (rtl.c builds with -Ofast and re-associates itself; the parity bar for dm is 1e-5).
+template <int CPR, int UU, int BB, int TILE, bool FOLD>
 __device__ __forceinline__ void fird_tile(u4v_t* st /* [U] */, __amdgpu_buffer_rsrc_t cur, __amdgpu_buffer_rsrc_t nxt,
-                                          unsigned int voff, const float4* Tl, f2* Pw, const f2* Pr, float* __restrict__ dm_out, int lane)
+                                          unsigned int voff, const float4* Tl, f2* Pw, const f2* Pr, float* __restrict__ dm_out, int lane,
+                                          f2 dc)
 {
     typedef FirD<CPR, UU, BB> F;
     float4 w0 = Tl[0 * F::TS], w1 = Tl[1 * F::TS], w2 = Tl[2 * F::TS], w3 = Tl[3 * F::TS];          // step 0: column of lane 0 is 0
@@ -755,8 +762,9 @@ __device__ __forceinline__ void fird_tile(u4v_t* st /* [U] */, __amdgpu_buffer_r
             const unsigned int word = d[j >> 1];
             const unsigned int sh = (j & 1) * 16;
             f2 tt;
-            tt.x = (float)((word >> sh) & 0xffu) - 127.37f;            // rtl.c:338 (exact in f32)
-            tt.y = (float)((word >> (sh + 8)) & 0xffu) - 127.37f;      // rtl.c:339
+            tt.x = (float)((word >> sh) & 0xffu);                      // rtl.c:338 (the conversion and the difference are exact in f32)
+            tt.y = (float)((word >> (sh + 8)) & 0xffu);                // rtl.c:339
+            if (!FOLD) { tt.x -= 127.37f; tt.y -= 127.37f; }
             const f2 wv = {w[2 * j], w[2 * j + 1]};
             const f2 ws = {w[2 * j + 1], w[2 * j]};
             accA = __builtin_elementwise_fma(tt, wv, accA);
@@ -777,10 +785,11 @@ __device__ __forceinline__ void fird_tile(u4v_t* st /* [U] */, __amdgpu_buffer_r
     f2 D = {0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < CPR; ++j) D = D + Pr[j];
+    if (FOLD) D = D - dc;
     dm_out[lane] = cabs_like_glibc(D.x, D.y);
 }
 
-template <int CPR, int UU, int BB>
+template <int CPR, int UU, int BB, bool FOLD>
 __device__ __forceinline__ void fird_body(const FirArgs& a, const uint8_t* __restrict__ iq_base, const float* __restrict__ taps_base,
                                           const int* __restrict__ stream_of, float* __restrict__ dm_base)
 {
@@ -857,8 +866,20 @@ __device__ __forceinline__ void fird_body(const FirArgs& a, const uint8_t* __res
 #pragma unroll
         for (int k = 0; k < 4; ++k) tp[k] = src[k];
     };
+    f2 dc = {0.f, 0.f};                                             // 127.37 (1 + j) sum w of the current run's channel
     auto write_taps = [&](const float4 (&tp)[4]) {
         const bool on = lane < nck;                                 // columns beyond the last tap: zero
+        if (FOLD) {
+            float sr = 0.f, si = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { sr += tp[k].x + tp[k].z; si += tp[k].y + tp[k].w; }
+            sr = on ? sr : 0.f;
+            si = on ? si : 0.f;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) { sr += __shfl_xor(sr, m, 64); si += __shfl_xor(si, m, 64); }
+            dc.x = 127.37f * (sr - si);
+            dc.y = 127.37f * (sr + si);
+        }
 #pragma unroll
         for (int rep = 0; rep * CPR < F::TS; ++rep) {
             const int u = lane + rep * CPR;
@@ -902,7 +923,7 @@ __device__ __forceinline__ void fird_body(const FirArgs& a, const uint8_t* __res
         unsigned int nrun_ = NONE, nch_ = ch, nt0 = t0;
         float4 tp[4];
         for (unsigned int j = 0; j < pairs; ++j) {
-            fird_tile<CPR, UU, BB, 0>(st, cur, cur, voff, Tl, Pw, Pr, dm_out, lane);
+            fird_tile<CPR, UU, BB, 0, FOLD>(st, cur, cur, voff, Tl, Pw, Pr, dm_out, lane, dc);
             // second tile of the body: where does the stream go next?
             const uint8_t* nbase = base + run_bytes;                // the next body of this run ...
             if (j + 1 == pairs) {                                   // ... or the first body of the next run
@@ -918,7 +939,7 @@ __device__ __forceinline__ void fird_body(const FirArgs& a, const uint8_t* __res
                 fetch_taps(nch_, tp);
             }
             const __amdgpu_buffer_rsrc_t nxt = fird_rsrc(nbase, has_next ? run_bytes : 0u);
-            fird_tile<CPR, UU, BB, 1>(st, cur, nxt, voff, Tl, Pw, Pr, dm_out + ACG_TILE_WIN, lane);
+            fird_tile<CPR, UU, BB, 1, FOLD>(st, cur, nxt, voff, Tl, Pw, Pr, dm_out + ACG_TILE_WIN, lane, dc);
             dm_out += FIRD_R * ACG_TILE_WIN;
             base = nbase;
             cur = nxt;
@@ -932,14 +953,14 @@ __device__ __forceinline__ void fird_body(const FirArgs& a, const uint8_t* __res
     sign_off();
 }
 
-template <int CPR, int UU = 0, int BB = 0>
+template <int CPR, int UU = 0, int BB = 0, bool FOLD = true>
 __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_direct_kernel(const FirArgs a,
                                                                     const uint8_t* __restrict__ iq_base,
                                                                     const float* __restrict__ taps_base,
                                                                     const int* __restrict__ stream_of,
                                                                     float* __restrict__ dm_base)
 {
-    fird_body<CPR, UU, BB>(a, iq_base, taps_base, stream_of, dm_base);
+    fird_body<CPR, UU, BB, FOLD>(a, iq_base, taps_base, stream_of, dm_base);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1541,7 +1562,7 @@ extern "C" size_t acg_fir_lds_bytes(const FirArgs* a)
 }
 
 // wave-private streaming kernel: whole tiles, runs inside one channel, a rate it is instantiated for
-template <int CPR, int UU = 0, int BB = 0>
+template <int CPR, int UU = 0, int BB = 0, bool FOLD = true>
 static int launch_direct(const FirArgs* a, int num_cu, hipStream_t stream)
 {
     // The waves of a workgroup are independent, so the workgroup size only decides in what pieces LDS is handed out
@@ -1565,13 +1586,16 @@ static int launch_direct(const FirArgs* a, int num_cu, hipStream_t stream)
     int pairs = 1;
     while (pairs < 8 && bodies_per_ch % (2 * pairs) == 0 && bodies / (2 * pairs) >= 32 * grid * wpg) pairs *= 2;
     pairs = env_int("ACG_FIR_RUN_PAIRS", pairs);
-    if (pairs < 1 || bodies_per_ch % pairs) pairs = 1;
+    if (pairs < 1 || pairs > 8 || (pairs & (pairs - 1)) || bodies_per_ch % pairs) pairs = 1;      // 1, 2, 4 or 8
     const long long nrun = bodies / pairs;
     const long long need = (nrun + wpg - 1) / wpg;
     if (grid > need) grid = need;
     FirArgs b = *a;
     b.run_pairs = pairs;
-    hipLaunchKernelGGL((fir_u8_direct_kernel<CPR, UU, BB>), dim3((unsigned int)grid), dim3(64 * wpg), lds, stream, b, a->iq, a->taps,
+    if (getenv("ACG_FIR_DEBUG_SHAPE"))
+        fprintf(stderr, "fir_u8_direct<%d>: nch %d nwin %d  wpg %d per_cu %d grid %lld  bodies/ch %lld pairs %d runs %lld  shares_cus %d prio %d\n",
+                CPR, a->nch, a->nwin, wpg, per_cu, grid, bodies_per_ch, pairs, nrun, a->shares_cus, a->high_prio);
+    hipLaunchKernelGGL((fir_u8_direct_kernel<CPR, UU, BB, FOLD>), dim3((unsigned int)grid), dim3(64 * wpg), lds, stream, b, a->iq, a->taps,
                        a->stream_of, a->dm);
     return (int)hipGetLastError();
 }
@@ -1586,16 +1610,17 @@ extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
     // segment; 1 / 2 static persistent partition without / with non-temporal loads; 3 workgroup-granular dynamic
     // dispenser; 4 LDS-DMA double buffering
     const int variant = env_int("ACG_FIR_VARIANT", 5);
-    if ((variant == 5 || (variant >= 50 && variant <= 53)) && a->nwin > 0 && a->nwin % ACG_TILE_WIN == 0 && (a->nwin / ACG_TILE_WIN) % FIRD_R == 0 &&
+    if ((variant == 5 || (variant >= 50 && variant <= 54)) && a->nwin > 0 && a->nwin % ACG_TILE_WIN == 0 && (a->nwin / ACG_TILE_WIN) % FIRD_R == 0 &&
         (long long)a->nch * (a->nwin / ACG_TILE_WIN) < (1ll << 31) && a->ntaps_pad <= a->decim) {
         switch (a->cpr) {
         case 20: return launch_direct<20>(a, num_cu, (hipStream_t)stream);
         case 24: return launch_direct<24>(a, num_cu, (hipStream_t)stream);
-        case 25:          // 50..53: measurement knobs (staging slots, burst length)
+        case 25:          // 50..54: measurement knobs (staging slots, burst length, 127.37 per sample)
             if (variant == 50) return launch_direct<25, 10, 1>(a, num_cu, (hipStream_t)stream);
             if (variant == 51) return launch_direct<25, 25, 5>(a, num_cu, (hipStream_t)stream);
             if (variant == 52) return launch_direct<25, 25, 10>(a, num_cu, (hipStream_t)stream);
             if (variant == 53) return launch_direct<25, 10, 10>(a, num_cu, (hipStream_t)stream);
+            if (variant == 54) return launch_direct<25, 0, 0, false>(a, num_cu, (hipStream_t)stream);      // 127.37 subtracted per sample
             return launch_direct<25>(a, num_cu, (hipStream_t)stream);
         default: break;
         }
