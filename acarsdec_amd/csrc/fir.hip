@@ -964,6 +964,191 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_direct_kernel(const FirArgs
 }
 
 // ---------------------------------------------------------------------------------------------------
+// fir_u8_mfma_kernel<CPR>: the same sums through the matrix pipe -- not for its flop rate (the kernel moves 8 flop
+// per 2 bytes) but for what the arithmetic costs beside a saturated memory path: the wave-private kernel above spends
+// 16 v_cvt + 16 v_pk_fma_f32 per 16 input bytes and sustained runs sit at the package power limit.
+// Here a tile (32 windows x 2M bytes) is parked in LDS as it lies in HBM, lane = window reads its row back 16 bytes
+// at a time (conflict free: 16 lanes x 4 banks at a stride of 25 * 4 dwords), two v_perm_b32 + two v_pk_add_f16 turn 4
+// bytes into (b - 127) as four exact f16, and ONE v_mfma_f32_4x4x4_16b_f16 (16 blocks of 4 x 4 x 4) multiplies the 4
+// bytes of all 64 windows with four columns of the channel's tap table: re and im, each split hi + lo in f16 (22 bits
+// of the f32 tap, scaled by a power of two into f16's range), f32 accumulation.  Per 4 bytes per lane: 1 MFMA + 4 VALU
+// instead of 4 v_cvt + 4 v_pk_fma.  The remaining 0.37 of the 127.37 is the per-channel constant of the fold above.
+//   block b = lane / 4, row i = lane % 4: A[b][i][0..3] = the 4 bytes of window `lane`;
+//   column j = lane % 4: B[.][0..3][j] = (wr, -wi, wr', -wi') hi | (wi, wr, wi', wr') hi | the same lo   (j = 0..3);
+//   D[b][i][j] lands in lane 4 b + j, register i  (profiles/probe/mfma_layout_probe.hip).
+// The next tile's wave-loads wait in registers while this tile is multiplied, then go to LDS.
+// Tile = 32 windows (CPR / 2 KiB, ceil(CPR / 2) wave-loads): lanes 0..31 multiply columns 0 .. NG - 1 of their window,
+// lanes 32..63 columns NG .. 2 NG - 1 of the same windows (a column past the window meets a zero table entry), so all 16
+// blocks of every MFMA work and a wave's LDS stays at ~17 KiB (9 waves per CU keep ~115 KiB per CU in flight).
+template <int CPR>
+struct FirM {
+    static constexpr int WIN = 32;                                 // windows per tile
+    static constexpr int NG = (CPR + 1) / 2;                       // 16-byte column groups per half
+    static constexpr int NLD = (WIN * CPR + 63) / 64;              // wave-loads per tile (the last one may run into the next tile)
+    static constexpr int TILE_BYTES = WIN * CPR * 16;
+    static constexpr int TILE_LDS = NLD * 1024;
+    static constexpr int TAB_BYTES = 2 * NG * 128;                 // [2 NG groups][4 columns][4 steps][4 f16]
+    static constexpr int OUT_BYTES = 2 * WIN * 16;
+    static constexpr int WAVE_LDS = TILE_LDS + TAB_BYTES + OUT_BYTES;
+};
+
+typedef _Float16 h4v_t __attribute__((ext_vector_type(4)));
+typedef _Float16 h2v_t __attribute__((ext_vector_type(2)));
+typedef float f4v_t __attribute__((ext_vector_type(4)));
+
+// bytes (b0, b1) / (b2, b3) of a dword -> packed f16 (b - 127, b' - 127): 0x6400 | b is the f16 1024 + b, exactly
+__device__ __forceinline__ h2v_t firm_pair(unsigned int d, unsigned int sel)
+{
+    const unsigned int biased = __builtin_amdgcn_perm(d, 0x64646464u, sel);
+    union { unsigned int u; h2v_t h; } x;
+    x.u = biased;
+    const h2v_t off = {(_Float16)1151.0f, (_Float16)1151.0f};
+    return x.h - off;
+}
+
+template <int CPR>
+__global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_mfma_kernel(const FirArgs a, const uint8_t* __restrict__ iq_base,
+                                                                  const float* __restrict__ taps_base,
+                                                                  const int* __restrict__ stream_of, float* __restrict__ dm_base)
+{
+    typedef FirM<CPR> F;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned char* my = fir_smem + wave * F::WAVE_LDS;
+    u4v_t* tileL = (u4v_t*)my;                                    // [32 windows][CPR chunks], as in HBM
+    u4v_t* tabL = (u4v_t*)(my + F::TILE_LDS);                     // [2 NG][4][2] x 16 bytes
+    _Float16* tabH = (_Float16*)(my + F::TILE_LDS);
+    float* outL = (float*)(my + F::TILE_LDS + F::TAB_BYTES);      // [2 halves][32 windows][4 columns]
+    const unsigned int wpg = blockDim.x >> 6;
+    const unsigned int nwaves = gridDim.x * wpg;
+    const unsigned int wg = blockIdx.x * wpg + (unsigned int)wave;
+    const unsigned int ntile = (unsigned int)a.nwin / F::WIN;                       // 32-window tiles (nwin is a multiple of 128: launcher)
+    const unsigned int tiles_per_run = (unsigned int)a.run_pairs * FIRD_R * (ACG_TILE_WIN / F::WIN);
+    const unsigned int runs_per_ch = ntile / tiles_per_run;
+    const unsigned int nrun = (unsigned int)a.nch * runs_per_ch;
+    const unsigned int voff = (unsigned int)lane << 4;
+    const int j = lane & 3;
+    const int half = lane >> 5;
+    const u4v_t* rowL = tileL + (lane & 31) * CPR + half * F::NG;                   // this lane's window, this half's first column
+    const u4v_t* tabR = tabL + (half * F::NG * 4 + j) * 2;
+
+    // two tiles wait in registers: while tile t is multiplied, t + 1 has landed or is landing and t + 2 is being asked for,
+    // so the wave always has a tile's worth of loads in the memory system
+    u4v_t stA[F::NLD], stB[F::NLD];
+    auto tile_step = [&](u4v_t (&st)[F::NLD], unsigned int t, unsigned int tiles_per_run_, __amdgpu_buffer_rsrc_t rs, float* __restrict__ dm_out,
+                         float inv_scale, f2 dc) {
+        // ---- this tile: registers -> LDS (as it lies in memory), then ask for the tile after the next one
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int p = 0; p < F::NLD; ++p) tileL[p * 64 + lane] = st[p];
+#pragma unroll
+        for (int p = 0; p < F::NLD; ++p)                            // beyond the run: the descriptor returns zeros without touching memory
+            st[p] = fird_load(rs, voff, (t + 2) * (unsigned int)F::TILE_BYTES + (unsigned int)p * 1024u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- 4 * NG matrix steps
+        f4v_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < F::NG; ++g) {
+            const u4v_t d = rowL[g];
+            const u4v_t b01 = tabR[g * 8 + 0];                                  // steps 0, 1 of the group: 2 x 4 f16
+            const u4v_t b23 = tabR[g * 8 + 1];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                union { h2v_t h[2]; h4v_t v; } A;
+                A.h[0] = firm_pair(d[r], 0x00050004u);                          // bytes 3..0 of the result: 0x64, b1, 0x64, b0
+                A.h[1] = firm_pair(d[r], 0x00070006u);                          //                           0x64, b3, 0x64, b2
+                union { unsigned int u[2]; h4v_t v; } B;
+                const u4v_t& bb = (r < 2) ? b01 : b23;
+                B.u[0] = bb[(r & 1) * 2 + 0];
+                B.u[1] = bb[(r & 1) * 2 + 1];
+                if (r & 1) acc1 = __builtin_amdgcn_mfma_f32_4x4x4f16(A.v, B.v, acc1, 0, 0, 0);
+                else acc0 = __builtin_amdgcn_mfma_f32_4x4x4f16(A.v, B.v, acc0, 0, 0, 0);
+            }
+        }
+        const f4v_t acc = acc0 + acc1;
+        // ---- D[b][i][j] sits in lane 4 b + j, register i: through LDS to lane = window, the two halves added there
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) outL[((lane & ~3) + i) * 4 + j] = acc[i];   // lanes 32..63 land in rows 32..63 = the second half
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < F::WIN) {
+            const f4v_t o = *(const f4v_t*)(outL + lane * 4) + *(const f4v_t*)(outL + (F::WIN + lane) * 4);
+            const float re = (o[0] + o[2]) * inv_scale - dc.x;
+            const float im = (o[1] + o[3]) * inv_scale - dc.y;
+            dm_out[t * F::WIN + lane] = cabs_like_glibc(re, im);
+        }
+        (void)tiles_per_run_;
+    };
+
+    for (unsigned int run = wg; run < nrun; run += nwaves) {       // static interleave (measurement build of the idea)
+        const unsigned int ch = run / runs_per_ch;
+        const unsigned int t0 = (run - ch * runs_per_ch) * tiles_per_run;
+        const size_t row = (size_t)(a.stream_identity ? (int)ch : stream_of[ch]) * a.pitch;
+        const uint8_t* base = iq_base + row + (size_t)t0 * F::TILE_BYTES;
+        float* __restrict__ dm_out = dm_base + (size_t)ch * a.dm_pitch + (size_t)t0 * F::WIN;
+        __amdgpu_buffer_rsrc_t rs = fird_rsrc(base, tiles_per_run * (unsigned int)F::TILE_BYTES);
+#pragma unroll
+        for (int p = 0; p < F::NLD; ++p) stA[p] = fird_load(rs, voff, (unsigned int)p * 1024u);
+#pragma unroll
+        for (int p = 0; p < F::NLD; ++p) stB[p] = fird_load(rs, voff, (unsigned int)F::TILE_BYTES + (unsigned int)p * 1024u);
+
+        // ---- the channel's table: scale, split, sign pattern (the loads above are in flight meanwhile).  Lane takes the taps
+        // n = lane + 64 q: one (wr, wi) load each, then the four 2 x f16 words that tap owns in each of the four columns.
+        const f2* tp = (const f2*)(taps_base + (size_t)ch * a.ntaps_pad * 2);
+        const int ntap = a.ntaps_pad;                                                // complex taps that exist; the rest of the window: 0
+        f2 w[4];
+        float mx = 0.f, sr = 0.f, si = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = lane + 64 * q;
+            const f2 z = {0.f, 0.f};
+            w[q] = n < ntap ? tp[n] : z;
+            mx = fmaxf(mx, fmaxf(fabsf(w[q].x), fabsf(w[q].y)));
+            sr += w[q].x;
+            si += w[q].y;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+            sr += __shfl_xor(sr, m, 64);
+            si += __shfl_xor(si, m, 64);
+        }
+        const unsigned int ebits = __float_as_uint(mx) & 0x7f800000u;               // 2^E <= max |w| < 2^(E+1)
+        const float inv_scale = ebits ? __uint_as_float(ebits) : 1.0f;              // 2^E
+        const float scale = ebits ? __uint_as_float(0x7f000000u - ebits) : 1.0f;    // 2^-E: scaled taps in (-2, 2)
+        const float crem = 127.37f - 127.0f;                                        // what the f16 bytes do not carry
+        const f2 dc = {crem * (sr - si), crem * (sr + si)};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = lane + 64 * q;                                            // sample n of the window: k-step n / 2, slots 2 (n & 1), + 1
+            if (n < 2 * F::NG * 8) {
+                const int s2 = n >> 1, g = s2 >> 2, r = s2 & 3;
+                const float wr = w[q].x * scale, wi = w[q].y * scale;
+                const _Float16 rh = (_Float16)wr, ih = (_Float16)wi;
+                const _Float16 rl = (_Float16)(wr - (float)rh), il = (_Float16)(wi - (float)ih);
+                h2v_t* dst = (h2v_t*)tabH + (((g * 4) * 4 + r) * 4 + 2 * (n & 1)) / 2;   // column 0; the next columns are 16 f16 = 8 words on
+                const h2v_t c0 = {rh, -ih}, c1 = {ih, rh}, c2 = {rl, -il}, c3 = {il, rl};
+                dst[0] = c0;
+                dst[8] = c1;
+                dst[16] = c2;
+                dst[24] = c3;
+            }
+        }
+
+        for (unsigned int t = 0; t < tiles_per_run; t += 2) {                        // tiles_per_run is even (launcher)
+            tile_step(stA, t, tiles_per_run, rs, dm_out, inv_scale, dc);
+            tile_step(stB, t + 1, tiles_per_run, rs, dm_out, inv_scale, dc);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // The other front ends' sample formats: same tile scheme, 4 bytes per input sample.
 //   FMT_CS16   interleaved int16 I,Q        soapy.c:238-241   (x/32768 folded into the output scale)
 //   FMT_SPLIT  int16 I plane + int16 Q plane sdrplay.c:219-223 (cabsf(D)/4 = output scale)
@@ -1451,6 +1636,8 @@ static int fir_device(FirDev** out)
             {(const void*)fir_u8_direct_kernel<25, 25, 5>, 4 * FirD<25>::WAVE_LDS},
             {(const void*)fir_u8_direct_kernel<25, 25, 10>, 4 * FirD<25>::WAVE_LDS},
             {(const void*)fir_u8_direct_kernel<25, 10, 10>, 4 * FirD<25>::WAVE_LDS},
+            {(const void*)fir_u8_direct_kernel<25, 0, 0, false>, 4 * FirD<25>::WAVE_LDS},
+            {(const void*)fir_u8_mfma_kernel<25>, 4 * FirM<25>::WAVE_LDS},
 #define FIRX_ATTR(F_, C_, W_) {(const void*)fir_fmt_direct_kernel<F_, C_, W_>, 4 * FirX<F_, C_, W_>::WAVE_LDS},
             FIRX_ATTR(FMT_CS16, 40, 32) FIRX_ATTR(FMT_CS16, 48, 32) FIRX_ATTR(FMT_CS16, 50, 32)
             FIRX_ATTR(FMT_F32R, 50, 32) FIRX_ATTR(FMT_F32R, 60, 16) FIRX_ATTR(FMT_F32R, 120, 8) FIRX_ATTR(FMT_F32R, 200, 8)
@@ -1600,6 +1787,35 @@ static int launch_direct(const FirArgs* a, int num_cu, hipStream_t stream)
     return (int)hipGetLastError();
 }
 
+// matrix-pipe variant (ACG_FIR_VARIANT=6): single-wave workgroups, as many as the LDS holds (5 per CU at 2.5 Msps)
+template <int CPR>
+static int launch_mfma(const FirArgs* a, int num_cu, hipStream_t stream)
+{
+    int wpg = env_int("ACG_FIR_WAVES_PER_WG", a->shares_cus ? 1 : 4);
+    if (wpg != 1 && wpg != 2 && wpg != 4) wpg = 4;
+    const size_t lds = (size_t)wpg * FirM<CPR>::WAVE_LDS;
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 12 / wpg) per_cu = 12 / wpg;
+    if (a->shares_cus && wpg == 1 && per_cu > 7) per_cu = 7;        // leave the demodulator's workgroups their LDS
+    per_cu = env_int("ACG_FIR_WG_PER_CU", per_cu);
+    long long grid = (long long)(a->ncu > 0 ? a->ncu : num_cu) * per_cu;
+    const long long bodies_per_ch = a->nwin / ACG_TILE_WIN / FIRD_R;
+    const long long bodies = (long long)a->nch * bodies_per_ch;
+    int pairs = 1;
+    while (pairs < 8 && bodies_per_ch % (2 * pairs) == 0 && bodies / (2 * pairs) >= 32 * grid * wpg) pairs *= 2;
+    pairs = env_int("ACG_FIR_RUN_PAIRS", pairs);
+    if (pairs < 1 || pairs > 8 || (pairs & (pairs - 1)) || bodies_per_ch % pairs) pairs = 1;
+    const long long nrun = bodies / pairs;
+    const long long need = (nrun + wpg - 1) / wpg;
+    if (grid > need) grid = need;
+    FirArgs b = *a;
+    b.run_pairs = pairs;
+    if (getenv("ACG_FIR_DEBUG_SHAPE"))
+        fprintf(stderr, "fir_u8_mfma<%d>: nch %d nwin %d  wpg %d per_cu %d grid %lld pairs %d runs %lld lds %zu\n", CPR, a->nch, a->nwin, wpg, per_cu, grid, pairs, nrun, lds);
+    hipLaunchKernelGGL((fir_u8_mfma_kernel<CPR>), dim3((unsigned int)grid), dim3(64 * wpg), lds, stream, b, a->iq, a->taps, a->stream_of, a->dm);
+    return (int)hipGetLastError();
+}
+
 extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
 {
     const size_t lds = acg_fir_lds_bytes(a);
@@ -1610,6 +1826,9 @@ extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
     // segment; 1 / 2 static persistent partition without / with non-temporal loads; 3 workgroup-granular dynamic
     // dispenser; 4 LDS-DMA double buffering
     const int variant = env_int("ACG_FIR_VARIANT", 5);
+    if (variant == 6 && a->cpr == 25 && a->nwin > 0 && a->nwin % ACG_TILE_WIN == 0 && (a->nwin / ACG_TILE_WIN) % FIRD_R == 0 &&
+        (long long)a->nch * (a->nwin / ACG_TILE_WIN) < (1ll << 31) && a->ntaps_pad <= a->decim)
+        return launch_mfma<25>(a, num_cu, (hipStream_t)stream);
     if ((variant == 5 || (variant >= 50 && variant <= 54)) && a->nwin > 0 && a->nwin % ACG_TILE_WIN == 0 && (a->nwin / ACG_TILE_WIN) % FIRD_R == 0 &&
         (long long)a->nch * (a->nwin / ACG_TILE_WIN) < (1ll << 31) && a->ntaps_pad <= a->decim) {
         switch (a->cpr) {

@@ -102,10 +102,11 @@ def run_cpu_baseline(M, seconds=12.0):
 
 
 # ------------------------------------------------------------------------------------------ workloads
-# Every case is sized to 54-60 GB of input per GPU (one buffer serves them all); 20 steps of the headline case make >= 0.5 s.
+# Every case is sized to 54-74 GB of input per GPU (one buffer serves them all); 20 steps of the headline case make >= 0.5 s
+# (176 callbacks = 14.4 s of signal per channel per step).
 CASES = {
     # BASELINE.json configs[2]: 1 GPU, 1024 channels, synthetic 2.5 Msps IQ, FIR decimate + MSK demod throughput
-    "throughput": dict(tag="BASELINE configs[2]", channels=1024, decim=200, ntaps=200, blocks=144, content="acars"),
+    "throughput": dict(tag="BASELINE configs[2]", channels=1024, decim=200, ntaps=200, blocks=176, content="acars"),
     # north-star regime: >= 10 000 concurrent channels at 2.5 Msps on one GPU
     "wide": dict(tag="north star (>= 10 000 channels per GPU)", channels=16384, decim=200, ntaps=200, blocks=8, content="acars"),
     # BASELINE.json configs[4]: 1 GPU stress, 192-tap LPF FIR, 2.5 Msps, 4096 channels

@@ -1,0 +1,27 @@
+#!/bin/bash
+O=gpurun_out/r02d
+mkdir -p $O
+export TMPDIR=/tmp
+run() { # label, env..., -- args
+  label=$1; shift
+  envs=()
+  while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
+  env "${envs[@]}" timeout 600 python bench.py --no-cpu-baseline --also none --steps 40 --warmup 5 --check-channels 8 "$@" > $O/$label.json 2> $O/$label.err
+  python - "$label" <<'PY'
+import json, sys
+l = sys.argv[1]
+try:
+    d = json.loads([x for x in open("gpurun_out/r02d/%s.json" % l) if x.startswith("{")][-1])
+    print("%-28s value %9.0f ms/step %8.3f fir_frac %.3f whole %.3f fir_ms %.3f msk_ms %.3f" % (l, d["value"], d["ms_per_step"], d["roofline"]["frac"], d["whole_job_frac_of_hbm"], d["kernels"]["fir_ms_per_step"], d["kernels"]["msk_ms_per_step"]))
+except Exception as e:
+    print(l, "FAILED", e, open("gpurun_out/r02d/%s.err" % l).read()[-300:])
+PY
+}
+run m_wide_v5 X=1 -- --config wide
+run m_wide_v6_w4 ACG_FIR_VARIANT=6 ACG_FIR_WAVES_PER_WG=4 -- --config wide
+run m_wide_v6_w2c3 ACG_FIR_VARIANT=6 ACG_FIR_WAVES_PER_WG=2 ACG_FIR_WG_PER_CU=3 -- --config wide
+run m_wide_v6_w2c4 ACG_FIR_VARIANT=6 ACG_FIR_WAVES_PER_WG=2 ACG_FIR_WG_PER_CU=4 -- --config wide
+run m_wide_v5_w4 ACG_FIR_WAVES_PER_WG=4 -- --config wide
+run m_stress_v5 X=1 -- --config stress
+run m_stress_v6_w4 ACG_FIR_VARIANT=6 ACG_FIR_WAVES_PER_WG=4 -- --config stress
+run m_stress_v6_w2c3 ACG_FIR_VARIANT=6 ACG_FIR_WAVES_PER_WG=2 ACG_FIR_WG_PER_CU=3 -- --config stress

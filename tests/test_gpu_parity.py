@@ -177,12 +177,13 @@ print("OK", worst)
 '''
 
 
-@pytest.mark.parametrize("variant,M", [("0", 200), ("1", 200), ("2", 160), ("4", 200), ("3", 192), ("3", 200), ("5", 200), ("5", 160), ("5", 192)])
+@pytest.mark.parametrize("variant,M", [("0", 200), ("1", 200), ("2", 160), ("4", 200), ("3", 192), ("3", 200), ("5", 200), ("5", 160), ("5", 192),
+                                       ("54", 200), ("6", 200)])
 def test_fir_kernel_variants_all_match_oracle(variant, M):
     """the down-converter's alternative kernels stay selectable (ACG_FIR_VARIANT: 0 one workgroup per
     segment, 1/2 static persistent partition without/with non-temporal loads, 3 the workgroup-granular dynamic
-    dispenser, 4 LDS-DMA double buffering, 5 the default wave-private streaming kernel): each one against the
-    oracle, in a fresh process."""
+    dispenser, 4 LDS-DMA double buffering, 5 the default wave-private streaming kernel, 54 the same with 127.37
+    subtracted per sample, 6 the matrix-pipe experiment): each one against the oracle, in a fresh process."""
     env = dict(os.environ, ACG_FIR_VARIANT=variant)
     r = subprocess.run([sys.executable, "-c", FIR_VARIANT_CHILD % dict(root=ROOT), str(M)], capture_output=True, text=True,
                        timeout=600, env=env)
