@@ -342,6 +342,10 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
         HIPCHK(c, hipMalloc(&c->d_groups, nch * sizeof(int4)));
         HIPCHK(c, hipMalloc(&c->d_group_ch, nch * sizeof(int)));
         HIPCHK(c, hipMalloc(&c->d_gtaps, nch * (size_t)c->ntaps_pad * 2 * sizeof(float)));
+        if (getenv("ACG_DEBUG_ADDR"))                      // placement probes (profiles/probe/placement_probe.py)
+            fprintf(stderr, "acg_create: taps %p (%zu B)  dm %p (%zu B)  st %p  work %p  stream_of %p  txt %p\n", (void*)c->d_taps,
+                    nch * c->ntaps_pad * 2 * sizeof(float), (void*)c->d_dm_all, 2 * nch * c->dm_pitch * sizeof(float), (void*)c->d_st,
+                    (void*)c->d_work, (void*)c->d_stream_of, (void*)c->d_txt);
         std::vector<int> so(nch);
         for (size_t i = 0; i < nch; ++i) so[i] = (int)(i % (size_t)cfg->nstreams);
         return upload_stream_map(c, so.data());

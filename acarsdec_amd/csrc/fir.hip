@@ -728,7 +728,7 @@ __device__ __forceinline__ unsigned int ticket_take(unsigned int& ticket)
 // (a fifth of the loop's vector instructions) become one subtraction per window.  x - 127.37f is exact in f32 either
 // way; what changes is the order of the roundings in the sum, at the 1e-7 level of full scale like any re-association
 // (rtl.c builds with -Ofast and re-associates itself; the parity bar for dm is 1e-5).
-template <int CPR, int UU, int BB, int TILE, bool FOLD>
+template <int CPR, int UU, int BB, int TILE, bool FOLD, bool WT = false>
 __device__ __forceinline__ void fird_tile(u4v_t* st /* [U] */, __amdgpu_buffer_rsrc_t cur, __amdgpu_buffer_rsrc_t nxt,
                                           unsigned int voff, const float4* Tl, f2* Pw, const f2* Pr, float* __restrict__ dm_out, int lane,
                                           f2 dc)
@@ -786,10 +786,16 @@ __device__ __forceinline__ void fird_tile(u4v_t* st /* [U] */, __amdgpu_buffer_r
 #pragma unroll
     for (int j = 0; j < CPR; ++j) D = D + Pr[j];
     if (FOLD) D = D - dc;
-    dm_out[lane] = cabs_like_glibc(D.x, D.y);
+    if (WT) {                                                      // write-through store (ACG_FIR_VARIANT=55): see firc_flush
+        float* p = dm_out + lane;
+        const float v = cabs_like_glibc(D.x, D.y);
+        asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+    } else {
+        dm_out[lane] = cabs_like_glibc(D.x, D.y);
+    }
 }
 
-template <int CPR, int UU, int BB, bool FOLD>
+template <int CPR, int UU, int BB, bool FOLD, bool WT = false>
 __device__ __forceinline__ void fird_body(const FirArgs& a, const uint8_t* __restrict__ iq_base, const float* __restrict__ taps_base,
                                           const int* __restrict__ stream_of, float* __restrict__ dm_base)
 {
@@ -923,7 +929,7 @@ __device__ __forceinline__ void fird_body(const FirArgs& a, const uint8_t* __res
         unsigned int nrun_ = NONE, nch_ = ch, nt0 = t0;
         float4 tp[4];
         for (unsigned int j = 0; j < pairs; ++j) {
-            fird_tile<CPR, UU, BB, 0, FOLD>(st, cur, cur, voff, Tl, Pw, Pr, dm_out, lane, dc);
+            fird_tile<CPR, UU, BB, 0, FOLD, WT>(st, cur, cur, voff, Tl, Pw, Pr, dm_out, lane, dc);
             // second tile of the body: where does the stream go next?
             const uint8_t* nbase = base + run_bytes;                // the next body of this run ...
             if (j + 1 == pairs) {                                   // ... or the first body of the next run
@@ -939,7 +945,7 @@ __device__ __forceinline__ void fird_body(const FirArgs& a, const uint8_t* __res
                 fetch_taps(nch_, tp);
             }
             const __amdgpu_buffer_rsrc_t nxt = fird_rsrc(nbase, has_next ? run_bytes : 0u);
-            fird_tile<CPR, UU, BB, 1, FOLD>(st, cur, nxt, voff, Tl, Pw, Pr, dm_out + ACG_TILE_WIN, lane, dc);
+            fird_tile<CPR, UU, BB, 1, FOLD, WT>(st, cur, nxt, voff, Tl, Pw, Pr, dm_out + ACG_TILE_WIN, lane, dc);
             dm_out += FIRD_R * ACG_TILE_WIN;
             base = nbase;
             cur = nxt;
@@ -953,14 +959,323 @@ __device__ __forceinline__ void fird_body(const FirArgs& a, const uint8_t* __res
     sign_off();
 }
 
-template <int CPR, int UU = 0, int BB = 0, bool FOLD = true>
+template <int CPR, int UU = 0, int BB = 0, bool FOLD = true, bool WT = false>
 __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_direct_kernel(const FirArgs a,
                                                                     const uint8_t* __restrict__ iq_base,
                                                                     const float* __restrict__ taps_base,
                                                                     const int* __restrict__ stream_of,
                                                                     float* __restrict__ dm_base)
 {
-    fird_body<CPR, UU, BB, FOLD>(a, iq_base, taps_base, stream_of, dm_base);
+    fird_body<CPR, UU, BB, FOLD, WT>(a, iq_base, taps_base, stream_of, dm_base);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fir_u8_coltap_kernel (ACG_FIR_VARIANT=7, 2.5 Msps only): the wave-private streaming kernel above with the taps in
+// REGISTERS.  What the kernel above pays per 16 input bytes besides its arithmetic is 64 bytes of tap reads from LDS
+// (four ds_read_b128 per step: with 1 KiB wave-loads the column of a lane, (64 q + L) mod 25, changes with every load,
+// so the lane needs all 25 columns over a tile).  Here the wave-loads are cut where the columns repeat: 125 chunks =
+// 5 windows = 2000 bytes are read as load A (chunks 125 g .. 125 g + 63) and load B (chunks 125 g + 64 .. 125 g + 127,
+// the last three of which belong to the next group), so lane L multiplies column L mod 25 in every A load and column
+// (L + 14) mod 25 in every B load: two tap sets of 8 complex taps = 32 VGPRs per lane, loaded once per run, and no tap
+// table in LDS at all (LDS traffic per 16 input bytes: 80 -> 16 bytes; 13 KiB instead of 18 KiB per wave, so twelve
+// waves fit a CU).  A tile is still 64 windows = 1600 chunks = 25 KiB contiguous: 12 groups + 100 chunks = 26
+// wave-loads (4 % of the lanes idle); the loads start 16-byte aligned instead of 1 KiB aligned (a wave-load touches 9
+// cache lines instead of 8; the two partial lines are shared with the neighbouring load of the same wave).
+// Lanes past the group (61..63 of a B load, 36..63 of the tile's last load) multiply bytes of the next group with
+// whatever taps they hold and write the result where the next group's A load overwrites it (LDS operations of a wave
+// execute in order) or into 28 pad entries behind the tile's partial sums: no predicate, no zero taps.
+// Everything else -- partial sums through LDS, lane = window reduction, |D|, dispenser, runs, the 127.37 fold -- is
+// the kernel above.
+template <int U_ = 13, int B_ = 1>
+struct FirC {
+    static constexpr int CPR = 25;
+    static constexpr int SPT = 26;                                 // wave-loads (steps) per tile
+    static constexpr int U = U_;                                   // staging slots per lane; divides the 52 loads of a body
+    static constexpr int B = B_;                                   // loads per burst: U - B .. U KiB per wave in flight
+    static constexpr int P_ENT = 64 * CPR + 28;                    // partial sums of a tile + the idle lanes of its last load
+    static constexpr int P_BYTES = (P_ENT * 8 + 15) & ~15;
+    static constexpr int CAP = 16;                                 // tiles of results a wave can hold back (staged variant)
+    static constexpr int STAGE_BYTES = CAP * 256 + CAP * 8;        // 64 floats per tile + where they go
+    static constexpr int WAVE_LDS = P_BYTES;
+    static constexpr int WAVE_LDS_STAGED = P_BYTES + STAGE_BYTES;
+    static_assert((FIRD_R * SPT) % U == 0 && (FIRD_R * SPT) % B == 0 && B <= U, "slots and bursts must divide the loads per body");
+    // first chunk of step q of a tile, byte offset of load position pos of a body
+    static constexpr int chunk0(int q) { return (q >> 1) * 125 + (q & 1) * 64; }
+    static constexpr unsigned int offset(int pos) { return (unsigned int)(pos / SPT) * (CPR * 1024u) + (unsigned int)chunk0(pos % SPT) * 16u; }
+};
+
+// Complex multiply-accumulate of one sample (tt = (I, Q)) with one tap (w = (wr, wi)) as two packed fmas on ONE register
+// pair per tap:  P += (I wr, I wi),  Q += (-Q wi, Q wr);  the chunk's sum is P + Q (one v_pk_add_f32, written as it is).
+// P.x, -Q.x, P.y, Q.y are exactly the four sums the kernel above keeps as accA.x, accA.y, accB.x, accB.y (negating a
+// product is exact), so the results are bit-identical to it; the half selection and the sign are instruction modifiers.
+// As inline asm because the taps are loop invariants here: left to the compiler, the swapped pair (wi, wr) is hoisted
+// into a second register copy of both tap sets (32 VGPRs, a wave per SIMD less) instead of an op_sel.
+__device__ __forceinline__ void firc_cmac_first(f2& P, f2& Q, f2 tt, f2 w)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(P) : "v"(tt), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel:[1,1,0] op_sel_hi:[1,0,0] neg_lo:[0,1,0]" : "=v"(Q) : "v"(tt), "v"(w));
+}
+__device__ __forceinline__ void firc_cmac(f2& P, f2& Q, f2 tt, f2 w)
+{
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(P) : "v"(tt), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(Q) : "v"(tt), "v"(w));
+}
+
+// STAGED: the 64 results of a tile are parked in LDS (with their destination) instead of being stored; see firc_flush.
+template <int TILE, bool FOLD, int UU, int BB, bool STAGED>
+__device__ __forceinline__ void firc_tile(u4v_t* st /* [U] */, __amdgpu_buffer_rsrc_t cur, __amdgpu_buffer_rsrc_t nxt,
+                                          unsigned int voff, const f2 (&wa)[8], const f2 (&wb)[8], f2* Pw, const f2* Pr,
+                                          float* __restrict__ dm_out, int lane, f2 dc, float* stage, float** stage_dst, int nst)
+{
+    typedef FirC<UU, BB> F;
+#pragma unroll
+    for (int q = 0; q < F::SPT; ++q) {
+        __builtin_amdgcn_sched_barrier(0);
+        const int p = TILE * F::SPT + q;                       // load position of the body consumed by this step
+        const u4v_t d = st[p % F::U];
+        if (p % F::B == 0) {
+#pragma unroll
+            for (int b = 0; b < F::B; ++b) {
+                const int pos = p + F::U - F::B + b;           // the slots of positions p - B .. p - 1 are free
+                if (pos < FIRD_R * F::SPT) st[pos % F::U] = fird_load(cur, voff, F::offset(pos));
+                else st[pos % F::U] = fird_load(nxt, voff, F::offset(pos - FIRD_R * F::SPT));
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const f2 (&w)[8] = (q & 1) ? wb : wa;
+        f2 accP, accQ;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const unsigned int word = d[j >> 1];
+            const unsigned int sh = (j & 1) * 16;
+            f2 tt;
+            tt.x = (float)((word >> sh) & 0xffu);                      // rtl.c:338
+            tt.y = (float)((word >> (sh + 8)) & 0xffu);                // rtl.c:339
+            if (!FOLD) { tt.x -= 127.37f; tt.y -= 127.37f; }
+            if (j == 0) firc_cmac_first(accP, accQ, tt, w[j]);
+            else firc_cmac(accP, accQ, tt, w[j]);
+        }
+        Pw[F::chunk0(q)] = accP + accQ;                                // chunk i = chunk0(q) + lane; rows of 25 (odd: conflict free)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // lane = window: add the 25 partial sums of the row, |D| (rtl.c:353), 64 consecutive floats
+    f2 D = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < F::CPR; ++j) D = D + Pr[j];
+    if (FOLD) D = D - dc;
+    if (STAGED) {
+        stage[nst * 64 + lane] = cabs_like_glibc(D.x, D.y);
+        stage_dst[nst] = dm_out;                                       // (every lane writes the same word: no branch)
+    } else {
+        dm_out[lane] = cabs_like_glibc(D.x, D.y);
+    }
+}
+
+// The write stream.  dm is 1 % of the kernel's traffic, and it costs 5-15 % of its read bandwidth: a pure streaming reader
+// at 7.1 TB/s drops to 6.0-6.7 TB/s when every wave adds 256 bytes of stores per 25.6 KB read, by how much depends on where
+// the output happens to lie relative to the input (profiles/probe/write_beside_read_probe.hip; the down-converter itself:
+// 0.75-0.83 of spec with its dm, 0.84-0.85 with the dm rows folded into one).  What helps is to make the writes of the WHOLE
+// CHIP come in bursts instead of a trickle: every wave parks its results in LDS (up to CAP tiles, each with its
+// destination, so that runs and channels may change in between) and flushes when the chip-wide 100 MHz clock
+// (s_memrealtime) crosses a multiple of 2^13 ticks = 82 us -- all waves see that within one tile -- or when the buffer is
+// full; the stores are write-through (sc0 sc1), 16 bytes per lane, four tiles per instruction.  Between two flushes HBM
+// sees reads only.  The probe: 6.0 -> 6.7 TB/s on a bad placement, 6.7 -> 6.85 on a good one.
+#define FIRC_EPOCH_SHIFT 13
+typedef float f4v_stage_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void firc_flush(const float* stage, float* const* stage_dst, int nst, int lane)
+{
+    for (int q = lane; q < nst * 16; q += 64) {
+        const f4v_stage_t v = *(const f4v_stage_t*)&stage[q * 4];
+        float* p = stage_dst[q >> 4] + (q & 15) * 4;
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+    }
+}
+
+template <bool FOLD, int UU, int BB, bool STAGED>
+__device__ __forceinline__ void firc_body(const FirArgs& a, const uint8_t* __restrict__ iq_base, const float* __restrict__ taps_base,
+                                          const int* __restrict__ stream_of, float* __restrict__ dm_base)
+{
+    typedef FirC<UU, BB> F;
+    constexpr unsigned int NONE = 0xffffffffu;
+    if (a.high_prio) __builtin_amdgcn_s_setprio(2);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned char* my = fir_smem + wave * (STAGED ? F::WAVE_LDS_STAGED : F::WAVE_LDS);
+    f2* P = (f2*)my;
+    float* stage = (float*)(my + F::P_BYTES);                      // STAGED: CAP x 64 results ...
+    float** stage_dst = (float**)(my + F::P_BYTES + F::CAP * 256); // ... and where each tile goes
+    int nst = 0;                                                   // tiles parked
+    unsigned long long epoch = STAGED ? (__builtin_amdgcn_s_memrealtime() >> FIRC_EPOCH_SHIFT) : 0ull;
+    // after a tile: flush when the chip-wide clock entered a new epoch or the buffer is full
+    auto tile_done = [&]() {
+        if (!STAGED) return;
+        ++nst;
+        const unsigned long long e = __builtin_amdgcn_s_memrealtime() >> FIRC_EPOCH_SHIFT;
+        if (e != epoch || nst == F::CAP) {
+            epoch = e;
+            firc_flush(stage, stage_dst, nst, lane);
+            nst = 0;
+        }
+    };
+    f2* Pw = P + lane;                                             // + chunk0(q) entries
+    const f2* Pr = P + lane * F::CPR;
+    const int colA = lane - (lane >= 25 ? 25 : 0) - (lane >= 50 ? 25 : 0);             // lane % 25
+    const int lb = lane + 14;
+    const int colB = lb - (lb >= 25 ? 25 : 0) - (lb >= 50 ? 25 : 0) - (lb >= 75 ? 25 : 0);   // (lane + 14) % 25
+
+    // runs, dispenser, run -> address: as in fird_body (a run is `pairs` consecutive two-tile bodies of one channel)
+    const unsigned int pairs = (unsigned int)a.run_pairs;
+    const unsigned int ntile = (unsigned int)a.nwin / ACG_TILE_WIN;
+    const unsigned int runs_per_ch = ntile / (FIRD_R * pairs);
+    const unsigned int nrun = (unsigned int)a.nch * runs_per_ch;
+    const unsigned int wpg = blockDim.x >> 6;
+    const unsigned int nwaves = gridDim.x * wpg;
+    const unsigned int wg = blockIdx.x * wpg + (unsigned int)wave;
+    unsigned int* ctr = a.work_counter;
+    constexpr unsigned int tile_bytes = (unsigned int)F::CPR * 1024u;
+    constexpr unsigned int run_bytes = FIRD_R * tile_bytes;
+    const unsigned int voff = (unsigned int)lane << 4;
+    const int nck = a.ntaps_pad >> 3;                                               // tap columns that carry taps
+
+    auto shard_runs = [&](unsigned int s) { return (nrun + ACG_DISP_SHARDS - 1 - s) / ACG_DISP_SHARDS; };
+    auto shard_static = [&](unsigned int s) { return (nwaves + ACG_DISP_SHARDS - 1 - s) / ACG_DISP_SHARDS; };
+    auto run_of_ticket = [&](unsigned int s, unsigned int t) -> unsigned int {
+        const unsigned long long k = (unsigned long long)shard_static(s) + t;
+        return k < shard_runs(s) ? (unsigned int)k * ACG_DISP_SHARDS + s : NONE;
+    };
+    auto probe = [&](unsigned int& s) -> unsigned int {
+        for (int k = 0; k < ACG_DISP_SHARDS; ++k) {
+            unsigned int t = 0;
+            if (lane == 0) t = __hip_atomic_fetch_add(ctr + s * ACG_DISP_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+            const unsigned int r = run_of_ticket(s, t);
+            if (r != NONE) return r;
+            s = (s + 1 == ACG_DISP_SHARDS) ? 0 : s + 1;
+        }
+        return NONE;
+    };
+    auto sign_off = [&]() {
+        if (lane == 0) {
+            const unsigned int d = atomicAdd(ctr + ACG_DISP_SHARDS * ACG_DISP_STRIDE, 1u);
+            if (d == nwaves - 1) {
+#pragma unroll
+                for (int k = 0; k <= ACG_DISP_SHARDS; ++k)
+                    __hip_atomic_store(ctr + k * ACG_DISP_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    };
+    auto run_base = [&](unsigned int run, unsigned int& ch, unsigned int& t0) -> const uint8_t* {
+        ch = run / runs_per_ch;
+        t0 = (run - ch * runs_per_ch) * FIRD_R * pairs;
+        const size_t row = (size_t)(a.stream_identity ? (int)ch : stream_of[ch]) * a.pitch;
+        return iq_base + row + (size_t)t0 * tile_bytes;
+    };
+    // the two tap columns of this lane for channel ch (64 bytes each); not looked at before adopt_taps, so the loads
+    // stay in flight under the last tile of the run
+    const bool onA = colA < nck, onB = colB < nck;                  // columns beyond the last tap: zero
+    auto fetch_taps = [&](unsigned int ch, float4 (&ta)[4], float4 (&tb)[4]) {
+        const float4* src = (const float4*)(taps_base + (size_t)ch * a.ntaps_pad * 2);
+        const float4* sa = src + (onA ? colA : 0) * 4;
+        const float4* sb = src + (onB ? colB : 0) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { ta[k] = sa[k]; tb[k] = sb[k]; }
+    };
+    f2 wa[8], wb[8];
+    f2 dc = {0.f, 0.f};                                             // 127.37 (1 + j) sum w of the current run's channel
+    auto adopt_taps = [&](const float4 (&ta)[4], const float4 (&tb)[4]) {
+        if (FOLD) {                                                 // lanes 0..24 hold every column once in set A
+            float sr = 0.f, si = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { sr += ta[k].x + ta[k].z; si += ta[k].y + ta[k].w; }
+            const bool mine = onA && lane < F::CPR;
+            sr = mine ? sr : 0.f;
+            si = mine ? si : 0.f;
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) { sr += __shfl_xor(sr, m, 64); si += __shfl_xor(si, m, 64); }
+            dc.x = 127.37f * (sr - si);
+            dc.y = 127.37f * (sr + si);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            wa[2 * k] = f2{onA ? ta[k].x : 0.f, onA ? ta[k].y : 0.f};
+            wa[2 * k + 1] = f2{onA ? ta[k].z : 0.f, onA ? ta[k].w : 0.f};
+            wb[2 * k] = f2{onB ? tb[k].x : 0.f, onB ? tb[k].y : 0.f};
+            wb[2 * k + 1] = f2{onB ? tb[k].z : 0.f, onB ? tb[k].w : 0.f};
+        }
+    };
+
+    unsigned int s = wg % ACG_DISP_SHARDS;
+    unsigned int run = wg < nrun ? wg : NONE;
+    if (run == NONE) {                                              // tiny launches: fewer runs than waves
+        s = (s + 1 == ACG_DISP_SHARDS) ? 0 : s + 1;
+        run = probe(s);
+    }
+    if (run == NONE) { sign_off(); return; }
+
+    unsigned int ch, t0;
+    const uint8_t* base = run_base(run, ch, t0);
+    {
+        float4 ta[4], tb[4];
+        fetch_taps(ch, ta, tb);
+        adopt_taps(ta, tb);
+    }
+    __amdgpu_buffer_rsrc_t cur = fird_rsrc(base, run_bytes);
+    u4v_t st[F::U];
+#pragma unroll
+    for (int i = 0; i < F::U - F::B; ++i) {                         // step 0 issues the burst U - B .. U - 1 itself
+        st[i] = fird_load(cur, voff, F::offset(i));
+        __builtin_amdgcn_sched_barrier(0);                          // keep the loads in issue order (the waits count on it)
+    }
+
+    for (;;) {
+        unsigned int tk;
+        if (lane == 0) ticket_request(ctr + s * ACG_DISP_STRIDE, tk);
+        float* __restrict__ dm_out = dm_base + (size_t)ch * a.dm_pitch + (size_t)t0 * ACG_TILE_WIN;
+        static_assert(FIRD_R == 2, "a body is unrolled by hand: first tile, second tile");
+        bool has_next = true;
+        unsigned int nrun_ = NONE, nch_ = ch, nt0 = t0;
+        float4 ta[4], tb[4];
+        for (unsigned int j = 0; j < pairs; ++j) {
+            firc_tile<0, FOLD, UU, BB, STAGED>(st, cur, cur, voff, wa, wb, Pw, Pr, dm_out, lane, dc, stage, stage_dst, nst);
+            tile_done();
+            const uint8_t* nbase = base + run_bytes;                // the next body of this run ...
+            if (j + 1 == pairs) {                                   // ... or the first body of the next run
+                // (U loads and a store are in flight, all younger than the ticket)
+                nrun_ = run_of_ticket(s, ticket_take<F::U + 1>(tk));
+                if (nrun_ == NONE) {
+                    s = (s + 1 == ACG_DISP_SHARDS) ? 0 : s + 1;
+                    nrun_ = probe(s);
+                }
+                has_next = nrun_ != NONE;
+                nbase = base;
+                if (has_next) nbase = run_base(nrun_, nch_, nt0);
+                fetch_taps(nch_, ta, tb);
+            }
+            const __amdgpu_buffer_rsrc_t nxt = fird_rsrc(nbase, has_next ? run_bytes : 0u);
+            firc_tile<1, FOLD, UU, BB, STAGED>(st, cur, nxt, voff, wa, wb, Pw, Pr, dm_out + ACG_TILE_WIN, lane, dc, stage, stage_dst, nst);
+            tile_done();
+            dm_out += FIRD_R * ACG_TILE_WIN;
+            base = nbase;
+            cur = nxt;
+        }
+        if (!has_next) break;
+        adopt_taps(ta, tb);
+        run = nrun_;
+        ch = nch_;
+        t0 = nt0;
+    }
+    if (STAGED && nst) firc_flush(stage, stage_dst, nst, lane);
+    sign_off();
+}
+
+template <bool FOLD = true, int UU = 13, int BB = 1, bool STAGED = false>
+__global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_coltap_kernel(const FirArgs a,
+                                                                    const uint8_t* __restrict__ iq_base,
+                                                                    const float* __restrict__ taps_base,
+                                                                    const int* __restrict__ stream_of,
+                                                                    float* __restrict__ dm_base)
+{
+    firc_body<FOLD, UU, BB, STAGED>(a, iq_base, taps_base, stream_of, dm_base);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1749,7 +2064,7 @@ extern "C" size_t acg_fir_lds_bytes(const FirArgs* a)
 }
 
 // wave-private streaming kernel: whole tiles, runs inside one channel, a rate it is instantiated for
-template <int CPR, int UU = 0, int BB = 0, bool FOLD = true>
+template <int CPR, int UU = 0, int BB = 0, bool FOLD = true, bool WT = false>
 static int launch_direct(const FirArgs* a, int num_cu, hipStream_t stream)
 {
     // The waves of a workgroup are independent, so the workgroup size only decides in what pieces LDS is handed out
@@ -1779,10 +2094,43 @@ static int launch_direct(const FirArgs* a, int num_cu, hipStream_t stream)
     if (grid > need) grid = need;
     FirArgs b = *a;
     b.run_pairs = pairs;
+    if (getenv("ACG_FIR_DEBUG_DMPITCH0")) b.dm_pitch = 0;          // measurement aid: every channel's dm lands in the first row (no write stream to HBM)
     if (getenv("ACG_FIR_DEBUG_SHAPE"))
         fprintf(stderr, "fir_u8_direct<%d>: nch %d nwin %d  wpg %d per_cu %d grid %lld  bodies/ch %lld pairs %d runs %lld  shares_cus %d prio %d\n",
                 CPR, a->nch, a->nwin, wpg, per_cu, grid, bodies_per_ch, pairs, nrun, a->shares_cus, a->high_prio);
-    hipLaunchKernelGGL((fir_u8_direct_kernel<CPR, UU, BB, FOLD>), dim3((unsigned int)grid), dim3(64 * wpg), lds, stream, b, a->iq, a->taps,
+    hipLaunchKernelGGL((fir_u8_direct_kernel<CPR, UU, BB, FOLD, WT>), dim3((unsigned int)grid), dim3(64 * wpg), lds, stream, b, a->iq, a->taps,
+                       a->stream_of, a->dm);
+    return (int)hipGetLastError();
+}
+
+// register-resident taps (ACG_FIR_VARIANT=7 / 8, 2.5 Msps): 13 / 17 KiB of LDS per wave
+template <bool FOLD = true, int UU = 13, int BB = 1, bool STAGED = false>
+static int launch_coltap(const FirArgs* a, int num_cu, hipStream_t stream)
+{
+    int wpg = env_int("ACG_FIR_WAVES_PER_WG", a->shares_cus ? 1 : 4);
+    if (wpg != 1 && wpg != 2 && wpg != 4) wpg = 4;
+    const size_t lds = (size_t)wpg * (STAGED ? FirC<UU, BB>::WAVE_LDS_STAGED : FirC<UU, BB>::WAVE_LDS);
+    int per_cu = (int)((160 * 1024) / lds);
+    // (twelve waves per CU fit and measure 1-6 % slower than eight, alone and beside the demodulator: profiles/r02_experiments)
+    if (per_cu > 8 / wpg) per_cu = 8 / wpg;
+    if (a->shares_cus && wpg == 1 && per_cu > 7) per_cu = 7;        // leave the demodulator's workgroups their LDS (28 KiB per CU)
+    per_cu = env_int("ACG_FIR_WG_PER_CU", per_cu);
+    long long grid = (long long)(a->ncu > 0 ? a->ncu : num_cu) * per_cu;
+    const long long bodies_per_ch = a->nwin / ACG_TILE_WIN / FIRD_R;
+    const long long bodies = (long long)a->nch * bodies_per_ch;
+    int pairs = 1;
+    while (pairs < 8 && bodies_per_ch % (2 * pairs) == 0 && bodies / (2 * pairs) >= 32 * grid * wpg) pairs *= 2;
+    pairs = env_int("ACG_FIR_RUN_PAIRS", pairs);
+    if (pairs < 1 || pairs > 8 || (pairs & (pairs - 1)) || bodies_per_ch % pairs) pairs = 1;
+    const long long nrun = bodies / pairs;
+    const long long need = (nrun + wpg - 1) / wpg;
+    if (grid > need) grid = need;
+    FirArgs b = *a;
+    b.run_pairs = pairs;
+    if (getenv("ACG_FIR_DEBUG_SHAPE"))
+        fprintf(stderr, "fir_u8_coltap: nch %d nwin %d  wpg %d per_cu %d grid %lld  bodies/ch %lld pairs %d runs %lld  shares_cus %d prio %d lds %zu\n",
+                a->nch, a->nwin, wpg, per_cu, grid, bodies_per_ch, pairs, nrun, a->shares_cus, a->high_prio, lds);
+    hipLaunchKernelGGL((fir_u8_coltap_kernel<FOLD, UU, BB, STAGED>), dim3((unsigned int)grid), dim3(64 * wpg), lds, stream, b, a->iq, a->taps,
                        a->stream_of, a->dm);
     return (int)hipGetLastError();
 }
@@ -1826,10 +2174,20 @@ extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
     // segment; 1 / 2 static persistent partition without / with non-temporal loads; 3 workgroup-granular dynamic
     // dispenser; 4 LDS-DMA double buffering
     const int variant = env_int("ACG_FIR_VARIANT", 5);
+    if ((variant == 7 || variant == 8 || (variant >= 70 && variant <= 73)) && a->cpr == 25 && a->nwin > 0 && a->nwin % ACG_TILE_WIN == 0 && (a->nwin / ACG_TILE_WIN) % FIRD_R == 0 &&
+        (long long)a->nch * (a->nwin / ACG_TILE_WIN) < (1ll << 31) && a->ntaps_pad <= a->decim)
+    {            // 70..73: measurement knobs (staging slots, burst length)
+        if (variant == 8) return launch_coltap<true, 13, 1, true>(a, num_cu, (hipStream_t)stream);      // results parked in LDS, chip-wide bursts
+        if (variant == 70) return launch_coltap<true, 26, 1>(a, num_cu, (hipStream_t)stream);
+        if (variant == 71) return launch_coltap<true, 26, 2>(a, num_cu, (hipStream_t)stream);
+        if (variant == 72) return launch_coltap<true, 26, 13>(a, num_cu, (hipStream_t)stream);
+        if (variant == 73) return launch_coltap<true, 4, 2>(a, num_cu, (hipStream_t)stream);
+        return launch_coltap<>(a, num_cu, (hipStream_t)stream);
+    }
     if (variant == 6 && a->cpr == 25 && a->nwin > 0 && a->nwin % ACG_TILE_WIN == 0 && (a->nwin / ACG_TILE_WIN) % FIRD_R == 0 &&
         (long long)a->nch * (a->nwin / ACG_TILE_WIN) < (1ll << 31) && a->ntaps_pad <= a->decim)
         return launch_mfma<25>(a, num_cu, (hipStream_t)stream);
-    if ((variant == 5 || (variant >= 50 && variant <= 54)) && a->nwin > 0 && a->nwin % ACG_TILE_WIN == 0 && (a->nwin / ACG_TILE_WIN) % FIRD_R == 0 &&
+    if ((variant == 5 || (variant >= 50 && variant <= 55)) && a->nwin > 0 && a->nwin % ACG_TILE_WIN == 0 && (a->nwin / ACG_TILE_WIN) % FIRD_R == 0 &&
         (long long)a->nch * (a->nwin / ACG_TILE_WIN) < (1ll << 31) && a->ntaps_pad <= a->decim) {
         switch (a->cpr) {
         case 20: return launch_direct<20>(a, num_cu, (hipStream_t)stream);
@@ -1840,6 +2198,7 @@ extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
             if (variant == 52) return launch_direct<25, 25, 10>(a, num_cu, (hipStream_t)stream);
             if (variant == 53) return launch_direct<25, 10, 10>(a, num_cu, (hipStream_t)stream);
             if (variant == 54) return launch_direct<25, 0, 0, false>(a, num_cu, (hipStream_t)stream);      // 127.37 subtracted per sample
+            if (variant == 55) return launch_direct<25, 0, 0, true, true>(a, num_cu, (hipStream_t)stream);  // dm stored write-through
             return launch_direct<25>(a, num_cu, (hipStream_t)stream);
         default: break;
         }

@@ -253,18 +253,22 @@ def run_case(J, name, case, args, steps, warmup, headline):
     ncall = nblk // cb
     if fmt == K.FMT_S16_SPLIT:
         cb, ncall = nblk, 1                                # (plane layout: one call)
-    dec = D.Decoder(nch, decim=M, ntaps=ntaps, nstreams=nstreams, max_blocks=cb, device=J.local, bitlog=True, timing=True)
-    dec.set_taps(taps)
-    if share > 1:
-        dec.set_channel_streams(np.arange(nch) // share)
+    def make_decoder():
+        d_ = D.Decoder(nch, decim=M, ntaps=ntaps, nstreams=nstreams, max_blocks=cb, device=J.local, bitlog=bool(args.bitlog), timing=True)
+        d_.set_taps(taps)
+        if share > 1:
+            d_.set_channel_streams(np.arange(nch) // share)
+        return d_
+    dec = dec0 = make_decoder()
     stream = torch.cuda.current_stream().cuda_stream
     maxfr = max(8192, int(nch * (cb / 3.0 + 2)))
     cb_bytes = cb * 1024 * M * bps
 
-    def step(lag=1, sink=None):
+    def step(lag=1, sink=None, dec=None):
         """one pass of the hot path over the batch; decoded blocks are delivered to the host one call behind
         (streaming double buffering: the newest call keeps the GPU busy while the host collects)"""
         n = 0
+        dec = dec or dec0
         for k in range(ncall):
             part = iq[:, k * cb_bytes:(k + 1) * cb_bytes]
             if fmt == 0:
@@ -346,6 +350,50 @@ def run_case(J, name, case, args, steps, warmup, headline):
     tim = dec.timing()
     dt, nfr_total = shard.reduce_timing(dt_local, nfr, world, dist if world > 1 else None, cdev)
     per_rank = shard.gather_scalars(dt_local, world, dist if world > 1 else None, cdev)
+    ab = None
+    if args.ab and world == 1:
+        # measurement aid: the same decoder, buffers and placement, timed again under each down-converter variant in turn
+        # (ACG_FIR_VARIANT is read at every launch), two rounds -- not part of the reported value
+        ab = {}
+        keep = os.environ.get("ACG_FIR_VARIANT")
+        for rnd in range(2):
+            for v in args.ab.split(","):
+                os.environ["ACG_FIR_VARIANT"] = v
+                step()
+                dec.drain_frames_raw(maxfr)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(steps):
+                    step()
+                dec.drain_frames_raw(maxfr)
+                torch.cuda.synchronize()
+                ab.setdefault(v, []).append(round(nch * nout * M * steps / (time.perf_counter() - t1) / 1e6, 0))
+        if keep is None:
+            del os.environ["ACG_FIR_VARIANT"]
+        else:
+            os.environ["ACG_FIR_VARIANT"] = keep
+    trials = None
+    if args.decoders > 1 and world == 1:
+        # measurement aid: further decoders in the same process (each with its own allocations, all kept alive), the same
+        # input, timed the same way -- how much of the run-to-run spread is where the decoder's buffers happen to lie
+        trials = [round(nch * nout * M * steps / dt_local / 1e6, 0)]
+        others, spacers = [], []
+        for k in range(1, args.decoders):
+            spacers.append(torch.empty((((k * 53) << 20) + 4096 * k,), dtype=torch.uint8, device=dev))
+            d2 = make_decoder()
+            others.append(d2)
+            for _ in range(2):
+                step(dec=d2)
+            d2.drain_frames_raw(maxfr)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                step(dec=d2)
+            d2.drain_frames_raw(maxfr)
+            torch.cuda.synchronize()
+            trials.append(round(nch * nout * M * steps / (time.perf_counter() - t1) / 1e6, 0))
+        for d2 in others:
+            d2.close()
     dec.close()
     if rank != 0:
         return None
@@ -411,6 +459,10 @@ def run_case(J, name, case, args, steps, warmup, headline):
                             "demodulator of i); the demodulator figure is taken during warm-up (its events are off in the timed region)"},
         "parity": parity,
     }
+    if ab:
+        out["ab_same_process"] = ab
+    if trials:
+        out["placement_trials"] = trials
     if ntaps != M:
         out["config"]["filter"] = ("%d-tap low-pass = the channel's NCO taps (rtl.c:283-286) x Hamming window, unit DC gain; the reference "
                                    "only has the boxcar, so the oracle for this filter is the same sum(vb*wf) formula with these taps" % ntaps)
@@ -447,6 +499,9 @@ def main():
     ap.add_argument("--share", type=int, default=1,
                     help="channels per input stream (rtl.c's own shape: one dongle feeds up to 16 channels); >1 = shared-stream "
                          "mode, VALU-bound, reported separately and never as the roofline figure (SURVEY 8d)")
+    ap.add_argument("--bitlog", type=int, default=1, help="1: the demodulator also writes its per-bit soft symbols (vo, level: 8 B per bit) to HBM")
+    ap.add_argument("--decoders", type=int, default=1, help="measurement aid: time this many decoders (separate allocations) in the same process")
+    ap.add_argument("--ab", default=None, help="measurement aid: comma-separated ACG_FIR_VARIANT values timed after the run in the same process")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-child", nargs=4, default=None)
     args = ap.parse_args()
@@ -488,7 +543,9 @@ def main():
 
     def fir_kernel_name(M, nout):
         v = int(os.environ.get("ACG_FIR_VARIANT", "5"))
-        if v == 5 and M in (160, 192, 200) and nout % 128 == 0:
+        if (v in (7, 8) or 70 <= v <= 73) and M == 200 and nout % 128 == 0:
+            return "fir_u8_coltap_kernel"
+        if (v in (5, 7, 8) or 50 <= v <= 55 or 70 <= v <= 73) and M in (160, 192, 200) and nout % 128 == 0:
             return "fir_u8_direct_kernel<%d>" % (M // 8)
         return {0: "fir_u8_tile_kernel", 4: "fir_u8_dma_kernel"}.get(v, "fir_u8_persist_kernel")
     J.fir_kernel_name = fir_kernel_name
@@ -549,7 +606,7 @@ def main():
             "dtype": "f32",
         }
         for k in ("data", "config", "roofline", "whole_job_frac_of_hbm", "whole_job_GBs_per_gpu", "time_dominant_kernel",
-                  "timed_region_s", "kernels", "parity", "per_gpu", "valu"):
+                  "timed_region_s", "kernels", "parity", "per_gpu", "valu", "ab_same_process", "placement_trials"):
             if k in head:
                 out[k] = head[k]
         if out["time_dominant_kernel"] != out["roofline"]["kernel"]:

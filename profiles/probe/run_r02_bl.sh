@@ -1,0 +1,26 @@
+#!/bin/bash
+# bit log on / off x kernel 5 / 8, sustained whole job, three rounds
+O=gpurun_out/r02bl
+mkdir -p $O
+export TMPDIR=/tmp
+run() { # label, env..., -- args
+  label=$1; shift
+  envs=()
+  while [ "$1" != "--" ]; do envs+=("$1"); shift; done; shift
+  env "${envs[@]}" timeout 600 python bench.py --no-cpu-baseline --also none --steps 40 --warmup 5 --check-channels 8 "$@" > $O/$label.json 2> $O/$label.err
+  python - "$label" <<'PY'
+import json, sys
+l = sys.argv[1]
+try:
+    d = json.loads([x for x in open("gpurun_out/r02bl/%s.json" % l) if x.startswith("{")][-1])
+    print("%-28s value %9.0f ms/step %8.3f fir_frac %.3f whole %.3f fir_ms %.3f msk_ms %.3f" % (l, d["value"], d["ms_per_step"], d["roofline"]["frac"], d["whole_job_frac_of_hbm"], d["kernels"]["fir_ms_per_step"], d["kernels"]["msk_ms_per_step"]))
+except Exception as e:
+    print(l, "FAILED", e, open("gpurun_out/r02bl/%s.err" % l).read()[-300:])
+PY
+}
+for r in a b c; do
+  for c in stress wide; do
+    for v in 5 8; do for b in 1 0; do run ${c}_v${v}_log${b}_$r ACG_FIR_VARIANT=$v -- --config $c --bitlog $b; done; done
+  done
+done
+for b in 1 0; do run head_v5_log$b ACG_FIR_VARIANT=5 -- --config throughput --steps 20 --bitlog $b; done

@@ -178,24 +178,28 @@ print("OK", worst)
 
 
 @pytest.mark.parametrize("variant,M", [("0", 200), ("1", 200), ("2", 160), ("4", 200), ("3", 192), ("3", 200), ("5", 200), ("5", 160), ("5", 192),
-                                       ("54", 200), ("6", 200)])
+                                       ("54", 200), ("6", 200), ("7", 200), ("8", 200)])
 def test_fir_kernel_variants_all_match_oracle(variant, M):
     """the down-converter's alternative kernels stay selectable (ACG_FIR_VARIANT: 0 one workgroup per
     segment, 1/2 static persistent partition without/with non-temporal loads, 3 the workgroup-granular dynamic
     dispenser, 4 LDS-DMA double buffering, 5 the default wave-private streaming kernel, 54 the same with 127.37
-    subtracted per sample, 6 the matrix-pipe experiment): each one against the oracle, in a fresh process."""
+    subtracted per sample, 6 the matrix-pipe experiment, 7 the wave-private kernel with register-resident taps, 8 the same
+    with the results parked in LDS and written in chip-wide bursts): each one against the oracle, in a fresh process."""
     env = dict(os.environ, ACG_FIR_VARIANT=variant)
     r = subprocess.run([sys.executable, "-c", FIR_VARIANT_CHILD % dict(root=ROOT), str(M)], capture_output=True, text=True,
                        timeout=600, env=env)
     assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("OK"), (r.stdout[-500:], r.stderr[-1500:])
 
 
-@pytest.mark.parametrize("M,ntaps", [(200, 200), (200, 192), (160, 160), (192, 192)])
-def test_fir_direct_kernel_many_runs_scrambled_streams(D, O, M, ntaps):
+@pytest.mark.parametrize("M,ntaps,variant", [(200, 200, None), (200, 192, None), (160, 160, None), (192, 192, None),
+                                             (200, 200, "7"), (200, 192, "7"), (200, 200, "8"), (200, 192, "8")])
+def test_fir_direct_kernel_many_runs_scrambled_streams(D, O, M, ntaps, variant, monkeypatch):
     """the wave-private streaming kernel where its run dispenser matters: far more runs than resident waves (every
     wave goes through many tickets, shards run dry and waves move on to the next shard), a channel -> stream map that
     is a permutation (row lookup instead of the identity shortcut), fewer taps than the window (zero columns), and
     three launches in a row on the same dispenser (it re-arms itself).  Every channel against the oracle."""
+    if variant:
+        monkeypatch.setenv("ACG_FIR_VARIANT", variant)      # (read at every launch) 7: register-resident taps, 26 loads per tile
     rng = np.random.default_rng(4242 + M + ntaps)
     nch, nblk = 300, 8
     nout = nblk * 1024
