@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <rocprofiler-sdk-roctx/roctx.h>
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -743,6 +744,22 @@ extern "C" int acg_sync(acg_ctx* ctx)
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->msk_stream));
     return ACG_OK;
+}
+
+extern "C" int acg_placement_trial(acg_ctx* ctx, const uint8_t* iq_dev, size_t pitch_bytes, int nblocks, int repeats,
+                                   void* hip_stream, double* ms_per_call)
+{
+    if (!ctx || !ms_per_call || repeats < 1) return ACG_EINVAL;
+    int rc = acg_process_iq_u8_dev(ctx, iq_dev, pitch_bytes, nblocks, hip_stream);      // untimed (and the argument check)
+    if (rc != ACG_OK) return rc;
+    HIPCHK(ctx, hipDeviceSynchronize());
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < repeats && rc == ACG_OK; ++i) rc = acg_process_iq_u8_dev(ctx, iq_dev, pitch_bytes, nblocks, hip_stream);
+    HIPCHK(ctx, hipDeviceSynchronize());
+    const auto t1 = std::chrono::steady_clock::now();
+    *ms_per_call = std::chrono::duration<double, std::milli>(t1 - t0).count() / repeats;
+    const int rr = acg_reset(ctx);
+    return rc != ACG_OK ? rc : rr;
 }
 
 // ------------------------------------------------------------------------------------------

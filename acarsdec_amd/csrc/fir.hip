@@ -786,7 +786,7 @@ __device__ __forceinline__ void fird_tile(u4v_t* st /* [U] */, __amdgpu_buffer_r
 #pragma unroll
     for (int j = 0; j < CPR; ++j) D = D + Pr[j];
     if (FOLD) D = D - dc;
-    if (WT) {                                                      // write-through store (ACG_FIR_VARIANT=55): see firc_flush
+    if (WT) {                                                      // write-through store (the default; 55 = write-back): see firc_flush
         float* p = dm_out + lane;
         const float v = cabs_like_glibc(D.x, D.y);
         asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
@@ -2190,16 +2190,17 @@ extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
     if ((variant == 5 || (variant >= 50 && variant <= 55)) && a->nwin > 0 && a->nwin % ACG_TILE_WIN == 0 && (a->nwin / ACG_TILE_WIN) % FIRD_R == 0 &&
         (long long)a->nch * (a->nwin / ACG_TILE_WIN) < (1ll << 31) && a->ntaps_pad <= a->decim) {
         switch (a->cpr) {
-        case 20: return launch_direct<20>(a, num_cu, (hipStream_t)stream);
-        case 24: return launch_direct<24>(a, num_cu, (hipStream_t)stream);
+        // (dm is stored write-through: beside the streaming reads a write-back line costs more, see firc_flush)
+        case 20: return launch_direct<20, 0, 0, true, true>(a, num_cu, (hipStream_t)stream);
+        case 24: return launch_direct<24, 0, 0, true, true>(a, num_cu, (hipStream_t)stream);
         case 25:          // 50..54: measurement knobs (staging slots, burst length, 127.37 per sample)
             if (variant == 50) return launch_direct<25, 10, 1>(a, num_cu, (hipStream_t)stream);
             if (variant == 51) return launch_direct<25, 25, 5>(a, num_cu, (hipStream_t)stream);
             if (variant == 52) return launch_direct<25, 25, 10>(a, num_cu, (hipStream_t)stream);
             if (variant == 53) return launch_direct<25, 10, 10>(a, num_cu, (hipStream_t)stream);
             if (variant == 54) return launch_direct<25, 0, 0, false>(a, num_cu, (hipStream_t)stream);      // 127.37 subtracted per sample
-            if (variant == 55) return launch_direct<25, 0, 0, true, true>(a, num_cu, (hipStream_t)stream);  // dm stored write-through
-            return launch_direct<25>(a, num_cu, (hipStream_t)stream);
+            if (variant == 55) return launch_direct<25>(a, num_cu, (hipStream_t)stream);                    // dm stored write-back (round 2a)
+            return launch_direct<25, 0, 0, true, true>(a, num_cu, (hipStream_t)stream);
         default: break;
         }
     }

@@ -161,6 +161,12 @@ class Decoder:
     def fir_only(self, iq_dev, nblocks, pitch, stream=None):
         _chk(self.ctx, self.L.acg_fir_only_dev(self.ctx, iq_dev.data_ptr(), pitch, nblocks, stream))
 
+    def placement_trial(self, iq_dev, nblocks, pitch, repeats=2, stream=None):
+        """ms per in_callback-sized call on this decoder's placement (acg_placement_trial); the decoder comes back reset."""
+        ms = C.c_double(0)
+        _chk(self.ctx, self.L.acg_placement_trial(self.ctx, iq_dev.data_ptr(), pitch, nblocks, repeats, stream, C.byref(ms)))
+        return ms.value
+
     def demod_msk(self, dm):
         """demodMSK() for all channels from 12.5 kHz samples: dm float32 [nch, len]."""
         dm = np.ascontiguousarray(dm, dtype=np.float32)
@@ -242,3 +248,17 @@ class Decoder:
 def frame_tuple(f):
     """(chn, len, err, crc, txt) -- the bit-exact part of a block."""
     return (int(f.chn), int(f.len), int(f.err), bytes(f.crc), bytes(f.txt[: max(0, f.len)]))
+
+
+def best_placed(factory, n, iq_dev, nblocks, pitch, repeats=2, stream=None):
+    """Creates `n` decoders with factory() -- all alive during the trials, so that their buffers lie in different places --
+    times the same call on each (Decoder.placement_trial) and keeps the fastest.  Returns (decoder, [ms per call], index)."""
+    decs = [factory() for _ in range(max(1, n))]
+    if len(decs) == 1:
+        return decs[0], [], 0
+    ms = [d.placement_trial(iq_dev, nblocks, pitch, repeats, stream) for d in decs]
+    best = min(range(len(decs)), key=lambda i: ms[i])
+    for i, d in enumerate(decs):
+        if i != best:
+            d.close()
+    return decs[best], ms, best

