@@ -30,6 +30,38 @@ def test_library_exports_every_declared_symbol():
     assert L.acg_strerror(K.ENODEV).startswith(b"no GPU")
 
 
+def test_best_placed_keeps_the_fastest_context_and_closes_the_rest():
+    """decoder.best_placed (the host side of acg_placement_trial): every candidate is created before the first trial (so
+    that their allocations differ), each is timed once, the fastest is kept and the others are closed; n = 1 takes the first
+    without a trial."""
+    log = []
+
+    class Fake:
+        def __init__(self, ms):
+            self.ms, self.closed = ms, False
+            log.append(("create", ms))
+
+        def placement_trial(self, iq, nblocks, pitch, repeats, stream):
+            assert not self.closed and (nblocks, pitch, repeats) == (8, 4096, 2)
+            log.append(("trial", self.ms))
+            return self.ms
+
+        def close(self):
+            self.closed = True
+    times = iter([3.0, 1.5, 2.0])
+    made = []
+
+    def factory():
+        made.append(Fake(next(times)))
+        return made[-1]
+    dec, ms, best = D.best_placed(factory, 3, object(), 8, 4096)
+    assert ms == [3.0, 1.5, 2.0] and best == 1 and dec is made[1]
+    assert [m.closed for m in made] == [True, False, True]
+    assert [k for k, _ in log] == ["create"] * 3 + ["trial"] * 3           # all alive before the first trial
+    one, ms1, best1 = D.best_placed(lambda: Fake(9.0), 1, object(), 8, 4096)
+    assert ms1 == [] and best1 == 0 and not one.closed
+
+
 @pytest.mark.skipif(has_gpu(), reason="only meaningful on a box without a GPU")
 def test_no_gpu_means_loud_failure_not_fallback():
     with pytest.raises(K.AcgError) as e:
