@@ -16,6 +16,7 @@
 #include "acg_internal.h"
 
 extern "C" void acg_host_msk_h(float* h);
+extern "C" void acg_host_sincos_table(double* tab);
 extern "C" float acg_host_level_db(double lvlsum, int bitcount);
 extern "C" void acg_host_crc_tables(unsigned short* crc, unsigned short* synd);
 extern "C" void acg_host_crc_tables_n(unsigned short* crc, unsigned short* synd, int nk);
@@ -74,6 +75,7 @@ struct acg_ctx {
     int gbase = 0;                  // offset of the current buffer's guards in msk_done / msk_done_owner
     AcgChan* d_st = nullptr;
     float* d_h = nullptr;
+    double* d_sctab = nullptr;      // (cos, sin) table of the demodulator's mixer
     unsigned char* d_txt = nullptr;
     AcgFrameRec* d_frames = nullptr;
     unsigned int* d_frame_count = nullptr;
@@ -152,7 +154,7 @@ static void free_all(acg_ctx* c)
 {
     if (!c) return;
     hipFree(c->d_taps); hipFree(c->d_stream_of); hipFree(c->d_groups); hipFree(c->d_group_ch); hipFree(c->d_gtaps); hipFree(c->d_dm_all); hipFree(c->d_st);
-    hipFree(c->d_h); hipFree(c->d_txt); hipFree(c->d_frames); hipFree(c->d_frame_count);
+    hipFree(c->d_h); hipFree(c->d_sctab); hipFree(c->d_txt); hipFree(c->d_frames); hipFree(c->d_frame_count);
     hipFree(c->d_stamp);
     hipFree(c->d_msgs); std::free(c->h_msgs);
     hipFree(c->d_bits); hipFree(c->d_nbits); hipFree(c->d_stage); hipFree(c->d_work); hipFree(c->d_msk_done); std::free(c->h_stage); hipFree(c->d_crctab); hipFree(c->d_rep_upto);
@@ -340,6 +342,10 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
         float h[136] = {0};
         acg_host_msk_h(h);                               // msk.c:44-48
         HIPCHK(c, hipMemcpy(c->d_h, h, sizeof(h), hipMemcpyHostToDevice));
+        double sct[2 * ACG_SINCOS_N];
+        acg_host_sincos_table(sct);                      // the mixer's cexp(-p*I), msk.c:86-91
+        HIPCHK(c, hipMalloc(&c->d_sctab, sizeof(sct)));
+        HIPCHK(c, hipMemcpy(c->d_sctab, sct, sizeof(sct), hipMemcpyHostToDevice));
         HIPCHK(c, hipMalloc(&c->d_groups, nch * sizeof(int4)));
         HIPCHK(c, hipMalloc(&c->d_group_ch, nch * sizeof(int)));
         HIPCHK(c, hipMalloc(&c->d_gtaps, nch * (size_t)c->ntaps_pad * 2 * sizeof(float)));
@@ -537,6 +543,7 @@ static int launch_msk(acg_ctx* c, const float* dm_dev, size_t pitch_floats, int 
     a.dm = dm_dev;
     a.dm_pitch = pitch_floats;
     a.h = c->d_h;
+    a.sctab = c->d_sctab;
     a.txt = c->d_txt;
     a.frames = c->d_frames;
     a.frame_count = c->d_frame_count;
@@ -1245,16 +1252,19 @@ extern "C" int acg_selftest_sincos(const double* x_host, double* sin_host, doubl
     if (!x_host || !sin_host || !cos_host || n < 1) return ACG_EINVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return ACG_ENODEV;
-    double *dx = nullptr, *ds = nullptr, *dc = nullptr;
+    double *dx = nullptr, *ds = nullptr, *dc = nullptr, *dt = nullptr;
     const size_t b = (size_t)n * sizeof(double);
+    double sct[2 * ACG_SINCOS_N];
+    acg_host_sincos_table(sct);
     int rc = ACG_EHIP;
     if (hipMalloc(&dx, b) == hipSuccess && hipMalloc(&ds, b) == hipSuccess && hipMalloc(&dc, b) == hipSuccess &&
+        hipMalloc(&dt, sizeof(sct)) == hipSuccess && hipMemcpy(dt, sct, sizeof(sct), hipMemcpyHostToDevice) == hipSuccess &&
         hipMemcpy(dx, x_host, b, hipMemcpyHostToDevice) == hipSuccess &&
-        acg_launch_sincos_selftest(dx, ds, dc, n, nullptr) == 0 &&
+        acg_launch_sincos_selftest(dx, ds, dc, n, dt, nullptr) == 0 &&
         hipMemcpy(sin_host, ds, b, hipMemcpyDeviceToHost) == hipSuccess &&
         hipMemcpy(cos_host, dc, b, hipMemcpyDeviceToHost) == hipSuccess)
         rc = ACG_OK;
-    hipFree(dx); hipFree(ds); hipFree(dc);
+    hipFree(dx); hipFree(ds); hipFree(dc); hipFree(dt);
     return rc;
 }
 

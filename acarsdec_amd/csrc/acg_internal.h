@@ -105,6 +105,7 @@ struct FirArgs {
 // Run dispenser of one launch in flight: words [0], [1] = {tickets, finished} of the workgroup-granular
 // kernels; the wave-granular kernel uses ACG_DISP_SHARDS ticket words, one 128-byte line apart (so that the
 // atomics of different shards go to different L2 channels), and a `finished` word after them.
+#define ACG_SINCOS_N 128
 #define ACG_DISP_SHARDS 8
 #define ACG_DISP_STRIDE 32
 #define ACG_DISP_WORDS ((ACG_DISP_SHARDS + 1) * ACG_DISP_STRIDE)
@@ -114,6 +115,7 @@ struct MskArgs {
     const float* dm;            // [nch][dm_pitch]
     size_t dm_pitch;
     const float* h;             // [133] matched filter prototype (msk.c:44-48)
+    const double* sctab;        // [ACG_SINCOS_N][2] (cos, sin) of j * 2 pi / N (acg_host_sincos_table)
     unsigned char* txt;         // [nch][256] blk->txt being assembled
     AcgFrameRec* frames;        // queue
     unsigned int* frame_count;  // queue length (atomic)
@@ -146,7 +148,7 @@ int acg_launch_msk(const MskArgs* a, int lanes_per_channel, void* stream);
 int acg_launch_blk_repair(AcgFrameRec* frames, unsigned int cap, const unsigned int* count, unsigned int* done_upto,
                           const unsigned short* synd, const unsigned short* crctab, void* stream);
 int acg_launch_msg_split(const AcgFrameRec* frames, unsigned int cap, unsigned int first, unsigned int n, AcgMsgRec* out, void* stream);
-int acg_launch_sincos_selftest(const double* x, double* s, double* c, int n, void* stream);
+int acg_launch_sincos_selftest(const double* x, double* s, double* c, int n, const double* sctab, void* stream);
 int acg_launch_div2_selftest(const double* n0, const double* n1, const double* d, double* out, int n, void* stream);
 int acg_launch_synth_iq(uint8_t* iq, size_t pitch, int nrows, int nout, int decim, const float* env,
                         size_t env_pitch, const int* env_index, const float* off_hz, const float* phase,

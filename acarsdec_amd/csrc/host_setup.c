@@ -7,6 +7,7 @@
  *   acg_rtl_choose_fc   <- rtl.c:131-168  chooseFc()
  *   acg_rtl_taps        <- rtl.c:283-286  the per-channel NCO*boxcar taps wf[]
  *   acg_host_msk_h      <- msk.c:44-48    the matched-filter prototype h[]
+ *   acg_host_sincos_table  (msk.c:86-91)  table behind the device's cexp(-p*I)
  *   acg_host_level_db   <- acars.c:351    blk->lvl
  */
 #include <math.h>
@@ -15,6 +16,9 @@
 #include "acarsdec_amd.h"
 
 #define FLENO (ACG_FLEN * 12 + 1)
+#ifndef ACG_SINCOS_N
+#define ACG_SINCOS_N 128
+#endif
 
 unsigned int acg_rtl_choose_fc(unsigned int *Fd, unsigned int nbch, int decim)
 {
@@ -76,6 +80,18 @@ void acg_host_msk_h(float *h)
 		/* msk.c:46-47 */
 		const float c = cosf(2.0 * M_PI * 600.0 / ACG_INTRATE / 12 * (i - (FLENO - 1) / 2));
 		h[i] = c < 0 ? 0 : c;
+	}
+}
+
+/* The demodulator's mixer (msk.c:86-91, cexp(-p*I)) on the device: (cos, sin) of j * 2 pi / 128, j = 0..127, correctly
+ * rounded to double (computed in x87 extended precision) -- the table behind msk.hip sincos_tab(). */
+void acg_host_sincos_table(double *tab)
+{
+	const long double d = 2.0L * 3.14159265358979323846264338327950288L / ACG_SINCOS_N;
+	int j;
+	for (j = 0; j < ACG_SINCOS_N; j++) {
+		tab[2 * j] = (double)cosl(j * d);
+		tab[2 * j + 1] = (double)sinl(j * d);
 	}
 }
 

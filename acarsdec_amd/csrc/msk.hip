@@ -192,6 +192,36 @@ __device__ __forceinline__ void sincos_2pi(double x, double* sn, double* cs)
     *cs = ((q + 1) & 2) ? -cc : cc;
 }
 
+// The mixer's sin/cos as the product ships it: a 128-entry table of (cos, sin)(j * 2 pi / 128) in LDS (correctly rounded
+// doubles, acg_host_sincos_table) and a rotation by the small remainder |r| <= pi / 128,
+//     cos p = cj + (cj (cos r - 1) - sj sin r),    sin p = sj + (sj (cos r - 1) + cj sin r),
+// with sin r - r and cos r - 1 from three-term series (next terms < 4e-19 relative).  23 vector instructions and one LDS
+// read instead of ~40 for sincos_2pi above (no quadrant logic, shorter polynomials) on a loop that is bound by the number
+// of instructions it issues.  Error <= 2.1 ulp (the table entry's and the last addition's rounding dominate)
+// where sincos_2pi has < 1; what the demodulator keeps is (float)(in * cos), (float)(in * -sin) (msk.c:90), and on 4e7 random
+// phases those are identical to glibc cexp's for both (tests/sincos_model.c: the same operations on the CPU, in the CPU suite).
+__device__ __forceinline__ void sincos_tab(double x, const double* __restrict__ tab /* LDS, [128][2] */, double* sn, double* cs)
+{
+    const double kd = __builtin_rint(x * (6.36619772367581382433e-01 * 32.0));   // x * 128 / (2 pi)
+    const int q = (int)kd;
+    double r = __builtin_fma(-kd, 1.57079632673412561417e+00 / 32.0, x);        // 2 pi / 128, high 33 bits (exact products: kd <= 128)
+    r = __builtin_fma(-kd, 6.07710050650619224932e-11 / 32.0, r);               // tail
+    const double2 e = *(const double2*)(tab + 2 * (q & (ACG_SINCOS_N - 1)));
+    const double cj = e.x, sj = e.y;
+    const double z = r * r;
+    double ps = __builtin_fma(z, -1.98412698412698412698e-04, 8.33333333333333333333e-03);
+    ps = __builtin_fma(z, ps, -1.66666666666666666667e-01);
+    const double sm = (r * z) * ps;                                              // sin r - r
+    double pc = __builtin_fma(z, -1.38888888888888888889e-03, 4.16666666666666666667e-02);
+    pc = __builtin_fma(z, pc, -0.5);
+    const double cm1 = z * pc;                                                   // cos r - 1
+    const double sr = r + sm;
+    const double u = __builtin_fma(cj, cm1, -(sj * sr));
+    const double w = __builtin_fma(sj, cm1, cj * sr);
+    *cs = cj + u;
+    *sn = sj + w;
+}
+
 // n0 / d and n1 / d, both correctly rounded, for d in [1e-8, ~1e2] and |n| < ~1e2 or n == +0 (the matched filter's
 // sum starts from +0 and so is never -0, the one numerator whose quotient would come out as +0 here): see the call site.
 // acg_selftest_div2 compares it with the compiler's IEEE division on the device.
@@ -301,6 +331,7 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
     // address o * 4 (placed after the ring, every pair of reads needed its own base register)
     struct alignas(16) Lds {
         float hs[(FLEN * MFLTOVER + 1 + 3) & ~3];
+        double sc[2 * ACG_SINCOS_N];               // (cos, sin)(j * 2 pi / 128): the mixer's table, 2 KiB
         float2 ring_all[WPG][3 * FLEN + 1][CPW];   // rows 0..21: inb[] twice; rows 22 and 33: where lanes without a sample write
         float win_all[WPG][CPW][WSTR];             // sliding window of dm: blocks j and j+1
     };
@@ -308,6 +339,7 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
     float* hs = lds.hs;
 
     for (int i = threadIdx.x; i < FLEN * MFLTOVER + 1; i += 64 * WPG) hs[i] = a.h[i];
+    for (int i = threadIdx.x; i < 2 * ACG_SINCOS_N; i += 64 * WPG) lds.sc[i] = a.sctab[i];
 
     const int wv = threadIdx.x >> 6;               // the waves of a workgroup never talk to each other
     const int tid = threadIdx.x & 63;
@@ -539,7 +571,11 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
                 // only the ring row differs: no branch around the mixer, so it schedules as one block with the tap-phase
                 // divide and the first filter taps around it (0.8 % per bit)
                 double sn, cs;
-                sincos_2pi(myp[j], &sn, &cs);
+#ifdef ACG_MSK_SINCOS_POLY
+                sincos_2pi(myp[j], &sn, &cs);                              // (A/B builds: the < 1 ulp polynomial version)
+#else
+                sincos_tab(myp[j], lds.sc, &sn, &cs);
+#endif
                 const double in = (double)in_cur[j];
                 unsigned int k = idx + (unsigned int)u;
                 if (k >= FLEN) k -= FLEN;
@@ -691,10 +727,13 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
 
 
 // test hook: the device sin/cos used by the mixer, on n arguments
-__global__ void sincos_selftest_kernel(const double* x, double* s, double* c, int n)
+__global__ void sincos_selftest_kernel(const double* x, double* s, double* c, int n, const double* sctab)
 {
+    __shared__ double sc[2 * ACG_SINCOS_N];
+    for (int i = threadIdx.x; i < 2 * ACG_SINCOS_N; i += blockDim.x) sc[i] = sctab[i];
+    __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) sincos_2pi(x[i], &s[i], &c[i]);
+    if (i < n) sincos_tab(x[i], sc, &s[i], &c[i]);
 }
 
 // test hook: the shared-reciprocal quotients of the normalisation against the compiler's IEEE division
@@ -721,9 +760,9 @@ extern "C" int acg_launch_div2_selftest(const double* n0, const double* n1, cons
     return (int)hipGetLastError();
 }
 
-extern "C" int acg_launch_sincos_selftest(const double* x, double* s, double* c, int n, void* stream)
+extern "C" int acg_launch_sincos_selftest(const double* x, double* s, double* c, int n, const double* sctab, void* stream)
 {
-    hipLaunchKernelGGL(sincos_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, s, c, n);
+    hipLaunchKernelGGL(sincos_selftest_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, s, c, n, sctab);
     return (int)hipGetLastError();
 }
 

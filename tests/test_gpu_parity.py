@@ -615,20 +615,29 @@ def test_many_channels_synthetic_msk(D, O, S):
     dec.close()
 
 
-def test_device_sincos_within_one_ulp_of_libm(D):
-    """the mixer's sin/cos (msk.c:90 calls cexp): device result vs libm on 2e5 phases in [0, 2*pi)"""
+def test_device_sincos_keeps_the_mixer_products_of_libm(D):
+    """the mixer's sin/cos (msk.c:90 calls cexp) is a 128-entry table + a rotation by the remainder (msk.hip sincos_tab):
+    device result vs libm on 2e5 phases in [0, 2*pi): <= 2.5 ulp (3e-17 absolute near the zeros), and the float-rounded
+    products in * cos, in * -sin -- what the demodulator keeps -- identical to libm's."""
     from acarsdec_amd import _capi as K
     rng = np.random.default_rng(9)
     x = np.concatenate([rng.uniform(0, 2 * np.pi, 200000), [0.0, np.pi / 4, np.pi / 2, np.pi, 1.5 * np.pi, 2 * np.pi - 1e-15],
-                        np.arange(8) * (np.pi / 4) + 1e-9, np.arange(1, 9) * (np.pi / 4) - 1e-9])
+                        np.arange(8) * (np.pi / 4) + 1e-9, np.arange(1, 9) * (np.pi / 4) - 1e-9,
+                        np.arange(129) * (2 * np.pi / 128), (np.arange(128) + 0.5) * (2 * np.pi / 128)])
+    x = x[x < 2 * np.pi + 1e-12]
     s = np.zeros_like(x)
     c = np.zeros_like(x)
     assert K.load().acg_selftest_sincos(x.ctypes.data, s.ctypes.data, c.ctypes.data, x.size) == 0
     for got, want in ((s, np.sin(x)), (c, np.cos(x))):
         ulp = np.abs(got - want) / np.maximum(np.spacing(np.abs(want)), 2.0 ** -80)
-        ok = (ulp <= 1.0) | (np.abs(got - want) < 3e-17)      # absolute bound near the zeros
+        ok = (ulp <= 2.5) | (np.abs(got - want) < 3e-17)      # absolute bound near the zeros
         assert ok.all(), (ulp.max(), x[np.argmax(ulp)])
-    assert (s == np.sin(x)).mean() > 0.8 and (c == np.cos(x)).mean() > 0.8      # most are bit-identical to libm
+    assert (s == np.sin(x)).mean() > 0.7 and (c == np.cos(x)).mean() > 0.7      # most are bit-identical to libm
+    amp = rng.uniform(1e-3, 1.0, x.size).astype(np.float32).astype(np.float64)
+    for got, want in ((c, np.cos(x)), (-s, -np.sin(x))):
+        # (at the zeros of sin / cos both are ~1e-16 and differ by ~1e-20: a product of that size is nothing in the filter's sum)
+        far = np.abs(want) > 1e-9
+        assert np.count_nonzero(((amp * got).astype(np.float32) != (amp * want).astype(np.float32)) & far) <= 1
 
 
 @pytest.mark.parametrize("lpc", [1, 2, 4, 8])

@@ -30,6 +30,34 @@ def test_library_exports_every_declared_symbol():
     assert L.acg_strerror(K.ENODEV).startswith(b"no GPU")
 
 
+def test_device_sincos_model_keeps_the_mixer_products_of_glibc_cexp(tmp_path):
+    """msk.hip sincos_tab (128-entry table + rotation by the remainder) restated on the CPU operation for operation
+    (tests/sincos_model.c): <= 2.5 ulp against long-double libm, and -- what the demodulator keeps, msk.c:90 -- every
+    float-rounded product in * cos, in * -sin identical to glibc cexp's on 4e6 random phases.  Also pins the constants of
+    the device function to the model's."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("gcc not available")
+    exe = str(tmp_path / "sincos_model")
+    r = subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tests", "sincos_model.c"), "-lm"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe, "4000000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    m = re.search(r"sin ([0-9.]+) ulp, cos ([0-9.]+) ulp; bit-identical to libm: sin ([0-9.]+) %, cos ([0-9.]+) %", r.stdout)
+    assert m and float(m.group(1)) <= 2.5 and float(m.group(2)) <= 2.5 and float(m.group(3)) > 70 and float(m.group(4)) > 70, r.stdout
+    m = re.search(r"differ from glibc cexp: (\d+) of (\d+)", r.stdout)
+    assert m and int(m.group(1)) == 0 and int(m.group(2)) == 8000000, r.stdout
+    dev = open(os.path.join(ROOT, "acarsdec_amd", "csrc", "msk.hip")).read()
+    dev = dev[dev.index("void sincos_tab("):dev.index("// n0 / d and n1 / d")]
+    model = open(os.path.join(ROOT, "tests", "sincos_model.c")).read()
+    consts = set(re.findall(r"-?\d\.\d{10,}e[-+]\d+", dev))
+    assert len(consts) >= 7 and consts <= set(re.findall(r"-?\d\.\d{10,}e[-+]\d+", model)), consts
+    host = open(os.path.join(ROOT, "acarsdec_amd", "csrc", "host_setup.c")).read()
+    assert "ACG_SINCOS_N 128" in host and "cosl(j * d)" in host and "tab[128][2]" in model
+
+
 def test_best_placed_keeps_the_fastest_context_and_closes_the_rest():
     """decoder.best_placed (the host side of acg_placement_trial): every candidate is created before the first trial (so
     that their allocations differ), each is timed once, the fastest is kept and the others are closed; n = 1 takes the first
