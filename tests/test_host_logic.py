@@ -58,6 +58,29 @@ def test_device_sincos_model_keeps_the_mixer_products_of_glibc_cexp(tmp_path):
     assert "ACG_SINCOS_N 128" in host and "cosl(j * d)" in host and "tab[128][2]" in model
 
 
+def test_coltap_load_groups_cover_a_tile_with_two_fixed_columns_per_lane():
+    """fir.hip FirC (ACG_FIR_VARIANT=7 / 8): a 64-window tile at 2.5 Msps is 1600 chunks of 16 bytes; step q of a tile loads
+    chunks chunk0(q) + lane with chunk0(q) = 125 (q / 2) + 64 (q % 2).  Claimed there: every chunk of the tile is written last by
+    the lane that loaded exactly that chunk, a lane multiplies column lane % 25 in every even step and (lane + 14) % 25 in
+    every odd one, idle lanes only ever land in slots that are overwritten later or in the 28 pad entries, and the byte offsets
+    of a two-tile body are what FirC::offset computes.  The constants are read from the source."""
+    src = open(os.path.join(ROOT, "acarsdec_amd", "csrc", "fir.hip")).read()
+    src = src[src.index("struct FirC {"):src.index("// Complex multiply-accumulate of one sample")]
+    assert "SPT = 26" in src and "(q >> 1) * 125 + (q & 1) * 64" in src and "P_ENT = 64 * CPR + 28" in src
+    assert "(pos / SPT) * (CPR * 1024u) + (unsigned int)chunk0(pos % SPT) * 16u" in src
+    slot = {}
+    for q in range(26):
+        base = (q >> 1) * 125 + (q & 1) * 64
+        for lane in range(64):
+            col = lane % 25 if q % 2 == 0 else (lane + 14) % 25
+            slot[base + lane] = (base + lane, col)                  # (chunk the lane loaded, column of the taps it used)
+    assert all(slot[i] == (i, i % 25) for i in range(1600))         # every chunk: its own bytes times its own column
+    assert max(slot) == 1600 + 28 - 1                               # idle lanes of the last load: the pad entries
+    offs = [(pos // 26) * 25600 + ((pos % 26 >> 1) * 125 + (pos % 26 & 1) * 64) * 16 for pos in range(52)]
+    assert offs[0] == 0 and offs[1] == 1024 and offs[2] == 2000 and offs[26] == 25600 and offs[51] + 36 * 16 == 51200
+    assert all(o % 16 == 0 for o in offs) and sorted(offs) == offs
+
+
 def test_best_placed_keeps_the_fastest_context_and_closes_the_rest():
     """decoder.best_placed (the host side of acg_placement_trial): every candidate is created before the first trial (so
     that their allocations differ), each is timed once, the fastest is kept and the others are closed; n = 1 takes the first
