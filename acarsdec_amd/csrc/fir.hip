@@ -2170,9 +2170,10 @@ extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
     FirDev* fd = nullptr;
     if (int e = fir_device(&fd)) return e;
     const int num_cu = fd->num_cu;
-    // ACG_FIR_VARIANT: 5 (default) wave-private streaming kernel where it applies, else 3; 0 one workgroup per
-    // segment; 1 / 2 static persistent partition without / with non-temporal loads; 3 workgroup-granular dynamic
-    // dispenser; 4 LDS-DMA double buffering
+    // ACG_FIR_VARIANT: 5 (default) wave-private streaming kernel where it applies (dm stored write-through), else 3;
+    // 0 one workgroup per segment; 1 / 2 static persistent partition without / with non-temporal loads; 3 workgroup-
+    // granular dynamic dispenser; 4 LDS-DMA double buffering; 6 matrix pipe; 7 taps in registers; 8 = 7 with the results
+    // parked in LDS and written in chip-wide bursts; 50..55, 70..73 measurement knobs of 5 and 7 (55: write-back stores)
     const int variant = env_int("ACG_FIR_VARIANT", 5);
     if ((variant == 7 || variant == 8 || (variant >= 70 && variant <= 73)) && a->cpr == 25 && a->nwin > 0 && a->nwin % ACG_TILE_WIN == 0 && (a->nwin / ACG_TILE_WIN) % FIRD_R == 0 &&
         (long long)a->nch * (a->nwin / ACG_TILE_WIN) < (1ll << 31) && a->ntaps_pad <= a->decim)
