@@ -205,42 +205,89 @@ static void sweep(const unsigned char* d, size_t nbytes, float* out, unsigned in
 
 int main(int argc, char** argv)
 {
+    // write_beside_read_probe [GiB of input = 24] [experiment = 0: all]
+    //   1 store shapes on three output allocations   2 chip-wide bursts by epoch length   3 offsets inside one 6 GiB allocation
+    //   4 allocation sizes   5 two inputs x several outputs (the pair decides)
+    // (profiles/r02_experiments/write_beside_read{,_2,_3}.txt: 1 (+ 2 in _3);  _4: 3;  _5: 4;  _6: 5)
     const size_t nbytes = (argc > 1 ? (size_t)atof(argv[1]) : 24.0) * (1ull << 30);
+    const int which = argc > 2 ? atoi(argv[2]) : 0;
     unsigned char* d = nullptr;
     unsigned int* sink = nullptr;
     if (hipMalloc(&d, nbytes) != hipSuccess || hipMalloc(&sink, 4) != hipSuccess) { printf("alloc failed\n"); return 1; }
-    hipMemset(d, 0x5a, nbytes);
+    (void)hipMemset(d, 0x5a, nbytes);
     const size_t out_bytes = nbytes / 100 + (1 << 20);           // 256 B per 25.6 KB
     float* outs[3] = {nullptr, nullptr, nullptr};
     void* spacer[3] = {nullptr, nullptr, nullptr};
     for (int i = 0; i < 3; ++i) {
         if (hipMalloc(&outs[i], out_bytes) != hipSuccess) { printf("alloc failed\n"); return 1; }
-        hipMalloc(&spacer[i], (size_t)(i + 1) * 37 * 4096 * 1024 + 12345);       // the next output buffer lands elsewhere
+        (void)hipMalloc(&spacer[i], (size_t)(i + 1) * 37 * 4096 * 1024 + 12345);       // the next output buffer lands elsewhere
     }
-    hipDeviceSynchronize();
+    (void)hipDeviceSynchronize();
     printf("input %.1f GiB at %p; outputs of %.0f MiB at %p %p %p\n", nbytes / 1073741824.0, (void*)d, out_bytes / 1048576.0, (void*)outs[0],
            (void*)outs[1], (void*)outs[2]);
-    if (argc > 2 && atoi(argv[2]) == 1) {
+    if (which == 0 || which == 1) {
         sweep<5, 16>(d, nbytes, outs[0], sink, 2, "output buffer 0");
+        sweep<5, 16>(d, nbytes, outs[1], sink, 2, "output buffer 1");
         sweep<5, 16>(d, nbytes, outs[2], sink, 2, "output buffer 2");
     }
-    // is "good" / "bad" a property of the output allocation alone, or of the pair (input, output)?
-    unsigned char* d2 = nullptr;
-    if (hipMalloc(&d2, nbytes) != hipSuccess) { printf("second input alloc failed\n"); return 1; }
-    hipMemset(d2, 0x33, nbytes);
-    hipDeviceSynchronize();
-    printf("second input at %p.  output = base of a fresh allocation; plain per-tile store with input 1 | input 2 | input 1, second half of the input only\n", (void*)d2);
-    const size_t sizes_mib[] = {248, 256, 512, 248, 1024, 248, 300, 400, 248, 2048, 248};
-    void* keepalive[16] = {nullptr};
-    int nk = 0;
-    for (size_t mib : sizes_mib) {
-        void* a = nullptr;
-        if (hipMalloc(&a, mib << 20) != hipSuccess) { printf("alloc of %zu MiB failed\n", mib); break; }
-        keepalive[nk++] = a;
-        float* out = (float*)a;
-        printf("   %5zu MiB at %p: %6.0f | %6.0f | %6.0f GB/s\n", mib, a, run<W_TILE, 5, 16>(d, nbytes, out, sink, 2),
-               run<W_TILE, 5, 16>(d2, nbytes, out, sink, 2), run<W_TILE, 5, 16>(d + nbytes / 2, nbytes / 2, out, sink, 2));
-        fflush(stdout);
+    if (which == 0 || which == 2) {
+        for (int b = 0; b < 3; b += 2) {
+            printf("output buffer %d, 8 waves per CU, runs of 64 tiles, results held in LDS (up to 32 tiles) and flushed when the 100 MHz clock crosses 2^k ticks:\n", b);
+            printf("   no clock, flushed every 32 tiles (k = 40)  %6.0f GB/s\n", run_epoch<40, 5, 64, 32>(d, nbytes, outs[b], sink, 2));
+            printf("   k = 10 (10 us)   %6.0f GB/s\n", run_epoch<10, 5, 64, 32>(d, nbytes, outs[b], sink, 2));
+            printf("   k = 11 (20 us)   %6.0f GB/s\n", run_epoch<11, 5, 64, 32>(d, nbytes, outs[b], sink, 2));
+            printf("   k = 12 (41 us)   %6.0f GB/s\n", run_epoch<12, 5, 64, 32>(d, nbytes, outs[b], sink, 2));
+            printf("   k = 13 (82 us)   %6.0f GB/s\n", run_epoch<13, 5, 64, 32>(d, nbytes, outs[b], sink, 2));
+            printf("   k = 14 (164 us)  %6.0f GB/s\n", run_epoch<14, 5, 64, 32>(d, nbytes, outs[b], sink, 2));
+            printf("   k = 15 (328 us)  %6.0f GB/s\n", run_epoch<15, 5, 64, 32>(d, nbytes, outs[b], sink, 2));
+            fflush(stdout);
+        }
+    }
+    if (which == 0 || which == 3) {
+        // placement inside ONE allocation: is it the address bits or the backing of the allocation?
+        unsigned char* slab = nullptr;
+        if (hipMalloc(&slab, 6ull << 30) != hipSuccess) { printf("slab alloc failed\n"); return 1; }
+        printf("slab of 6 GiB at %p: output at slab + offset;  plain per-tile store | run-end sc0 sc1 b128 | epoch 82 us (runs of 64)\n", (void*)slab);
+        const size_t offs[] = {0, 1ull << 20, 2ull << 20, 64ull << 20, 256ull << 20, 512ull << 20, 1ull << 30, (1ull << 30) + (300ull << 20), 2ull << 30,
+                               3ull << 30, (3ull << 30) + (64ull << 10), 4ull << 30, 5ull << 30};
+        for (size_t o : offs) {
+            float* out = (float*)(slab + o);
+            printf("   offset %8.2f MiB: %6.0f | %6.0f | %6.0f GB/s\n", o / 1048576.0, run<W_TILE, 5, 16>(d, nbytes, out, sink, 2),
+                   run<W_RUN_END_SC, 5, 16>(d, nbytes, out, sink, 2), run_epoch<13, 5, 64, 32>(d, nbytes, out, sink, 2));
+            fflush(stdout);
+        }
+        printf("the three separate allocations again (plain per-tile store): %6.0f %6.0f %6.0f GB/s\n", run<W_TILE, 5, 16>(d, nbytes, outs[0], sink, 2),
+               run<W_TILE, 5, 16>(d, nbytes, outs[1], sink, 2), run<W_TILE, 5, 16>(d, nbytes, outs[2], sink, 2));
+        (void)hipFree(slab);
+    }
+    if (which == 0 || which == 4) {
+        printf("output = base of a fresh allocation of the given size; plain per-tile store | run-end sc0 sc1 b128 | epoch 82 us\n");
+        const size_t sizes_mib[] = {248, 256, 248, 512, 248, 1024, 248, 2048, 248, 4096, 248, 8192, 248};
+        for (size_t mib : sizes_mib) {
+            void* a = nullptr;                                       // (kept alive: the next one lands elsewhere)
+            if (hipMalloc(&a, mib << 20) != hipSuccess) { printf("alloc of %zu MiB failed\n", mib); break; }
+            float* out = (float*)a;
+            printf("   %5zu MiB at %p: %6.0f | %6.0f | %6.0f GB/s\n", mib, a, run<W_TILE, 5, 16>(d, nbytes, out, sink, 2),
+                   run<W_RUN_END_SC, 5, 16>(d, nbytes, out, sink, 2), run_epoch<13, 5, 64, 32>(d, nbytes, out, sink, 2));
+            fflush(stdout);
+        }
+    }
+    if (which == 0 || which == 5) {
+        // is "good" / "bad" a property of the output allocation alone, or of the pair (input, output)?
+        unsigned char* d2 = nullptr;
+        if (hipMalloc(&d2, nbytes) != hipSuccess) { printf("second input alloc failed\n"); return 1; }
+        (void)hipMemset(d2, 0x33, nbytes);
+        (void)hipDeviceSynchronize();
+        printf("second input at %p.  output = base of a fresh allocation; plain per-tile store with input 1 | input 2 | input 1, second half of the input only\n", (void*)d2);
+        const size_t sizes_mib[] = {248, 256, 512, 248, 1024, 248, 300, 400, 248, 2048, 248};
+        for (size_t mib : sizes_mib) {
+            void* a = nullptr;
+            if (hipMalloc(&a, mib << 20) != hipSuccess) { printf("alloc of %zu MiB failed\n", mib); break; }
+            float* out = (float*)a;
+            printf("   %5zu MiB at %p: %6.0f | %6.0f | %6.0f GB/s\n", mib, a, run<W_TILE, 5, 16>(d, nbytes, out, sink, 2),
+                   run<W_TILE, 5, 16>(d2, nbytes, out, sink, 2), run<W_TILE, 5, 16>(d + nbytes / 2, nbytes / 2, out, sink, 2));
+            fflush(stdout);
+        }
     }
     return 0;
 }
