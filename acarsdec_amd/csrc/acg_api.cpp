@@ -568,7 +568,12 @@ static int launch_msk(acg_ctx* c, const float* dm_dev, size_t pitch_floats, int 
         HIPCHK(c, hipEventRecord(ev.a, s));
     }
     roctxRangePushA("acg:demodulator");
-    const int e = acg_launch_msk(&a, c->msk_lpc, s);
+    int lpc = c->msk_lpc;
+    if (const char* le = std::getenv("ACG_MSK_LPC_LIVE")) {         // measurement aid: lanes per channel per launch (the channel state
+        const int v = std::atoi(le);                                  // does not depend on it), for same-context A/B (bench.py --ab)
+        if (v == 1 || v == 2 || v == 4 || v == 8) lpc = v;
+    }
+    const int e = acg_launch_msk(&a, lpc, s);
     roctxRangePop();
     if (e != 0) {
         c->err = std::string("MSK launch: ") + hipGetErrorString((hipError_t)e);

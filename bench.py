@@ -389,10 +389,12 @@ def run_case(J, name, case, args, steps, warmup, headline):
         # measurement aid: the same decoder, buffers and placement, timed again under each down-converter variant in turn
         # (ACG_FIR_VARIANT is read at every launch), two rounds -- not part of the reported value
         ab = {}
-        keep = os.environ.get("ACG_FIR_VARIANT")
+        ab_name, _, ab_vals = args.ab.rpartition("=")                # "5,55,8" or "ACG_MSK_LPC_LIVE=2,4"
+        ab_name = ab_name or "ACG_FIR_VARIANT"
+        keep = os.environ.get(ab_name)
         for rnd in range(2):
-            for v in args.ab.split(","):
-                os.environ["ACG_FIR_VARIANT"] = v
+            for v in ab_vals.split(","):
+                os.environ[ab_name] = v
                 step()
                 dec.drain_frames_raw(maxfr)
                 torch.cuda.synchronize()
@@ -403,9 +405,9 @@ def run_case(J, name, case, args, steps, warmup, headline):
                 torch.cuda.synchronize()
                 ab.setdefault(v, []).append(round(nch * nout * M * steps / (time.perf_counter() - t1) / 1e6, 0))
         if keep is None:
-            del os.environ["ACG_FIR_VARIANT"]
+            del os.environ[ab_name]
         else:
-            os.environ["ACG_FIR_VARIANT"] = keep
+            os.environ[ab_name] = keep
     trials = None
     if args.decoders > 1 and world == 1:
         # measurement aid: further decoders in the same process (each with its own allocations, all kept alive), the same
@@ -539,7 +541,8 @@ def main():
     ap.add_argument("--bitlog", type=int, default=1, help="1: the demodulator also writes its per-bit soft symbols (vo, level: 8 B per bit) to HBM")
     ap.add_argument("--placements", type=int, default=4, help="contexts tried for placement before the run (1 = take the first)")
     ap.add_argument("--decoders", type=int, default=1, help="measurement aid: time this many decoders (separate allocations) in the same process")
-    ap.add_argument("--ab", default=None, help="measurement aid: comma-separated ACG_FIR_VARIANT values timed after the run in the same process")
+    ap.add_argument("--ab", default=None, help="measurement aid: comma-separated ACG_FIR_VARIANT values (or NAME=v1,v2 for another per-launch "
+                                               "switch, e.g. ACG_MSK_LPC_LIVE=2,4) timed after the run in the same process, same decoder")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-child", nargs=4, default=None)
     args = ap.parse_args()
