@@ -79,7 +79,7 @@ def build_lib(force=False, stamp=False):
         _run(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-I" + INC, "-c", src, "-o", obj])
     objs.append(obj)
     if force or _newer(objs, out_lib):
-        _run([hc, "--offload-arch=" + ARCH, "-shared", "-o", out_lib] + objs + ["-lrocprofiler-sdk-roctx", "-lm"])
+        _run([hc, "--offload-arch=" + ARCH, "-shared", "-o", out_lib] + objs + ["-ldl", "-lm"])
     return out_lib
 
 

@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ACARSDEC_AMD_LIB") or os.path.join(HERE, "lib", "libacarsdec_amd.so")
 
 OK, EINVAL, ENOMEM, EHIP, ENODEV, EOVERFLOW, ESTATE = 0, -1, -2, -3, -4, -5, -6
-F_BITLOG, F_TIMING, F_REPAIR = 1, 2, 4
+F_BITLOG, F_TIMING, F_REPAIR, F_EXACT_FIR = 1, 2, 4, 8
 INTRATE, BLOCK, MAXDECIM, FLEN, TXTMAX = 12500, 1024, 320, 11, 250
 MAXDECIM_SAMPLES = 1024
 FMT_CS16, FMT_S16_SPLIT, FMT_F32_REAL = 1, 2, 3
@@ -76,6 +76,8 @@ SYMBOLS = {
     "acg_read_bits": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "acg_read_bits_all": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "acg_bit_capacity": (C.c_int, [C.c_void_p]),
+    "acg_max_lag": (C.c_int, [C.c_void_p]),
+    "acg_tune": (C.c_int, [C.c_char_p, C.c_char_p]),
     "acg_read_dm": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "acg_get_state": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(ChanState)]),
     "acg_set_state": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(ChanState)]),
@@ -115,6 +117,14 @@ def load():
             fn.argtypes = args
         _lib = L
     return _lib
+
+
+def tune(name, value):
+    """Measurement switch NAME (ACG_...) := value for the following launches; None removes the override.  The library
+    reads the environment only once, at its first look-up, so changing os.environ later has no effect: use this."""
+    rc = load().acg_tune(name.encode(), None if value is None else str(value).encode())
+    if rc != OK:
+        raise AcgError(rc, "acg_tune(%s)" % name)
 
 
 class AcgError(RuntimeError):

@@ -2,12 +2,14 @@
 // Host runtime only: buffers, launches, result queues.  There is deliberately no CPU compute
 // path here: without a GPU acg_create() fails with ACG_ENODEV.
 #include <hip/hip_runtime.h>
-#include <rocprofiler-sdk-roctx/roctx.h>
+#include <dlfcn.h>
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -21,11 +23,90 @@ extern "C" float acg_host_level_db(double lvlsum, int bitcount);
 extern "C" void acg_host_crc_tables(unsigned short* crc, unsigned short* synd);
 extern "C" void acg_host_crc_tables_n(unsigned short* crc, unsigned short* synd, int nk);
 
+extern char** environ;
+
 namespace {
 
 struct EvPair { hipEvent_t a, b; };
 
+// ---- tuning overrides --------------------------------------------------------------------------------------------
+// Every measurement / layout switch of the library (ACG_FIR_VARIANT, ACG_MSK_LPC, ACG_FIR_DEBUG_*, ...) lives in ONE
+// table.  The environment is read ONCE, at the first look-up of the process, and whatever was picked up is reported on
+// stderr: a stray variable in a host process can no longer change results or speed silently, and no launch calls
+// getenv().  After that the table only changes through acg_tune() (bench.py --ab, the probes under profiles/probe).
+std::mutex g_tune_mx;
+std::map<std::string, std::string> g_tune;
+bool g_tune_ready = false;
+
+void tune_init_locked()
+{
+    if (g_tune_ready) return;
+    g_tune_ready = true;
+    std::string seen;
+    for (char** e = environ; e && *e; ++e) {
+        const char* kv = *e;
+        if (std::strncmp(kv, "ACG_", 4) != 0 || std::strncmp(kv, "ACG_BENCH_", 10) == 0) continue;
+        const char* eq = std::strchr(kv, '=');
+        if (!eq) continue;
+        g_tune[std::string(kv, (size_t)(eq - kv))] = std::string(eq + 1);
+        seen += std::string(" ") + kv;
+    }
+    if (!seen.empty())
+        std::fprintf(stderr, "acarsdec_amd: tuning overrides taken from the environment (measurement switches, not product "
+                             "configuration):%s\n", seen.c_str());
+}
+
+// ---- roctx ranges (rocprofv3 --marker-trace): bound at run time, so the library carries no profiler dependency ----
+typedef int (*roctx_push_fn)(const char*);
+typedef int (*roctx_pop_fn)(void);
+roctx_push_fn g_roctx_push = nullptr;
+roctx_pop_fn g_roctx_pop = nullptr;
+std::once_flag g_roctx_once;
+
+void roctx_bind()
+{
+    // rocprofv3 --marker-trace preloads librocprofiler-sdk-roctx: its symbols are then in the global scope.  Otherwise
+    // there is nobody to read the ranges and they cost nothing.
+    g_roctx_push = (roctx_push_fn)dlsym(RTLD_DEFAULT, "roctxRangePushA");
+    g_roctx_pop = (roctx_pop_fn)dlsym(RTLD_DEFAULT, "roctxRangePop");
+    if (!g_roctx_push || !g_roctx_pop) g_roctx_push = nullptr, g_roctx_pop = nullptr;
+}
+struct RoctxRange {
+    bool on;
+    explicit RoctxRange(const char* name)
+    {
+        std::call_once(g_roctx_once, roctx_bind);
+        on = g_roctx_push != nullptr;
+        if (on) g_roctx_push(name);
+    }
+    ~RoctxRange() { if (on) g_roctx_pop(); }
+};
+
 }  // namespace
+
+// look-up used by the launchers (fir.hip, msk.hip) and this file: the override's integer value, or dflt
+extern "C" int acg_tune_get(const char* name, int dflt)
+{
+    std::lock_guard<std::mutex> lk(g_tune_mx);
+    tune_init_locked();
+    auto it = g_tune.find(name);
+    return it == g_tune.end() ? dflt : std::atoi(it->second.c_str());
+}
+extern "C" int acg_tune_has(const char* name)
+{
+    std::lock_guard<std::mutex> lk(g_tune_mx);
+    tune_init_locked();
+    return g_tune.count(name) ? 1 : 0;
+}
+extern "C" int acg_tune(const char* name, const char* value)
+{
+    if (!name || std::strncmp(name, "ACG_", 4) != 0) return ACG_EINVAL;
+    std::lock_guard<std::mutex> lk(g_tune_mx);
+    tune_init_locked();
+    if (value) g_tune[name] = value;
+    else g_tune.erase(name);
+    return ACG_OK;
+}
 
 struct acg_ctx {
     acg_config cfg{};
@@ -50,6 +131,8 @@ struct acg_ctx {
     unsigned long long call_seq = 0;        // process calls issued
     unsigned int consumed = 0;              // frames already handed to the host (monotonic, wraps with the counter)
     bool tile_path = true;          // decim % 8 == 0 -> LDS-tiled kernel
+    bool exact_fir = false;         // ACG_F_EXACT_FIR: the exact-order down-converter (verification mode)
+    int lag_max = 1;                // most calls acg_collect_* may stay behind (what frame_cap was sized for)
     int ntaps_pad = 0;
     int max_len = 0;                // max_blocks * 1024
     size_t dm_pitch = 0;
@@ -211,7 +294,7 @@ static int upload_stream_map(acg_ctx* c, const int* so)
     HIPCHK(c, hipMemcpy(c->d_group_ch, ord.data(), (size_t)nch * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_groups, groups.data(), groups.size() * sizeof(int4), hipMemcpyHostToDevice));
     c->ngroups = (int)groups.size();
-    if (const char* e = std::getenv("ACG_FIR_SHARED")) if (!std::atoi(e)) c->ngroups = 0;
+    if (!acg_tune_get("ACG_FIR_SHARED", 1)) c->ngroups = 0;
     return ACG_OK;
 }
 
@@ -234,8 +317,19 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
     c->max_len = cfg->max_blocks * ACG_BLOCK;
     c->dm_pitch = ((size_t)c->max_len + 63) & ~(size_t)63;
     c->bit_cap = c->max_len / 4 + 8;
-    // shortest possible block: SYN SYN SOH ETX CRC CRC + END byte = 56 bits ~ 291 samples
-    c->frame_cap = 2u * (unsigned int)cfg->nch * (unsigned int)(c->max_len / 291 + 2);   // two calls' worth (lagged collection)
+    // shortest possible block: SYN SYN SOH ETX CRC CRC + END byte = 56 bits ~ 291 samples.  The ring holds the worst case of
+    // lag_max + 1 calls (a collect that stays `lag` calls behind leaves lag + 1 calls' blocks in it), so a host that
+    // collects after every call can never be lapped: lag up to NCALL - 2 = 6 where that costs <= 512 MiB (1024 channels x
+    // 8 callbacks: 66 MB for all seven), fewer calls for very wide contexts (16 384 channels x 8 callbacks: three calls).
+    {
+        const unsigned long long per_call = (unsigned long long)cfg->nch * (unsigned long long)(c->max_len / 291 + 2);
+        unsigned long long calls = (512ull << 20) / (per_call * sizeof(AcgFrameRec));
+        calls = std::max<unsigned long long>(2, std::min<unsigned long long>(acg_ctx::NCALL - 1, calls));
+        if (per_call * calls > 0xffffffffull) { delete c; return ACG_EINVAL; }
+        c->frame_cap = (unsigned int)(per_call * calls);
+        c->lag_max = (int)calls - 1;
+    }
+    c->exact_fir = (cfg->flags & ACG_F_EXACT_FIR) != 0;
     // MSK kernel shape: the chip has 1024 SIMDs; give every channel as many lanes as keeps the
     // wave count around one per SIMD (latency mode), down to one lane per channel (throughput mode)
     c->msk_lpc = cfg->nch <= 8192 ? 8 : cfg->nch <= 16384 ? 4 : cfg->nch <= 32768 ? 2 : 1;
@@ -245,7 +339,7 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
     // channels even that is not worth a second pair: the down-converter of call i+1 hides under the
     // demodulator of call i entirely (0 = whole calls).
     c->pipe_blocks = cfg->nch <= 1024 ? 0 : 4;
-    if (const char* e = std::getenv("ACG_PIPE_BLOCKS")) c->pipe_blocks = std::max(0, std::atoi(e));
+    c->pipe_blocks = std::max(0, acg_tune_get("ACG_PIPE_BLOCKS", c->pipe_blocks));
     c->msk_high_prio = cfg->nch <= 8192 ? 1 : 0;   // <= 8192: its chain is the longer stage (neutral at 4096, +7 % at 8192)
     c->timing_mode = (cfg->flags & ACG_F_TIMING) ? 1 : 0;
     // few channels: the demodulator's serial chain is the critical path -> give its waves CUs of their own
@@ -259,9 +353,9 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
         const int need = std::max(1, (cfg->nch * c->msk_lpc / 64 + 3) / 4);
         c->msk_cus_default = std::min(128, (5 * need + 1) / 2);
     }
-    if (const char* e = std::getenv("ACG_MSK_PRIO")) c->msk_high_prio = std::atoi(e) ? 1 : 0;
-    if (const char* e = std::getenv("ACG_MSK_LPC")) {
-        const int v = std::atoi(e);
+    c->msk_high_prio = acg_tune_get("ACG_MSK_PRIO", c->msk_high_prio) ? 1 : 0;
+    {
+        const int v = acg_tune_get("ACG_MSK_LPC", c->msk_lpc);
         if (v == 1 || v == 2 || v == 4 || v == 8) c->msk_lpc = v;
     }
 
@@ -274,8 +368,7 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
             // (mask bits [0, n)) and the down-converter runs on the other 256 - n through an internal
             // stream that is ordered against the caller's stream by events.  Whatever physical CUs the
             // driver maps the bits to, the two masks are disjoint.
-            const char* e = std::getenv("ACG_MSK_CUS");
-            int ncu = e ? std::atoi(e) : c->msk_cus_default;
+            int ncu = acg_tune_get("ACG_MSK_CUS", c->msk_cus_default);
             int total = 256;
             (void)hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, cfg->device);
             if (ncu > 0 && ncu < total && total <= 256) {
@@ -349,7 +442,7 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
         HIPCHK(c, hipMalloc(&c->d_groups, nch * sizeof(int4)));
         HIPCHK(c, hipMalloc(&c->d_group_ch, nch * sizeof(int)));
         HIPCHK(c, hipMalloc(&c->d_gtaps, nch * (size_t)c->ntaps_pad * 2 * sizeof(float)));
-        if (getenv("ACG_DEBUG_ADDR"))                      // placement probes (profiles/probe/placement_probe.py)
+        if (acg_tune_has("ACG_DEBUG_ADDR"))                    // placement probes (profiles/probe/placement_probe.py)
             fprintf(stderr, "acg_create: taps %p (%zu B)  dm %p (%zu B)  st %p  work %p  stream_of %p  txt %p\n", (void*)c->d_taps,
                     nch * c->ntaps_pad * 2 * sizeof(float), (void*)c->d_dm_all, 2 * nch * c->dm_pitch * sizeof(float), (void*)c->d_st,
                     (void*)c->d_work, (void*)c->d_stream_of, (void*)c->d_txt);
@@ -475,6 +568,7 @@ static int launch_fir(acg_ctx* c, const uint8_t* iq_dev, size_t pitch, int nbloc
     a.nch = g.nch;
     a.decim = g.decim;
     a.ntaps_pad = c->ntaps_pad;
+    a.ntaps = g.ntaps;
     a.nwin = nblocks * ACG_BLOCK;
     a.row_bytes = 2 * g.decim;
     a.work_counter = c->d_work + (size_t)ACG_DISP_WORDS * block0;     // one dispenser per chunk slot
@@ -483,12 +577,12 @@ static int launch_fir(acg_ctx* c, const uint8_t* iq_dev, size_t pitch, int nbloc
     // at 16 384 channels).  Below that the starved demodulator becomes the longer stage: 8192 channels lose 7 % with the
     // raise, 4096 channels 15 % (profiles/r02_experiments/bench_variants.txt, "v_" rows).
     a.high_prio = (!c->fir_stream && g.nch >= 16384) ? 1 : 0;
-    if (const char* e = std::getenv("ACG_FIR_PRIO")) a.high_prio = std::atoi(e) ? 1 : 0;
+    a.high_prio = acg_tune_get("ACG_FIR_PRIO", a.high_prio) ? 1 : 0;
     a.shares_cus = (with_demod && !c->fir_stream) ? 1 : 0;
     // few channels: the demodulator's serial chain is the critical path; three resident workgroups per CU
     // cost the down-converter ~5 % of its bandwidth and give the demodulator waves ~10 % (whole job +5 %)
     a.wg_per_cu = (g.nch <= 2048 && c->msk_high_prio && !c->fir_stream) ? 3 : 0;
-    if (const char* e = std::getenv("ACG_FIR_WG_HINT")) a.wg_per_cu = std::atoi(e);
+    a.wg_per_cu = acg_tune_get("ACG_FIR_WG_HINT", a.wg_per_cu);
     a.ncu = (s == c->fir_stream) ? c->fir_ncu : 0;
     const bool timing = c->timing_mode != 0;
     EvPair ev{};
@@ -498,9 +592,12 @@ static int launch_fir(acg_ctx* c, const uint8_t* iq_dev, size_t pitch, int nbloc
         HIPCHK(c, hipEventRecord(ev.a, s));
     }
     int e;
-    roctxRangePushA("acg:down-converter");                 // named range around the launch (rocprofv3 --marker-trace)
-    struct RangePop { ~RangePop() { roctxRangePop(); } } range_pop;
-    if (c->tile_path) {
+    RoctxRange range("acg:down-converter");                // named range around the launch (rocprofv3 --marker-trace)
+    if (c->exact_fir) {
+        // verification mode: rtl.c:335-353 in the reference's own order of operations (fir.hip, fir_u8_generic_kernel)
+        a.nseg = 1;
+        e = acg_launch_fir_generic(&a, s);
+    } else if (c->tile_path) {
         a.cpr = a.row_bytes / 16;
         a.row_stride = (a.cpr & 1) ? a.row_bytes : a.row_bytes + 16;
         a.cpr_magic = ((1u << 20) + (unsigned int)a.cpr - 1) / (unsigned int)a.cpr;
@@ -567,14 +664,16 @@ static int launch_msk(acg_ctx* c, const float* dm_dev, size_t pitch_floats, int 
         if ((r = get_event(c, &ev.a)) != ACG_OK || (r = get_event(c, &ev.b)) != ACG_OK) return r;
         HIPCHK(c, hipEventRecord(ev.a, s));
     }
-    roctxRangePushA("acg:demodulator");
     int lpc = c->msk_lpc;
-    if (const char* le = std::getenv("ACG_MSK_LPC_LIVE")) {         // measurement aid: lanes per channel per launch (the channel state
-        const int v = std::atoi(le);                                  // does not depend on it), for same-context A/B (bench.py --ab)
+    {                                                               // measurement aid: lanes per channel per launch (the channel state
+        const int v = acg_tune_get("ACG_MSK_LPC_LIVE", lpc);          // does not depend on it), for same-context A/B (bench.py --ab)
         if (v == 1 || v == 2 || v == 4 || v == 8) lpc = v;
     }
-    const int e = acg_launch_msk(&a, lpc, s);
-    roctxRangePop();
+    int e;
+    {
+        RoctxRange range("acg:demodulator");
+        e = acg_launch_msk(&a, lpc, s);
+    }
     if (e != 0) {
         c->err = std::string("MSK launch: ") + hipGetErrorString((hipError_t)e);
         return ACG_EHIP;
@@ -847,6 +946,7 @@ extern "C" int acg_collect_frames(acg_ctx* ctx, int lag, acg_frame* out, int max
 {
     if (!ctx || !nframes || (max_frames > 0 && !out) || lag < 0 || lag >= acg_ctx::NCALL - 1) return ACG_EINVAL;
     *nframes = 0;
+    if (lag > ctx->lag_max) return fail(ctx, ACG_EINVAL, "lag above acg_max_lag(): the block queue of this context holds fewer calls");
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
     if (ctx->call_seq <= (unsigned long long)lag) return ACG_OK;              // nothing old enough yet
     const unsigned long long call = ctx->call_seq - 1 - (unsigned long long)lag;
@@ -873,36 +973,47 @@ static_assert(sizeof(AcgMsgRec) == sizeof(acg_msg), "device record and public re
 static int fetch_msgs(acg_ctx* ctx, unsigned int upto, acg_msg* out, int max_msgs, int* nmsgs)
 {
     if (!ctx->d_crctab) return fail(ctx, ACG_ESTATE, "context created without ACG_F_REPAIR");
-    const unsigned int pending = upto - ctx->consumed;
+    unsigned int pending = upto - ctx->consumed;
     int rc = ACG_OK;
-    unsigned int take = pending;
     if (pending > ctx->frame_cap) {                               // the device lapped the host: oldest lost
         ctx->consumed = upto - ctx->frame_cap;
-        take = ctx->frame_cap;
+        pending = ctx->frame_cap;
         rc = ACG_EOVERFLOW;
     }
-    if (take > ctx->msgs_cap) {
+    if (pending > ctx->msgs_cap) {
         hipFree(ctx->d_msgs);
         std::free(ctx->h_msgs);
         ctx->d_msgs = nullptr;
         ctx->h_msgs = nullptr;
         ctx->msgs_cap = 0;
-        const size_t want = std::max<size_t>(take, 4096);
+        const size_t want = std::max<size_t>(pending, 4096);
         HIPCHK(ctx, hipMalloc(&ctx->d_msgs, want * sizeof(AcgMsgRec)));
         ctx->h_msgs = (AcgMsgRec*)std::malloc(want * sizeof(AcgMsgRec));
         if (!ctx->h_msgs) return fail(ctx, ACG_ENOMEM, "message staging");
         ctx->msgs_cap = want;
     }
-    if (take) {
-        if (acg_launch_msg_split(ctx->d_frames, ctx->frame_cap, ctx->consumed, take, ctx->d_msgs, ctx->copy_stream) != 0)
+    if (pending) {
+        // the split writes every byte of a record (text tail zeroed), so nothing stale crosses the ABI
+        if (acg_launch_msg_split(ctx->d_frames, ctx->frame_cap, ctx->consumed, pending, ctx->d_msgs, ctx->copy_stream) != 0)
             return fail(ctx, ACG_EHIP, "message split launch failed");
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_msgs, ctx->d_msgs, (size_t)take * sizeof(AcgMsgRec), hipMemcpyDeviceToHost, ctx->copy_stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_msgs, ctx->d_msgs, (size_t)pending * sizeof(AcgMsgRec), hipMemcpyDeviceToHost, ctx->copy_stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
     }
-    ctx->consumed = upto;
+    // Queue order is completion order.  If the caller's buffer is too small, hand out the longest PREFIX of the queue
+    // whose valid messages fit and consume only that prefix: the rest stays queued for the next call (ACG_EOVERFLOW tells
+    // the caller to come again) -- nothing is dropped.
     const AcgMsgRec* rec = ctx->h_msgs;
+    unsigned int take = 0, nvalid = 0;
+    while (take < pending) {
+        if (rec[take].valid) {
+            if ((int)nvalid >= max_msgs) { rc = ACG_EOVERFLOW; break; }
+            ++nvalid;
+        }
+        ++take;
+    }
+    ctx->consumed += take;
     std::vector<unsigned int> order;
-    order.reserve(take);
+    order.reserve(nvalid);
     for (unsigned int i = 0; i < take; ++i)
         if (rec[i].valid) order.push_back(i);
     std::sort(order.begin(), order.end(), [rec](unsigned int x, unsigned int y) {
@@ -910,7 +1021,6 @@ static int fetch_msgs(acg_ctx* ctx, unsigned int upto, acg_msg* out, int max_msg
     });
     unsigned int kept = 0;
     for (unsigned int i : order) {
-        if ((int)kept >= max_msgs) { rc = ACG_EOVERFLOW; break; }
         acg_msg& m = out[kept++];
         std::memcpy(&m, &rec[i], sizeof(m));
         m.lvl = acg_host_level_db(rec[i].lvlsum, rec[i].bitcount);   // acars.c:351
@@ -919,7 +1029,7 @@ static int fetch_msgs(acg_ctx* ctx, unsigned int upto, acg_msg* out, int max_msg
         m.reserved2 = 0;
     }
     *nmsgs = (int)kept;
-    if (rc != ACG_OK) return fail(ctx, rc, "message queue overflow");
+    if (rc != ACG_OK) return fail(ctx, rc, pending == take ? "block queue lapped: oldest messages lost" : "more messages queued than fit: call again");
     return ACG_OK;
 }
 
@@ -927,6 +1037,7 @@ extern "C" int acg_collect_msgs(acg_ctx* ctx, int lag, acg_msg* out, int max_msg
 {
     if (!ctx || !nmsgs || (max_msgs > 0 && !out) || lag < 0 || lag >= acg_ctx::NCALL - 1) return ACG_EINVAL;
     *nmsgs = 0;
+    if (lag > ctx->lag_max) return fail(ctx, ACG_EINVAL, "lag above acg_max_lag(): the block queue of this context holds fewer calls");
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
     if (ctx->call_seq <= (unsigned long long)lag) return ACG_OK;
     const unsigned long long call = ctx->call_seq - 1 - (unsigned long long)lag;
@@ -947,6 +1058,7 @@ extern "C" int acg_drain_msgs(acg_ctx* ctx, acg_msg* out, int max_msgs, int* nms
 }
 
 extern "C" int acg_bit_capacity(const acg_ctx* ctx) { return ctx ? ctx->bit_cap : 0; }
+extern "C" int acg_max_lag(const acg_ctx* ctx) { return ctx ? ctx->lag_max : 0; }
 
 extern "C" int acg_read_bits(acg_ctx* ctx, int ch, float* vo, float* lvl, int max_bits, int* nbits)
 {
@@ -1103,6 +1215,7 @@ static int fmt_geometry(acg_ctx* ctx, int fmt, FirArgs* a, int nwin)
     a->nch = g.nch;
     a->decim = g.decim;
     a->ntaps_pad = ctx->ntaps_pad;
+    a->ntaps = g.ntaps;
     a->nwin = nwin;
     a->row_bytes = 4 * g.decim;
     a->cpr_total = a->row_bytes / 16;
@@ -1150,9 +1263,11 @@ static int run_fmt(acg_ctx* ctx, int fmt, FirArgs* a, hipStream_t caller)
             HIPCHK(ctx, hipEventRecord(ev.a, s));
         }
         if (ctx->msk_go_valid) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->msk_go, 0));   // see acg_process_iq_u8_dev
-        roctxRangePushA("acg:down-converter");
-        const int e = acg_launch_fir_fmt(a, fmt, s);
-        roctxRangePop();
+        int e;
+        {
+            RoctxRange range("acg:down-converter");
+            e = acg_launch_fir_fmt(a, fmt, s);
+        }
         if (e != 0) {
             ctx->err = std::string("FIR launch: ") + hipGetErrorString((hipError_t)e);
             return ACG_EHIP;

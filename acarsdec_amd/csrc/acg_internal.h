@@ -79,6 +79,7 @@ struct FirArgs {
     int nch;
     int decim;                  // M
     int ntaps_pad;              // taps per channel, zero padded to a multiple of 8
+    int ntaps;                  // taps per channel that carry values (the exact-order kernel stops there)
     int nwin;                   // outputs per channel this launch
     int nseg;                   // time segments per channel (grid = nch * nseg)
     int row_bytes;              // 2*M

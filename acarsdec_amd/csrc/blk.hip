@@ -106,6 +106,11 @@ __global__ void msg_split_kernel(const AcgFrameRec* frames, unsigned int cap, un
     if (q >= n) return;
     const AcgFrameRec* f = frames + ((first + q) % cap);
     AcgMsgRec* m = out + q;
+    {   // every byte of the record is written (the staging buffer comes from hipMalloc): nothing stale crosses the ABI
+        static_assert(sizeof(AcgMsgRec) % 8 == 0, "record is cleared in 8-byte words");
+        unsigned long long* z = (unsigned long long*)m;
+        for (unsigned int i = 0; i < sizeof(AcgMsgRec) / 8; ++i) z[i] = 0ull;
+    }
     const unsigned char* t = f->txt;
     const int len = f->len;
     m->chn = f->chn;

@@ -15,6 +15,8 @@
 //   * the 4 waves split the tap range; partial sums meet in LDS; wave 0 takes |D| and writes 64
 //     consecutive floats of dm.
 #include <hip/hip_runtime.h>
+#include <map>
+#include <mutex>
 #include <cstdio>
 #include <stdlib.h>
 #include <type_traits>
@@ -1920,8 +1922,10 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_fmt_direct_kernel(const FirArg
 struct FirDev {
     bool ready;
     int num_cu;
+    std::map<const void*, size_t>* lds_optin;      // kernel -> dynamic LDS bytes it has been opted in for on this device
 };
 static FirDev g_firdev[FIR_MAXDEV];
+static std::mutex g_firdev_mx;
 
 static int fir_device(FirDev** out)
 {
@@ -1930,52 +1934,44 @@ static int fir_device(FirDev** out)
     if (e != hipSuccess) return (int)e;
     if (dev < 0 || dev >= FIR_MAXDEV) return (int)hipErrorInvalidDevice;
     FirDev* d = &g_firdev[dev];
+    std::lock_guard<std::mutex> lk(g_firdev_mx);
     if (!d->ready) {
-        const int big = 64 * 1024;
-        struct { const void* f; int bytes; } attrs[] = {
-            {(const void*)fir_u8_tile_kernel, big},
-            {(const void*)fir_u8_persist_kernel<false, false, false>, big},
-            {(const void*)fir_u8_persist_kernel<true, false, false>, big},
-            {(const void*)fir_u8_persist_kernel<true, true, true>, big},
-            {(const void*)fir_u8_persist_kernel<true, true, false>, big},
-            {(const void*)fir_u8_dma_kernel, 96 * 1024},
-            {(const void*)fir_u8_shared_kernel<true>, big},
-            {(const void*)fir_u8_shared_kernel<false>, big},
-            {(const void*)fir_fmt_kernel<FMT_CS16>, big},
-            {(const void*)fir_fmt_kernel<FMT_SPLIT>, big},
-            {(const void*)fir_fmt_kernel<FMT_F32R>, big},
-            {(const void*)fir_u8_direct_kernel<20>, 4 * FirD<20>::WAVE_LDS},
-            {(const void*)fir_u8_direct_kernel<24>, 4 * FirD<24>::WAVE_LDS},
-            {(const void*)fir_u8_direct_kernel<25>, 4 * FirD<25>::WAVE_LDS},
-            {(const void*)fir_u8_direct_kernel<25, 10, 1>, 4 * FirD<25>::WAVE_LDS},
-            {(const void*)fir_u8_direct_kernel<25, 25, 5>, 4 * FirD<25>::WAVE_LDS},
-            {(const void*)fir_u8_direct_kernel<25, 25, 10>, 4 * FirD<25>::WAVE_LDS},
-            {(const void*)fir_u8_direct_kernel<25, 10, 10>, 4 * FirD<25>::WAVE_LDS},
-            {(const void*)fir_u8_direct_kernel<25, 0, 0, false>, 4 * FirD<25>::WAVE_LDS},
-            {(const void*)fir_u8_mfma_kernel<25>, 4 * FirM<25>::WAVE_LDS},
-#define FIRX_ATTR(F_, C_, W_) {(const void*)fir_fmt_direct_kernel<F_, C_, W_>, 4 * FirX<F_, C_, W_>::WAVE_LDS},
-            FIRX_ATTR(FMT_CS16, 40, 32) FIRX_ATTR(FMT_CS16, 48, 32) FIRX_ATTR(FMT_CS16, 50, 32)
-            FIRX_ATTR(FMT_F32R, 50, 32) FIRX_ATTR(FMT_F32R, 60, 16) FIRX_ATTR(FMT_F32R, 120, 8) FIRX_ATTR(FMT_F32R, 200, 8)
-            FIRX_ATTR(FMT_SPLIT, 20, 64)
-#undef FIRX_ATTR
-        };
-        for (const auto& at : attrs) {
-            e = hipFuncSetAttribute(at.f, hipFuncAttributeMaxDynamicSharedMemorySize, at.bytes);
-            if (e != hipSuccess) return (int)e;
-        }
         d->num_cu = 256;
         (void)hipDeviceGetAttribute(&d->num_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        d->lds_optin = new std::map<const void*, size_t>();
         d->ready = true;
     }
     *out = d;
     return 0;
 }
 
-static int env_int(const char* name, int dflt)
+// Dynamic LDS above the default limit needs an opt-in per kernel (hipFuncAttributeMaxDynamicSharedMemorySize).  It is
+// made HERE, at the launch site, with the bytes the launch is about to ask for and for exactly the instantiation being
+// launched -- a table of instantiations kept elsewhere drifts from the launch switch (round 2's did: the write-through
+// kernels that are the default were not in it).
+static int fir_lds_optin(const void* kernel, size_t bytes)
 {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
+    FirDev* d = nullptr;
+    if (int e = fir_device(&d)) return e;
+    std::lock_guard<std::mutex> lk(g_firdev_mx);
+    size_t& have = (*d->lds_optin)[kernel];
+    if (bytes > have) {
+        const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) return (int)e;
+        have = bytes;
+    }
+    return 0;
 }
+#define FIR_LAUNCH(K_, grid_, blk_, lds_, stream_, ...)                                            \
+    do {                                                                                           \
+        if (int oe_ = fir_lds_optin((const void*)(K_), (size_t)(lds_))) return oe_;                \
+        hipLaunchKernelGGL((K_), grid_, blk_, lds_, stream_, __VA_ARGS__);                         \
+    } while (0)
+
+// measurement / layout switches: one table, filled from the environment once per process (acg_api.cpp)
+extern "C" int acg_tune_get(const char* name, int dflt);
+extern "C" int acg_tune_has(const char* name);
+static int env_int(const char* name, int dflt) { return acg_tune_get(name, dflt); }
 
 template <int FMT, int CPR, int W>
 static int launch_fmt_direct(const FirArgs* a, int num_cu, hipStream_t stream)
@@ -1990,7 +1986,7 @@ static int launch_fmt_direct(const FirArgs* a, int num_cu, hipStream_t stream)
     long long grid = (long long)(a->ncu > 0 ? a->ncu : num_cu) * per_cu;
     const long long need = (nrun + ACG_WG_FIR / 64 - 1) / (ACG_WG_FIR / 64);
     if (grid > need) grid = need;
-    hipLaunchKernelGGL((fir_fmt_direct_kernel<FMT, CPR, W>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds, stream, *a, a->iq, a->taps,
+    FIR_LAUNCH((fir_fmt_direct_kernel<FMT, CPR, W>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds, stream, *a, a->iq, a->taps,
                        a->stream_of, a->dm);
     return (int)hipGetLastError();
 }
@@ -2022,13 +2018,13 @@ extern "C" int acg_launch_fir_fmt(const FirArgs* a, int fmt, void* stream)
     if (grid > G) grid = G;
     switch (fmt) {
     case FMT_CS16:
-        hipLaunchKernelGGL(fir_fmt_kernel<FMT_CS16>, dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds, (hipStream_t)stream, *a, a->iq, a->taps, a->stream_of, a->dm);
+        FIR_LAUNCH(fir_fmt_kernel<FMT_CS16>, dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds, (hipStream_t)stream, *a, a->iq, a->taps, a->stream_of, a->dm);
         break;
     case FMT_SPLIT:
-        hipLaunchKernelGGL(fir_fmt_kernel<FMT_SPLIT>, dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds, (hipStream_t)stream, *a, a->iq, a->taps, a->stream_of, a->dm);
+        FIR_LAUNCH(fir_fmt_kernel<FMT_SPLIT>, dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds, (hipStream_t)stream, *a, a->iq, a->taps, a->stream_of, a->dm);
         break;
     case FMT_F32R:
-        hipLaunchKernelGGL(fir_fmt_kernel<FMT_F32R>, dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds, (hipStream_t)stream, *a, a->iq, a->taps, a->stream_of, a->dm);
+        FIR_LAUNCH(fir_fmt_kernel<FMT_F32R>, dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds, (hipStream_t)stream, *a, a->iq, a->taps, a->stream_of, a->dm);
         break;
     default:
         return (int)hipErrorInvalidValue;
@@ -2036,9 +2032,13 @@ extern "C" int acg_launch_fir_fmt(const FirArgs* a, int fmt, void* stream)
     return (int)hipGetLastError();
 }
 
-// Fallback for decimations whose window is not a whole number of 16-byte chunks (M % 8 != 0):
-// one thread per output, sequential accumulation exactly in the reference's order.
-__global__ void fir_u8_generic_kernel(const FirArgs a, int ntaps)
+// Exact-order kernel: one thread per output, the M terms accumulated sequentially with separately rounded products,
+// differences and sums and the 127.37 subtracted per sample -- rtl.c:335-353 operation for operation as an IEEE (-O2, no
+// contraction) build of the reference executes it, so dm is BIT-IDENTICAL to such a build (and to oracle/orc_fir_u8).
+// Two uses: the fallback for decimations whose window is not a whole number of 16-byte chunks (M % 8 != 0), and the
+// verification mode (ACG_F_EXACT_FIR): the streaming kernels re-associate the sum (1e-7 relative), which can flip a
+// razor-edge soft decision of the demodulator; with this kernel in front the whole GPU path is bit-identical end to end.
+__global__ void fir_u8_generic_kernel(const FirArgs a)
 {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = (long long)a.nch * a.nwin;
@@ -2048,9 +2048,9 @@ __global__ void fir_u8_generic_kernel(const FirArgs a, int ntaps)
     const uint8_t* p = a.iq + (size_t)a.stream_of[ch] * a.pitch + (size_t)m * a.row_bytes;
     const float* w = a.taps + (size_t)ch * a.ntaps_pad * 2;
     float Dr = 0.f, Di = 0.f;
-    for (int k = 0; k < ntaps; ++k) {
-        const float r = (float)p[2 * k] - 127.37f;
-        const float g = (float)p[2 * k + 1] - 127.37f;
+    for (int k = 0; k < a.ntaps; ++k) {
+        const float r = __fsub_rn((float)p[2 * k], 127.37f);
+        const float g = __fsub_rn((float)p[2 * k + 1], 127.37f);
         const float wr = w[2 * k], wi = w[2 * k + 1];
         Dr = __fadd_rn(Dr, __fsub_rn(__fmul_rn(r, wr), __fmul_rn(g, wi)));
         Di = __fadd_rn(Di, __fadd_rn(__fmul_rn(r, wi), __fmul_rn(g, wr)));
@@ -2094,11 +2094,11 @@ static int launch_direct(const FirArgs* a, int num_cu, hipStream_t stream)
     if (grid > need) grid = need;
     FirArgs b = *a;
     b.run_pairs = pairs;
-    if (getenv("ACG_FIR_DEBUG_DMPITCH0")) b.dm_pitch = 0;          // measurement aid: every channel's dm lands in the first row (no write stream to HBM)
-    if (getenv("ACG_FIR_DEBUG_SHAPE"))
+    if (acg_tune_has("ACG_FIR_DEBUG_DMPITCH0")) b.dm_pitch = 0;          // measurement aid: every channel's dm lands in the first row (no write stream to HBM)
+    if (acg_tune_has("ACG_FIR_DEBUG_SHAPE"))
         fprintf(stderr, "fir_u8_direct<%d>: nch %d nwin %d  wpg %d per_cu %d grid %lld  bodies/ch %lld pairs %d runs %lld  shares_cus %d prio %d\n",
                 CPR, a->nch, a->nwin, wpg, per_cu, grid, bodies_per_ch, pairs, nrun, a->shares_cus, a->high_prio);
-    hipLaunchKernelGGL((fir_u8_direct_kernel<CPR, UU, BB, FOLD, WT>), dim3((unsigned int)grid), dim3(64 * wpg), lds, stream, b, a->iq, a->taps,
+    FIR_LAUNCH((fir_u8_direct_kernel<CPR, UU, BB, FOLD, WT>), dim3((unsigned int)grid), dim3(64 * wpg), lds, stream, b, a->iq, a->taps,
                        a->stream_of, a->dm);
     return (int)hipGetLastError();
 }
@@ -2127,10 +2127,10 @@ static int launch_coltap(const FirArgs* a, int num_cu, hipStream_t stream)
     if (grid > need) grid = need;
     FirArgs b = *a;
     b.run_pairs = pairs;
-    if (getenv("ACG_FIR_DEBUG_SHAPE"))
+    if (acg_tune_has("ACG_FIR_DEBUG_SHAPE"))
         fprintf(stderr, "fir_u8_coltap: nch %d nwin %d  wpg %d per_cu %d grid %lld  bodies/ch %lld pairs %d runs %lld  shares_cus %d prio %d lds %zu\n",
                 a->nch, a->nwin, wpg, per_cu, grid, bodies_per_ch, pairs, nrun, a->shares_cus, a->high_prio, lds);
-    hipLaunchKernelGGL((fir_u8_coltap_kernel<FOLD, UU, BB, STAGED>), dim3((unsigned int)grid), dim3(64 * wpg), lds, stream, b, a->iq, a->taps,
+    FIR_LAUNCH((fir_u8_coltap_kernel<FOLD, UU, BB, STAGED>), dim3((unsigned int)grid), dim3(64 * wpg), lds, stream, b, a->iq, a->taps,
                        a->stream_of, a->dm);
     return (int)hipGetLastError();
 }
@@ -2158,9 +2158,9 @@ static int launch_mfma(const FirArgs* a, int num_cu, hipStream_t stream)
     if (grid > need) grid = need;
     FirArgs b = *a;
     b.run_pairs = pairs;
-    if (getenv("ACG_FIR_DEBUG_SHAPE"))
+    if (acg_tune_has("ACG_FIR_DEBUG_SHAPE"))
         fprintf(stderr, "fir_u8_mfma<%d>: nch %d nwin %d  wpg %d per_cu %d grid %lld pairs %d runs %lld lds %zu\n", CPR, a->nch, a->nwin, wpg, per_cu, grid, pairs, nrun, lds);
-    hipLaunchKernelGGL((fir_u8_mfma_kernel<CPR>), dim3((unsigned int)grid), dim3(64 * wpg), lds, stream, b, a->iq, a->taps, a->stream_of, a->dm);
+    FIR_LAUNCH((fir_u8_mfma_kernel<CPR>), dim3((unsigned int)grid), dim3(64 * wpg), lds, stream, b, a->iq, a->taps, a->stream_of, a->dm);
     return (int)hipGetLastError();
 }
 
@@ -2207,7 +2207,7 @@ extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
     }
     if (variant == 0) {
         const unsigned int grid = (unsigned int)a->nch * (unsigned int)a->nseg;
-        hipLaunchKernelGGL(fir_u8_tile_kernel, dim3(grid), dim3(ACG_WG_FIR), lds, (hipStream_t)stream, *a,
+        FIR_LAUNCH(fir_u8_tile_kernel, dim3(grid), dim3(ACG_WG_FIR), lds, (hipStream_t)stream, *a,
                            a->iq, a->taps, a->stream_of, a->dm);
         return (int)hipGetLastError();
     }
@@ -2223,7 +2223,7 @@ extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
             const long long nrun4 = (G4 + FIR_RUN - 1) / FIR_RUN;
             long long grid4 = (long long)num_cu * per;
             if (grid4 > nrun4) grid4 = nrun4;
-            hipLaunchKernelGGL(fir_u8_dma_kernel, dim3((unsigned int)grid4), dim3(ACG_WG_FIR), lds2, (hipStream_t)stream,
+            FIR_LAUNCH(fir_u8_dma_kernel, dim3((unsigned int)grid4), dim3(ACG_WG_FIR), lds2, (hipStream_t)stream,
                                *a, a->iq, a->taps, a->stream_of, a->dm);
             return (int)hipGetLastError();
         }
@@ -2239,23 +2239,23 @@ extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
     long long grid = (long long)(a->ncu > 0 ? a->ncu : num_cu) * per_cu;
     if (grid > G) grid = G;
     FirArgs b = *a;
-    const bool nocompute = getenv("ACG_FIR_DEBUG_NOCOMPUTE") != nullptr;   // measurement aid: loads + LDS staging only
+    const bool nocompute = acg_tune_has("ACG_FIR_DEBUG_NOCOMPUTE") != 0;   // measurement aid: loads + LDS staging only
     if (nocompute) b.ntaps_pad = 0;
     if (variant == 1) {
-        hipLaunchKernelGGL((fir_u8_persist_kernel<false, false, false>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds,
+        FIR_LAUNCH((fir_u8_persist_kernel<false, false, false>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds,
                            (hipStream_t)stream, b, a->iq, a->taps, a->stream_of, a->dm);
     } else if (variant == 2) {
-        hipLaunchKernelGGL((fir_u8_persist_kernel<true, false, false>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds,
+        FIR_LAUNCH((fir_u8_persist_kernel<true, false, false>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds,
                            (hipStream_t)stream, b, a->iq, a->taps, a->stream_of, a->dm);
     } else {
         const long long nrun = (G + FIR_RUN - 1) / FIR_RUN;
         if (grid > nrun) grid = nrun;
         if (G >= (1ll << 31)) return (int)hipErrorInvalidValue;
         if (a->nwin % ACG_TILE_WIN == 0)      // whole callbacks: every tile is complete
-            hipLaunchKernelGGL((fir_u8_persist_kernel<true, true, true>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds,
+            FIR_LAUNCH((fir_u8_persist_kernel<true, true, true>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds,
                                (hipStream_t)stream, b, a->iq, a->taps, a->stream_of, a->dm);
         else
-            hipLaunchKernelGGL((fir_u8_persist_kernel<true, true, false>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds,
+            FIR_LAUNCH((fir_u8_persist_kernel<true, true, false>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds,
                                (hipStream_t)stream, b, a->iq, a->taps, a->stream_of, a->dm);
     }
     return (int)hipGetLastError();
@@ -2279,17 +2279,17 @@ extern "C" int acg_launch_fir_shared(const FirArgs* a, void* stream)
     if (grid > nrun) grid = nrun;
     if (G >= (1ll << 31)) return (int)hipErrorInvalidValue;
     if (a->nwin % ACG_TILE_WIN == 0)
-        hipLaunchKernelGGL(fir_u8_shared_kernel<true>, dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds, (hipStream_t)stream, *a,
+        FIR_LAUNCH(fir_u8_shared_kernel<true>, dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds, (hipStream_t)stream, *a,
                            a->iq, a->gtaps, a->groups, a->group_ch, a->dm);
     else
-        hipLaunchKernelGGL(fir_u8_shared_kernel<false>, dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds, (hipStream_t)stream, *a,
+        FIR_LAUNCH(fir_u8_shared_kernel<false>, dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds, (hipStream_t)stream, *a,
                            a->iq, a->gtaps, a->groups, a->group_ch, a->dm);
     return (int)hipGetLastError();
 }
 
 extern "C" int acg_launch_regroup_taps(const FirArgs* a, void* stream)
 {
-    hipLaunchKernelGGL(regroup_taps_kernel, dim3((unsigned int)a->ngroups), dim3(256), 0, (hipStream_t)stream, a->taps,
+    FIR_LAUNCH(regroup_taps_kernel, dim3((unsigned int)a->ngroups), dim3(256), 0, (hipStream_t)stream, a->taps,
                        (float*)a->gtaps, a->groups, a->group_ch, a->ntaps_pad);
     return (int)hipGetLastError();
 }
@@ -2298,7 +2298,6 @@ extern "C" int acg_launch_fir_generic(const FirArgs* a, void* stream)
 {
     const long long total = (long long)a->nch * a->nwin;
     const unsigned int grid = (unsigned int)((total + 255) / 256);
-    // ntaps_pad == ntaps on this path (no chunk padding)
-    hipLaunchKernelGGL(fir_u8_generic_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a, a->ntaps_pad);
+    FIR_LAUNCH(fir_u8_generic_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, *a);
     return (int)hipGetLastError();
 }

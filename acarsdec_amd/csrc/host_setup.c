@@ -83,15 +83,53 @@ void acg_host_msk_h(float *h)
 	}
 }
 
-/* The demodulator's mixer (msk.c:86-91, cexp(-p*I)) on the device: (cos, sin) of j * 2 pi / 128, j = 0..127, correctly
- * rounded to double (computed in x87 extended precision) -- the table behind msk.hip sincos_tab(). */
+/* The demodulator's mixer (msk.c:86-91, cexp(-p*I)) on the device: (cos, sin) of j * 2 pi / 128, j = 0..127 -- the table
+ * behind msk.hip sincos_tab().  The first octant (j = 0..16) is embedded as correctly rounded doubles (generated offline with
+ * 80-digit decimal arithmetic: no dependence on the host's long double); the other seven octants follow by symmetry, so the
+ * axis entries are exactly 0 and +-1 and cos/sin of mirrored angles are the same doubles. */
+static const double acg_octant[17][2] = {
+	{0x1.0000000000000p+0, 0x0.0p+0},
+	{0x1.ff621e3796d7ep-1, 0x1.91f65f10dd814p-5},
+	{0x1.fd88da3d12526p-1, 0x1.917a6bc29b42cp-4},
+	{0x1.fa7557f08a517p-1, 0x1.2c8106e8e613ap-3},
+	{0x1.f6297cff75cb0p-1, 0x1.8f8b83c69a60bp-3},
+	{0x1.f0a7efb9230d7p-1, 0x1.f19f97b215f1bp-3},
+	{0x1.e9f4156c62ddap-1, 0x1.294062ed59f06p-2},
+	{0x1.e212104f686e5p-1, 0x1.58f9a75ab1fddp-2},
+	{0x1.d906bcf328d46p-1, 0x1.87de2a6aea963p-2},
+	{0x1.ced7af43cc773p-1, 0x1.b5d1009e15cc0p-2},
+	{0x1.c38b2f180bdb1p-1, 0x1.e2b5d3806f63bp-2},
+	{0x1.b728345196e3ep-1, 0x1.073879922ffeep-1},
+	{0x1.a9b66290ea1a3p-1, 0x1.1c73b39ae68c8p-1},
+	{0x1.9b3e047f38741p-1, 0x1.30ff7fce17035p-1},
+	{0x1.8bc806b151741p-1, 0x1.44cf325091dd6p-1},
+	{0x1.7b5df226aafafp-1, 0x1.57d69348ceca0p-1},
+	{0x1.6a09e667f3bcdp-1, 0x1.6a09e667f3bcdp-1},
+};
+
 void acg_host_sincos_table(double *tab)
 {
-	const long double d = 2.0L * 3.14159265358979323846264338327950288L / ACG_SINCOS_N;
 	int j;
 	for (j = 0; j < ACG_SINCOS_N; j++) {
-		tab[2 * j] = (double)cosl(j * d);
-		tab[2 * j + 1] = (double)sinl(j * d);
+		int k = j & 63;                      /* angle within a half turn, in units of pi / 64 */
+		double c, s;
+		if (k > 32)
+			k = 64 - k;                  /* cos(pi - t) = -cos t, sin(pi - t) = sin t */
+		if (k <= 16) {
+			c = acg_octant[k][0];
+			s = acg_octant[k][1];
+		} else {                             /* cos(pi/2 - t) = sin t */
+			c = acg_octant[32 - k][1];
+			s = acg_octant[32 - k][0];
+		}
+		if ((j & 63) > 32)
+			c = -c;
+		if (j >= 64) {                       /* + pi: both change sign */
+			c = -c;
+			s = -s;
+		}
+		tab[2 * j] = c + 0.0;                /* (-0.0 -> +0.0 on the axes) */
+		tab[2 * j + 1] = s + 0.0;
 	}
 }
 

@@ -766,6 +766,8 @@ extern "C" int acg_launch_sincos_selftest(const double* x, double* s, double* c,
     return (int)hipGetLastError();
 }
 
+extern "C" int acg_tune_has(const char* name);
+
 extern "C" int acg_launch_msk(const MskArgs* a, int lpc, void* stream)
 {
     const int cpw = 64 / lpc;
@@ -774,7 +776,7 @@ extern "C" int acg_launch_msk(const MskArgs* a, int lpc, void* stream)
     const unsigned int grid = (waves + wpg - 1) / wpg;
     const dim3 blk(64 * wpg);
     hipStream_t s = (hipStream_t)stream;
-    const bool vec = ((uintptr_t)a->dm % 16 == 0) && (a->dm_pitch % 4 == 0) && (a->len % 32 == 0) && !getenv("ACG_MSK_NOVEC");
+    const bool vec = ((uintptr_t)a->dm % 16 == 0) && (a->dm_pitch % 4 == 0) && (a->len % 32 == 0) && !acg_tune_has("ACG_MSK_NOVEC");
 #define MSK_LAUNCH(L_, W_) do { if (vec) hipLaunchKernelGGL((msk_demod_kernel<L_, W_, true>), dim3(grid), blk, 0, s, *a); \
                                 else hipLaunchKernelGGL((msk_demod_kernel<L_, W_, false>), dim3(grid), blk, 0, s, *a); } while (0)
     switch (lpc * 16 + wpg) {

@@ -64,19 +64,21 @@ def parse_freq_mhz(s):
 
 class Decoder:
     def __init__(self, nch, decim=160, ntaps=None, nstreams=None, max_blocks=1, device=0,
-                 bitlog=True, timing=False, repair=False):
+                 bitlog=True, timing=False, repair=False, exact_fir=False):
         self.L = K.load()
         self.nch, self.decim = int(nch), int(decim)
         self.ntaps = int(ntaps if ntaps is not None else decim)
         self.nstreams = int(nstreams if nstreams is not None else nch)
         self.max_blocks = int(max_blocks)
         cfg = K.Config(device, self.nch, self.nstreams, self.decim, self.ntaps, self.max_blocks,
-                       (K.F_BITLOG if bitlog else 0) | (K.F_TIMING if timing else 0) | (K.F_REPAIR if repair else 0))
+                       (K.F_BITLOG if bitlog else 0) | (K.F_TIMING if timing else 0) | (K.F_REPAIR if repair else 0) |
+                       (K.F_EXACT_FIR if exact_fir else 0))
         self.ctx = C.c_void_p()
         rc = self.L.acg_create(C.byref(self.ctx), C.byref(cfg))
         if rc != K.OK:
             raise K.AcgError(rc, "acg_create")
         self.bit_cap = self.L.acg_bit_capacity(self.ctx)
+        self.max_lag = self.L.acg_max_lag(self.ctx)
         self.Fc = None
 
     def close(self):

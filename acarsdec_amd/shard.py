@@ -24,12 +24,13 @@ def local_index(channel, world):
     return int(channel) // int(world)
 
 
-def scatter_channel_config(cfg_rows, world, rank, dist=None, src=0, device=None):
+def scatter_channel_config(cfg_rows, world, rank, dist=None, src=0, device=None, force=False):
     """Rank `src` holds one config row per GLOBAL channel (e.g. [offset_hz, phase, track, id]); every
     rank ends up with the rows of the channels it owns.  The table is tiny (32 B per channel), so it
     is sent with the most basic collective -- one broadcast -- and sliced locally; the same code
-    runs over gloo (CPU tests) and RCCL (device tensors).  cfg_rows may be None on other ranks."""
-    if world == 1 or dist is None:
+    runs over gloo (CPU tests) and RCCL (device tensors).  cfg_rows may be None on other ranks.
+    force: go through the collective even with world == 1 (bench.py --rccl-selftest: the RCCL path on a one-GPU box)."""
+    if dist is None or (world == 1 and not force):
         rows = np.asarray(cfg_rows, dtype=np.float64)
         return rows[owned_channels(len(rows), rank, world)]
     import torch
@@ -49,7 +50,7 @@ def gather_blocks(local_blocks, own_ids, world, rank, dist=None, dst=0):
     """Blocks decoded on this rank carry LOCAL channel indices; returns on `dst` the merged list
     with GLOBAL channel ids, ordered by (channel, end_bit) like the single-GPU drain."""
     fixed = [(int(own_ids[b[0]]),) + tuple(b[1:]) for b in local_blocks]
-    if world == 1 or dist is None:
+    if dist is None:
         return sorted(fixed, key=lambda b: (b[0], b[-1]))
     box = [None] * world if rank == dst else None
     dist.gather_object(fixed, box, dst=dst)
@@ -60,8 +61,9 @@ def gather_blocks(local_blocks, own_ids, world, rank, dist=None, dst=0):
 
 
 def reduce_timing(seconds, count, world, dist=None, device=None):
-    """max over ranks of the timed-region duration, sum of a per-rank count."""
-    if world == 1 or dist is None:
+    """max over ranks of the timed-region duration, sum of a per-rank count.  With a `dist` handle the collectives run
+    whatever the world size (a world of one still exercises the backend)."""
+    if dist is None:
         return float(seconds), float(count)
     import torch
     t = torch.tensor([float(seconds)], dtype=torch.float64, device=device)
@@ -73,7 +75,7 @@ def reduce_timing(seconds, count, world, dist=None, device=None):
 
 def gather_scalars(x, world, dist=None, device=None):
     """every rank's scalar, in rank order, on every rank (per-GPU timings of the bench report)."""
-    if world == 1 or dist is None:
+    if dist is None:
         return [float(x)]
     import torch
     mine = torch.tensor([float(x)], dtype=torch.float64, device=device)

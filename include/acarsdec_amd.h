@@ -49,6 +49,11 @@ extern "C" {
                                      drain/collect then return what outputmsg() receives -- parity/CRC
                                      verified or repaired, parity stripped, err = parity errors found --
                                      and omit the blocks the reference drops */
+#define ACG_F_EXACT_FIR 8u        /* verification mode: the u8 down-converter adds the rtlMult terms of rtl.c:349-351 one after
+                                     the other, products and 127.37 per sample rounded separately -- what an IEEE (-O2) build of
+                                     the reference executes -- so dm and everything after it is BIT-IDENTICAL to that build.
+                                     The streaming kernels re-associate the sum (|d dm| <= 1e-5 |dm|, like the reference's own
+                                     -Ofast build); this one is ~20x slower and exists to prove that nothing else differs */
 
 typedef struct acg_ctx acg_ctx;
 
@@ -193,11 +198,17 @@ int  acg_feed_samples_host(acg_ctx *ctx, int fmt, const void *p0, const void *p1
 int  acg_drain_frames(acg_ctx *ctx, acg_frame *out, int max_frames, int *nframes);
 /* Streaming variant: hands over the blocks of every process call except the `lag` most recent
  * ones and waits only for those older calls, so that the newest call(s) keep the GPU busy
- * (lag = 1: classic double buffering; lag = 0: wait for the last call only).  0 <= lag <= 6. */
+ * (lag = 1: classic double buffering; lag = 0: wait for the last call only).  0 <= lag <= acg_max_lag(). */
 int  acg_collect_frames(acg_ctx *ctx, int lag, acg_frame *out, int max_frames, int *nframes);
+/* Largest lag this context accepts: its block queue is sized for the worst case (a 56-bit block every 291 samples on
+ * every channel) of acg_max_lag() + 1 calls, so a host that collects after every call cannot be lapped.  6 unless that
+ * would take more than 512 MiB (then fewer, at least 1). */
+int  acg_max_lag(const acg_ctx *ctx);
 /* SURVEY 8f.4, the batch sink: like acg_drain_frames / acg_collect_frames, but every block is taken through
  * outputmsg()'s field split on the device and handed over as a fixed binary record.  Needs ACG_F_REPAIR (outputmsg()
- * receives repaired, parity-stripped blocks); blocks the repair drops are omitted.  Ordered by (chn, end_bit). */
+ * receives repaired, parity-stripped blocks); blocks the repair drops are omitted.  Ordered by (chn, end_bit).  If more
+ * messages are queued than max_msgs, the oldest max_msgs are handed out, the rest STAY queued and the call returns
+ * ACG_EOVERFLOW ("call again"); every byte of a record is defined (unused text bytes are 0). */
 int  acg_drain_msgs(acg_ctx *ctx, acg_msg *out, int max_msgs, int *nmsgs);
 int  acg_collect_msgs(acg_ctx *ctx, int lag, acg_msg *out, int max_msgs, int *nmsgs);
 /* Per-bit records of the LAST process call for one channel (needs ACG_F_BITLOG):
@@ -218,6 +229,10 @@ typedef void (*acg_bit_sink)(void *user, int ch, float vo, float lvl);
 int  acg_replay_bits(acg_ctx *ctx, acg_bit_sink sink, void *user);
 
 /* ---- measurement -------------------------------------------------------------------------- */
+/* Measurement / layout switches (ACG_FIR_VARIANT, ACG_MSK_LPC, ACG_FIR_WAVES_PER_WG, ...: see DESIGN.md).  The
+ * environment is read ONCE per process, at the library's first look-up, and what was picked up is reported on stderr;
+ * afterwards only this call changes a switch (value NULL removes the override).  Not product configuration. */
+int  acg_tune(const char *name, const char *value);
 /* Sums of HIP-event-bracketed kernel time since the last call (ACG_F_TIMING), in ms, and the
  * number of launches they cover.  Synchronises. */
 int  acg_get_timing(acg_ctx *ctx, double *fir_ms, int *fir_launches, double *msk_ms, int *msk_launches);

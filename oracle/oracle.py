@@ -284,6 +284,9 @@ class Ref:
             L.ref_in_callback.argtypes = [C.c_void_p, C.c_uint]
             L.ref_get_wf.argtypes = [C.c_int, C.c_void_p, C.c_int]
             L.ref_get_wf.restype = C.c_int
+            if hasattr(L, 'ref_set_wf'):
+                L.ref_set_wf.argtypes = [C.c_int, C.c_void_p, C.c_int]
+                L.ref_set_wf.restype = C.c_int
         L.ref_init_file.argtypes = [C.c_int]
         L.ref_demod.argtypes = [C.c_int, C.c_void_p, C.c_int]
         L.ref_get_dm.argtypes = [C.c_int]
@@ -394,6 +397,12 @@ class Ref:
         fr = self.L.ref_get_wf(n, out.ctypes.data, self.M)
         return fr, out
 
+    def set_wf(self, n, taps):
+        """channel n's taps := taps ([ntaps, 2] float32, zero beyond): the reference's in_callback on a caller's tap table"""
+        taps = np.ascontiguousarray(taps, dtype=np.float32).reshape(-1, 2)
+        if self.L.ref_set_wf(n, taps.ctypes.data, taps.shape[0]) != 0:
+            raise RuntimeError("ref_set_wf failed")
+
     def dm(self, n, count=1024):
         return np.ctypeslib.as_array(self.L.ref_get_dm(n), shape=(count,)).copy()
 
@@ -455,3 +464,59 @@ def read_wav_pcm16(path):
 def wav_to_float(pcm16):
     """libsndfile's sf_read_float normalisation for PCM16: x / 32768 (soundfile.c:65)."""
     return (pcm16.astype(np.float32) / np.float32(32768.0)).astype(np.float32)
+
+
+# --------------------------------------------------------------------------- reference builds against each other
+def ref_blocks_forked(variant, rows, M, taps, timeout_s=600):
+    """The UNMODIFIED reference build `variant` ("" = -O2 IEEE, "_fast" = the reference's own -Ofast -march=native,
+    "_v3") run over rows[c] (u8 I/Q of whole callbacks) with channel c's tap table taps[c], one channel per pass, through
+    its own in_callback -> demodMSK -> decodeAcars.  Returns [blocks of channel c as (len, err, crc, txt)] or None when
+    the build is missing or cannot run on this host (an -march=native build may hit an illegal instruction elsewhere).
+    Runs in a forked child: the reference is all global state, and a crash must not take the caller down.  The child
+    touches only numpy and the reference library (no GPU runtime calls after the fork)."""
+    import pickle
+    import select
+    import signal
+    import time
+    if not ref_available(variant):
+        return None
+    blk = 1024 * M * 2
+    rfd, wfd = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        rc = 1
+        try:
+            os.close(rfd)
+            os.dup2(os.open(os.devnull, os.O_WRONLY), 2)      # initRtl narrates on stderr
+            ref = Ref(variant)
+            out = []
+            for c in range(len(rows)):
+                ref.init_rtl(["131.725"], M)               # one channel; its state is re-initialised by every init
+                ref.set_wf(0, taps[c])
+                r = np.ascontiguousarray(rows[c]).reshape(-1)
+                for b in range(r.size // blk):
+                    ref.in_callback(r[b * blk:(b + 1) * blk])
+                out.append([(int(f.len), int(f.err), bytes(f.crc), bytes(f.txt[: max(0, f.len)])) for f in ref.raw_frames()])
+            with os.fdopen(wfd, "wb") as w:
+                pickle.dump(out, w)
+            rc = 0
+        finally:
+            os._exit(rc)
+    os.close(wfd)
+    data = b""
+    t0 = time.time()
+    with os.fdopen(rfd, "rb") as r:
+        while True:
+            left = timeout_s - (time.time() - t0)
+            if left <= 0:
+                os.kill(pid, signal.SIGKILL)
+                break
+            if select.select([r], [], [], min(left, 1.0))[0]:
+                chunk = os.read(r.fileno(), 1 << 20)
+                if not chunk:
+                    break
+                data += chunk
+    _, status = os.waitpid(pid, 0)
+    if status != 0 or not data:
+        return None
+    return pickle.loads(data)

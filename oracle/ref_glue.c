@@ -284,6 +284,18 @@ int ref_get_wf(int n, float *out, int M)
 	}
 	return channel[n].Fr;
 }
+/* Overwrites the tap table initRtl built for channel n (rtl.c:283-286) with the caller's: lets a test run the
+ * reference's in_callback on the very taps another implementation was given (bench.py's reference -O2 vs -Ofast leg).
+ * Taps beyond ntaps are zero.  Harness only: nothing of the reference is modified. */
+int ref_set_wf(int n, const float *taps, int ntaps)
+{
+	int i;
+	if (n < 0 || (unsigned int)n >= nbch || ntaps < 0 || ntaps > rtlMult)
+		return -1;
+	for (i = 0; i < rtlMult; i++)
+		channel[n].wf[i] = i < ntaps ? taps[2 * i] + taps[2 * i + 1] * I : 0;
+	return 0;
+}
 #endif /* WITH_RTL */
 
 #ifdef WITH_SOAPY

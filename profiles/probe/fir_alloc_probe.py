@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np
 import torch
 from acarsdec_amd import decoder as D, _capi as K
+from acarsdec_amd import _capi as _K   # switches go through acg_tune: the library reads the environment once
 
 nch = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 nblk = int(sys.argv[2]) if len(sys.argv) > 2 else 4
@@ -48,16 +49,16 @@ for r in range(rounds):
     dec = D.Decoder(nch, decim=M, ntaps=ntaps, max_blocks=nblk, bitlog=False)
     dec.set_taps(base[np.arange(nch) % 40])
     f1 = time_fir(dec, iq)
-    os.environ["ACG_FIR_VARIANT"] = ALT
+    _K.tune("ACG_FIR_VARIANT", ALT)
     f1n = time_fir(dec, iq)
-    os.environ.pop("ACG_FIR_VARIANT")
+    _K.tune("ACG_FIR_VARIANT", None)
     dec.close()
     dec = D.Decoder(nch, decim=M, ntaps=ntaps, max_blocks=nblk, bitlog=False)
     dec.set_taps(base[np.arange(nch) % 40])
     f2 = time_fir(dec, iq)
-    os.environ["ACG_FIR_VARIANT"] = ALT
+    _K.tune("ACG_FIR_VARIANT", ALT)
     f2n = time_fir(dec, iq)
-    os.environ.pop("ACG_FIR_VARIANT")
+    _K.tune("ACG_FIR_VARIANT", None)
     g = C.c_double(0)
     L.acg_probe_read_dev(iq.data_ptr(), min(iq.numel(), 1 << 34), 3, C.byref(g))
     print("round %d: iq at 0x%x  fir %.3f of 8 TB/s (variant %s: %.3f); same iq, new decoder: %.3f (%.3f); pure reader %.0f GB/s" % (

@@ -3,6 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 from acarsdec_amd import decoder as D
+from acarsdec_amd import _capi as _K   # switches go through acg_tune: the library reads the environment once
 from oracle import oracle as O
 for M, nch, nblk in ((200, 5, 2), (160, 5, 2), (200, 40, 8)):
     rng = np.random.default_rng(M)
@@ -10,7 +11,7 @@ for M, nch, nblk in ((200, 5, 2), (160, 5, 2), (200, 40, 8)):
     iq = rng.integers(0, 256, size=(nch, nout * M * 2), dtype=np.uint8)
     taps = np.stack([O.rtl_taps(131000000 + 25000 * (c + 1), 131000000, M) for c in range(nch)])
     for variant in ("5", "3"):
-        os.environ["ACG_FIR_VARIANT"] = variant
+        _K.tune("ACG_FIR_VARIANT", variant)
         dec = D.Decoder(nch, decim=M, max_blocks=nblk, bitlog=False)
         dec.set_taps(taps)
         dec.in_callback(iq)

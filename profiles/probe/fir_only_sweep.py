@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np
 import torch
 from acarsdec_amd import decoder as D, _capi as K
+from acarsdec_amd import _capi as _K   # switches go through acg_tune: the library reads the environment once
 
 specs = sys.argv[1:] or ["1024:200:8:200:3", "1024:200:8:200:5", "1024:200:128:200:5", "16384:200:8:200:3", "16384:200:8:200:5",
                          "4096:200:32:192:3", "4096:200:32:192:5", "1024:160:8:160:3", "1024:160:8:160:5", "1024:192:8:192:5",
@@ -36,11 +37,11 @@ for spec in specs:
         print("pure reader on %.2f GB: %.0f GB/s" % (iq.numel() / 1e9, g.value), flush=True)
         cache[key] = iq
     iq = cache[key]
-    os.environ["ACG_FIR_VARIANT"] = variant
+    _K.tune("ACG_FIR_VARIANT", variant)
     if wg:
-        os.environ["ACG_FIR_WG_PER_CU"] = wg
+        _K.tune("ACG_FIR_WG_PER_CU", wg)
     else:
-        os.environ.pop("ACG_FIR_WG_PER_CU", None)
+        _K.tune("ACG_FIR_WG_PER_CU", None)
     dec = D.Decoder(nch, decim=M, ntaps=ntaps, max_blocks=nblk, bitlog=False)
     base = np.stack([D.rtl_taps(131000000 + 25000 * (1 + c), 131000000, M)[:ntaps] for c in range(40)])
     dec.set_taps(base[np.arange(nch) % 40])

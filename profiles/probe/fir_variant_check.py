@@ -6,6 +6,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np
 import torch
 from acarsdec_amd import decoder as D, synth as S
+from acarsdec_amd import _capi as _K   # switches go through acg_tune: the library reads the environment once
 from oracle import oracle as O
 
 variant = sys.argv[1] if len(sys.argv) > 1 else "6"
@@ -29,7 +30,7 @@ taps = np.stack([D.rtl_taps(131000000 + 25000 * (1 + c % 7), 131000000, M)[:ntap
 d = torch.from_numpy(iq).cuda()
 out = {}
 for v in ("5", variant):
-    os.environ["ACG_FIR_VARIANT"] = v
+    _K.tune("ACG_FIR_VARIANT", v)
     dec = D.Decoder(nch, decim=M, ntaps=ntaps, max_blocks=nblk, bitlog=False)
     dec.set_taps(taps)
     st = torch.cuda.Stream()

@@ -7,10 +7,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np
 import torch
 from acarsdec_amd import decoder as D, _capi as K
+from acarsdec_amd import _capi as _K   # switches go through acg_tune: the library reads the environment once
 
 variant = sys.argv[1] if len(sys.argv) > 1 else "5"
 ndec = int(sys.argv[2]) if len(sys.argv) > 2 else 6
-os.environ["ACG_FIR_VARIANT"] = variant
+_K.tune("ACG_FIR_VARIANT", variant)
 L = K.load()
 nch, M, nblk, ntaps = 16384, 200, 4, 200
 row = nblk * 1024 * M * 2
@@ -53,14 +54,14 @@ for k in range(ndec):
 print("second pass over the same decoders (same placements):")
 for k, dec in enumerate(decs):
     g = measure(dec)
-    os.environ["ACG_FIR_DEBUG_DMPITCH0"] = "1"
+    _K.tune("ACG_FIR_DEBUG_DMPITCH0", "1")
     g0 = measure(dec)
-    del os.environ["ACG_FIR_DEBUG_DMPITCH0"]
+    _K.tune("ACG_FIR_DEBUG_DMPITCH0", None)
     other = {}
     for v in ("5", "55", "7", "8"):
-        os.environ["ACG_FIR_VARIANT"] = v
+        _K.tune("ACG_FIR_VARIANT", v)
         other[v] = measure(dec).mean() / 8000
-    os.environ["ACG_FIR_VARIANT"] = variant
+    _K.tune("ACG_FIR_VARIANT", variant)
     print("decoder %d: %s GB/s  (%.3f of 8 TB/s);  all dm rows folded into the first (no write stream): %.3f;  variants 5 / 55 / 7 / 8: %.3f %.3f %.3f %.3f" % (
         k, " ".join("%.0f" % x for x in g), g.mean() / 8000, g0.mean() / 8000, other["5"], other["55"], other["7"], other["8"]), flush=True)
 for dec in decs:

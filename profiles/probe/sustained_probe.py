@@ -11,9 +11,10 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np
 import torch
 from acarsdec_amd import decoder as D, _capi as K
+from acarsdec_amd import _capi as _K   # switches go through acg_tune: the library reads the environment once
 
 variant = sys.argv[1] if len(sys.argv) > 1 else "5"
-os.environ["ACG_FIR_VARIANT"] = variant
+_K.tune("ACG_FIR_VARIANT", variant)
 L = K.load()
 nch, M, nblk, ntaps = 16384, 200, 4, 200
 row = nblk * 1024 * M * 2

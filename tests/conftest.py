@@ -23,6 +23,21 @@ def has_gpu():
         return False
 
 
+@pytest.fixture
+def tune():
+    """tune(name, value): a measurement switch of the library for the rest of this test (acg_tune; None removes it).  The
+    library reads the environment only once per process, so setting os.environ inside a test would do nothing."""
+    from acarsdec_amd import _capi as K
+    touched = []
+
+    def set_(name, value):
+        K.tune(name, value)
+        touched.append(name)
+    yield set_
+    for n in touched:
+        K.tune(n, os.environ.get(n))
+
+
 @pytest.fixture(scope="session")
 def golden():
     with open(os.path.join(GOLDEN, "testwav_golden.json")) as f:

@@ -8,10 +8,8 @@
 #include <stdint.h>
 #include <complex.h>
 static double tab[128][2];
-static void build(void) {
-    const long double d = 2.0L * 3.14159265358979323846264338327950288L / 128.0L;
-    for (int j = 0; j < 128; j++) { tab[j][0] = (double)cosl(j * d); tab[j][1] = (double)sinl(j * d); }
-}
+void acg_host_sincos_table(double* t);       // the product's own table builder (acarsdec_amd/csrc/host_setup.c, linked in)
+static void build(void) { acg_host_sincos_table(&tab[0][0]); }
 static inline void sc_tab(double x, double* sn, double* cs) {
     const double kd = rint(x * (6.36619772367581382433e-01 * 32.0));
     const int q = (int)kd;

@@ -21,7 +21,7 @@ def last_json(text):
 
 def test_bench_line_contract():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--channels", "256", "--steps", "4", "--warmup", "1",
-                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--no-cpu-baseline", "--sustain", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     d = last_json(r.stdout)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -29,8 +29,16 @@ def test_bench_line_contract():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["peak"] == 8000.0
-    assert d["parity"]["bit_exact"] is True and d["parity"]["blocks"] > 0 and d["parity"]["dm_within_1e5_rel"] is True
-    assert d["parity"]["channels_checked"] == 64
+    par = d["parity"]
+    assert par["blocks_exact_given_gpu_dm"] is True and par["blocks"] > 0 and par["dm_within_1e5_rel"] is True
+    assert par["channels_checked"] == 64 and "bit_exact" not in par
+    # the exact-order mode closes the argument: same GPU demodulator, dm bit-identical to the oracle -> end to end identical
+    assert par["exact_order_mode"]["dm_bit_identical_to_oracle"] is True and par["exact_order_mode"]["blocks_identical_end_to_end"] is True
+    assert par["end_to_end"]["blocks_differing"] <= par["end_to_end"]["allowed"]
+    if par["reference_builds"] is not None:           # oracle/_ref travelled: the reference's two builds on the same bytes
+        assert par["reference_builds"]["oracle_vs_ref_o2_blocks_differing"] == 0
+        assert par["end_to_end"]["allowed"] == par["reference_builds"]["ref_fast_vs_ref_o2_blocks_differing"] + 1
+    assert d["sustain"]["passes_per_step"] == 1 and d["burst"]["value"] > 0
     assert abs(d["value"] - 256 * 8 * 1024 * 200 * 4 / (d["ms_per_step"] * 4e-3) / 1e6) < 1e-3 * d["value"]
     assert d["time_dominant_kernel"] in ("msk_demod_kernel", d["roofline"]["kernel"]) and 0 < d["whole_job_frac_of_hbm"] < 1
     assert d["roofline"]["pure_reader_GBs_measured_this_run"] > 1000
@@ -41,15 +49,23 @@ def test_bench_also_cases_in_one_line():
     roofline and whole-job fraction of HBM bandwidth (here at reduced sizes through the case table)."""
     code = ("import sys, bench; bench.CASES['throughput'].update(channels=128, blocks=4); "
             "bench.CASES['wide'].update(channels=512, blocks=2); bench.CASES['stress'].update(channels=256, blocks=2); "
-            "sys.argv = ['bench.py', '--steps', '3', '--warmup', '1', '--no-cpu-baseline']; bench.main()")
+            "sys.argv = ['bench.py', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--sustain', '0.5']; bench.main()")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     d = last_json(r.stdout)
     assert set(d["also"]) == {"wide", "stress"}
     for name, a in d["also"].items():
-        assert a["parity"]["dm_within_1e5_rel"] is True and a["parity"]["bit_exact"] is True and a["parity"]["channels_checked"] == 64
+        assert a["parity"]["dm_within_1e5_rel"] is True and a["parity"]["blocks_exact_given_gpu_dm"] is True and a["parity"]["channels_checked"] == 64
+        assert a["parity"]["exact_order_mode"]["blocks_identical_end_to_end"] is True
         assert 0 < a["roofline"]["frac"] < 1 and 0 < a["whole_job_frac_of_hbm"] < 1 and a["value"] > 0
-    assert d["also"]["wide"]["parity"]["blocks"] >= 0 and "filter" in d["also"]["stress"]["config"]
+        # sustained timing: a step is several passes, the timed region lasts what --sustain asked for, value follows from it
+        su = a["sustain"]
+        assert su["passes_per_step"] >= 1 and a["timed_region_s"] >= 0.45 and len(su["step_ms_min_median_max"]) == 3
+        c = a["config"]
+        want = c["channels_per_gpu"] * c["blocks_per_step"] * 1024 * c["decim"] * 3 / a["timed_region_s"] / 1e6
+        assert abs(a["value"] - want) < 2e-3 * want and c["blocks_per_step"] == c["blocks_per_pass"] * su["passes_per_step"]
+    # the stress case's gate channels carry ACARS: its block comparison is not vacuous
+    assert d["also"]["stress"]["parity"]["blocks"] > 0 and "filter" in d["also"]["stress"]["config"]
 
 
 def test_bench_gpus_flag_self_launch():
@@ -58,12 +74,12 @@ def test_bench_gpus_flag_self_launch():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
     env["ACG_BENCH_BACKEND"] = "gloo"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--channels", "256", "--steps", "4",
-                        "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+                        "--warmup", "1", "--no-cpu-baseline", "--sustain", "0"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     d = last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["channels_total"] == 512 and len(d["per_gpu"]) == 2
     assert len([l for l in r.stdout.splitlines() if l.startswith("{")]) == 1
-    assert d["parity"]["bit_exact"] is True and d["parity"]["channels_checked"] == 64
+    assert d["parity"]["blocks_exact_given_gpu_dm"] is True and d["parity"]["channels_checked"] == 64
     # without the rehearsal backend a 1-GPU box must refuse 2 ranks instead of running one
     import torch
     if torch.cuda.device_count() < 2:
@@ -77,12 +93,49 @@ def test_bench_two_ranks_rehearsal():
     env = dict(os.environ, ACG_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--channels", "256", "--steps", "4",
-           "--warmup", "1", "--no-cpu-baseline"]
+           "--warmup", "1", "--no-cpu-baseline", "--sustain", "0"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     d = last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["channels_per_gpu"] == 256 and d["config"]["channels_total"] == 512
-    assert d["parity"]["bit_exact"] is True
+    assert d["parity"]["blocks_exact_given_gpu_dm"] is True
     assert len([l for l in r.stdout.splitlines() if l.startswith("{")]) == 1          # rank 0 alone reports
     # whole-job aggregate: both ranks' samples over the slowest rank's time
     assert abs(d["value"] - 2 * 256 * 8 * 1024 * 200 * 4 / (d["ms_per_step"] * 4e-3) / 1e6) < 1e-3 * d["value"]
+
+
+def test_bench_rccl_path_runs_with_world_size_one():
+    """The RCCL code path on a one-GPU box: torch.distributed initialised with backend nccl and world size 1, and the channel
+    scatter (two broadcasts of device tensors), the barrier(device_ids=...) pairs around the timed regions, the MAX / SUM
+    all-reduces and the all-gather of the per-rank times all go through it instead of the world == 1 short-cuts -- the calls
+    the 8-GPU run makes, executed once on hardware."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "ACG_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--rccl-selftest", "--channels", "256", "--steps", "4",
+                        "--warmup", "1", "--no-cpu-baseline", "--sustain", "0", "--no-ref-leg"], capture_output=True, text=True, timeout=900,
+                       cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    d = last_json(r.stdout)
+    assert d["n_gpus"] == 1 and "nccl" in d["config"]["collectives"] and d["parity"]["blocks_exact_given_gpu_dm"] is True
+    assert abs(d["value"] - 256 * 8 * 1024 * 200 * 4 / (d["ms_per_step"] * 4e-3) / 1e6) < 1e-3 * d["value"]
+
+
+def test_shard_collectives_over_rccl_world_one():
+    """acarsdec_amd/shard.py's collectives on device tensors over nccl (= RCCL) with a world of one, in a child process."""
+    code = (
+        "import os, sys, numpy as np, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, %r)\n"
+        "from acarsdec_amd import shard\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29541', RANK='0', WORLD_SIZE='1')\n"
+        "dev = torch.device('cuda', 0); torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', device_id=dev)\n"
+        "cfg = np.arange(40, dtype=np.float64).reshape(10, 4)\n"
+        "mine = shard.scatter_channel_config(cfg, 1, 0, dist, device=dev, force=True)\n"
+        "assert np.array_equal(mine, cfg)\n"
+        "dist.barrier(device_ids=[0])\n"
+        "t, c = shard.reduce_timing(1.25, 7, 1, dist, dev)\n"
+        "assert (t, c) == (1.25, 7.0)\n"
+        "assert shard.gather_scalars(2.5, 1, dist, dev) == [2.5]\n"
+        "assert shard.gather_blocks([(0, 5, 0, b'ab', b'xyz', 9)], [3], 1, 0, dist) == [(3, 5, 0, b'ab', b'xyz', 9)]\n"
+        "dist.destroy_process_group(); print('RCCL_OK')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-800:], r.stderr[-2500:])

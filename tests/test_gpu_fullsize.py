@@ -90,7 +90,7 @@ def test_replicated_channels_agree_and_match_oracle(env, nch, M, ntaps, nblk):
     dec.close()
 
 
-def test_chunking_and_pipeline_invariance_1024(env, monkeypatch):
+def test_chunking_and_pipeline_invariance_1024(env, tune):
     """1024 channels x 2.5 Msps: 1 call x 4 callbacks == 4 calls x 1 callback == pipeline chunk 1/2/off."""
     torch, D, S, K, O = env
     nch, M, nblk, nsrc = 1024, 200, 4, 16
@@ -102,9 +102,9 @@ def test_chunking_and_pipeline_invariance_1024(env, monkeypatch):
     results = []
     for mode in ("one", "four", "pipe0", "pipe2"):
         if mode.startswith("pipe"):
-            monkeypatch.setenv("ACG_PIPE_BLOCKS", mode[4:])
+            tune("ACG_PIPE_BLOCKS", mode[4:])
         else:
-            monkeypatch.delenv("ACG_PIPE_BLOCKS", raising=False)
+            tune("ACG_PIPE_BLOCKS", None)
         dec = D.Decoder(nch, decim=M, nstreams=nsrc, max_blocks=nblk)
         dec.set_taps(taps)
         dec.set_channel_streams(smap)

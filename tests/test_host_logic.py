@@ -4,6 +4,8 @@ arithmetic (taps, centre frequency, filter prototype) equals the oracle's bit fo
 import ctypes as C
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -30,6 +32,20 @@ def test_library_exports_every_declared_symbol():
     assert L.acg_strerror(K.ENODEV).startswith(b"no GPU")
 
 
+def test_tuning_switches_go_through_one_table_not_the_environment():
+    """ACG_* measurement switches: the library reads the environment once (and says so on stderr); afterwards only acg_tune
+    changes them.  Names outside the ACG_ prefix are refused."""
+    L = K.load()
+    assert L.acg_tune(b"ACG_FIR_VARIANT", b"55") == K.OK and L.acg_tune(b"ACG_FIR_VARIANT", None) == K.OK
+    assert L.acg_tune(b"LD_PRELOAD", b"x") == K.EINVAL and L.acg_tune(None, b"1") == K.EINVAL
+    src = open(os.path.join(ROOT, "acarsdec_amd", "csrc", "fir.hip")).read() + open(os.path.join(ROOT, "acarsdec_amd", "csrc", "msk.hip")).read()
+    assert "getenv(" not in src                                   # no launch path reads the environment
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ['ACG_FIR_DEBUG_SHAPE'] = '1'\n"
+            "from acarsdec_amd import _capi as K; K.tune('ACG_MSK_LPC', 4)" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "tuning overrides taken from the environment" in r.stderr and "ACG_FIR_DEBUG_SHAPE=1" in r.stderr
+
+
 def test_device_sincos_model_keeps_the_mixer_products_of_glibc_cexp(tmp_path):
     """msk.hip sincos_tab (128-entry table + rotation by the remainder) restated on the CPU operation for operation
     (tests/sincos_model.c): <= 2.5 ulp against long-double libm, and -- what the demodulator keeps, msk.c:90 -- every
@@ -40,7 +56,8 @@ def test_device_sincos_model_keeps_the_mixer_products_of_glibc_cexp(tmp_path):
     if not shutil.which("gcc"):
         pytest.skip("gcc not available")
     exe = str(tmp_path / "sincos_model")
-    r = subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", exe, os.path.join(ROOT, "tests", "sincos_model.c"), "-lm"],
+    r = subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-o", exe, os.path.join(ROOT, "tests", "sincos_model.c"),
+                        os.path.join(ROOT, "acarsdec_amd", "csrc", "host_setup.c"), "-lm"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run([exe, "4000000"], capture_output=True, text=True, timeout=600)
@@ -55,7 +72,16 @@ def test_device_sincos_model_keeps_the_mixer_products_of_glibc_cexp(tmp_path):
     consts = set(re.findall(r"-?\d\.\d{10,}e[-+]\d+", dev))
     assert len(consts) >= 7 and consts <= set(re.findall(r"-?\d\.\d{10,}e[-+]\d+", model)), consts
     host = open(os.path.join(ROOT, "acarsdec_amd", "csrc", "host_setup.c")).read()
-    assert "ACG_SINCOS_N 128" in host and "cosl(j * d)" in host and "tab[128][2]" in model
+    assert "ACG_SINCOS_N 128" in host and "acg_octant[17][2]" in host and "tab[128][2]" in model and "acg_host_sincos_table(&tab[0][0])" in model
+    # the table itself: exact on the axes, mirrored entries are the same doubles, every entry next to libm
+    tab = (C.c_double * 256)()
+    K.load().acg_host_sincos_table(tab)
+    t = np.array(tab[:]).reshape(128, 2)
+    assert t[0].tolist() == [1.0, 0.0] and t[32].tolist() == [0.0, 1.0] and t[64].tolist() == [-1.0, 0.0] and t[96].tolist() == [0.0, -1.0]
+    j = np.arange(128)
+    assert np.array_equal(t[:, 0], t[(128 - j) % 128, 0]) and np.array_equal(t[:, 1], -t[(128 - j) % 128, 1] + 0.0)
+    ang = j * (2 * np.pi / 128)
+    assert np.all(np.abs(t[:, 0] - np.cos(ang)) <= 1e-15) and np.all(np.abs(t[:, 1] - np.sin(ang)) <= 1e-15)      # (np.cos of the ROUNDED angle)
 
 
 def test_coltap_load_groups_cover_a_tile_with_two_fixed_columns_per_lane():

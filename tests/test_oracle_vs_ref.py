@@ -330,3 +330,33 @@ def test_message_split_against_live_reference_program(tmp_path):
     ch.demod(pcm.astype(np.float32) / 32768.0)
     got = [msg_fields_from_record(O.msg_split(b)) for b in (O.blk_process(f) for f in ch.frames) if b is not None]
     assert len(want) >= 280 and got == want
+
+
+def test_reference_builds_against_each_other_and_the_oracle():
+    """bench.py's gate measures how many blocks the reference's own -O2 and -Ofast builds differ by on its input
+    (oracle.ref_blocks_forked: the unmodified in_callback -> demodMSK -> decodeAcars with a caller's tap table through
+    ref_set_wf).  Here at a small size: the -O2 build equals the oracle block for block (that is the pin), the -Ofast build
+    decodes the same blocks on this input (its dm differs at the 1e-7 level; a razor-edge soft decision could differ, none
+    does here), and a build that is not there reports None instead of raising."""
+    from acarsdec_amd import synth as S
+    M, nblk, nch = 200, 20, 6
+    nout = nblk * 1024
+    sigma = 0.25 * 0.5 * (M / (2.0 * 10 ** 2.0)) ** 0.5           # 20 dB SNR in the 12.5 kHz channel (bench.py)
+    rows, taps = [], []
+    for c in range(nch):
+        a, _ = S.channel_audio(np.random.default_rng(0xACA25 + c), nout, gap=(3125, 12500), text_len=(20, 220))
+        off = 25000.0 * (2 + c) * (-1) ** c
+        rows.append(S.iq_u8_from_envelopes((0.5 * (1 + 0.5 * a))[None, :], M, [off], phases=[0.37 * c], noise=sigma,
+                                           rng=np.random.default_rng(500 + c)).reshape(-1))
+        w = O.rtl_taps(131000000 + int(off), 131000000, M)
+        taps.append(w if c % 2 == 0 else w[:192])                  # ref_set_wf zero-fills a shorter table
+    o2 = O.ref_blocks_forked("", rows, M, taps)
+    assert o2 is not None and sum(len(b) for b in o2) >= nch - 1
+    for c in range(nch):
+        ch = O.Channel(c)
+        ch.demod(O.fir_u8(rows[c], M, taps[c], ntaps=taps[c].shape[0]))
+        assert [O.frame_tuple(f)[1:] for f in ch.frames] == o2[c], c
+    fast = O.ref_blocks_forked("_fast", rows, M, taps) or O.ref_blocks_forked("_v3", rows, M, taps)
+    assert fast is not None
+    assert sum(len(set(x) ^ set(y)) for x, y in zip(o2, fast)) == 0
+    assert O.ref_blocks_forked("_no_such_build", rows, M, taps) is None

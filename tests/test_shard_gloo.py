@@ -106,3 +106,31 @@ def test_bench_gpus_flag_launches_ranks_itself():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"], capture_output=True, text=True,
                        env=dict(env, WORLD_SIZE="2", RANK="0"), timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def _solo_worker(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    cfg = np.arange(24, dtype=np.float64).reshape(6, 4)
+    mine = shard.scatter_channel_config(cfg, 1, 0, dist, force=True)
+    t, c = shard.reduce_timing(0.75, 3, 1, dist)
+    per = shard.gather_scalars(0.75, 1, dist)
+    merged = shard.gather_blocks([(1, 7, b"t", 11), (0, 5, b"s", 4)], [10, 20], 1, 0, dist)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((mine.tolist(), t, c, per, merged))
+
+
+def test_collectives_run_with_a_world_of_one():
+    """bench.py --rccl-selftest sends the scatter / reductions / gathers through torch.distributed even with one rank
+    (that is how the RCCL calls get executed on a one-GPU box); the same path over gloo here."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_solo_worker, args=(free_port(), q))
+    p.start()
+    mine, t, c, per, merged = q.get(timeout=120)
+    p.join(60)
+    assert p.exitcode == 0
+    assert mine == np.arange(24, dtype=np.float64).reshape(6, 4).tolist() and (t, c, per) == (0.75, 3.0, [0.75])
+    assert merged == [(10, 5, b"s", 4), (20, 7, b"t", 11)]
