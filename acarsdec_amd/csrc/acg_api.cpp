@@ -1226,6 +1226,8 @@ static int fmt_geometry(acg_ctx* ctx, int fmt, FirArgs* a, int nwin)
     a->nseg = 1;
     a->out_scale = fmt == ACG_FMT_CS16 ? 1.0f / 32768.0f : fmt == ACG_FMT_S16_SPLIT ? 0.25f : 1.0f;
     a->work_counter = ctx->d_work;
+    a->shares_cus = ctx->fir_stream ? 0 : 1;                       // no CU partition: demodulator workgroups run on the same CUs
+    a->high_prio = acg_tune_get("ACG_FIR_PRIO", (!ctx->fir_stream && g.nch >= 16384) ? 1 : 0) ? 1 : 0;      // as launch_fir
     return ACG_OK;
 }
 

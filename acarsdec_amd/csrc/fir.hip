@@ -1771,7 +1771,13 @@ __device__ __forceinline__ void firx_tile(u4v_t* st /* [NLD][U] */, __amdgpu_buf
         D.y += __shfl_xor(D.y, m);
     }
     // power-of-two output scale (1/32768 soapy.c:241, 1/4 sdrplay.c:225): exact, commutes with cabsf
-    if (lane % F::S == 0) dm_out[lane / F::S] = cabs_like_glibc(D.x, D.y) * out_scale;
+    // (write-through like the u8 kernel's: beside the streaming reads a dirty line that waits in L2 costs more than one that
+    //  leaves at once)
+    if (lane % F::S == 0) {
+        float* p = dm_out + lane / F::S;
+        const float v = cabs_like_glibc(D.x, D.y) * out_scale;
+        asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+    }
 }
 
 template <int FMT, int CPR, int W>
@@ -1794,8 +1800,9 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_fmt_direct_kernel(const FirArg
     const unsigned int ntile = (unsigned int)a.nwin / W;                            // whole tiles only (launcher)
     const unsigned int runs_per_ch = ntile / FIRD_R;
     const unsigned int nrun = (unsigned int)a.nch * runs_per_ch;
-    const unsigned int nwaves = gridDim.x * (ACG_WG_FIR / 64);
-    const unsigned int wg = blockIdx.x * (ACG_WG_FIR / 64) + (unsigned int)wave;
+    const unsigned int wpg = blockDim.x >> 6;                                       // the waves of a workgroup never talk to each other
+    const unsigned int nwaves = gridDim.x * wpg;
+    const unsigned int wg = blockIdx.x * wpg + (unsigned int)wave;
     unsigned int* ctr = a.work_counter;
     constexpr unsigned int run_bytes = FIRD_R * F::TILE_BYTES;
     const unsigned int voff = (unsigned int)lane << 4;
@@ -1977,16 +1984,21 @@ template <int FMT, int CPR, int W>
 static int launch_fmt_direct(const FirArgs* a, int num_cu, hipStream_t stream)
 {
     typedef FirX<FMT, CPR, W> F;
-    const size_t lds = (size_t)(ACG_WG_FIR / 64) * F::WAVE_LDS;
+    // workgroup shape as for the u8 kernel (launch_direct): 4-wave workgroups alone, single-wave workgroups (seven per CU)
+    // beside demodulator workgroups on the same CUs, so that the demodulator's LDS fits next to them; 8 waves per CU at most
+    int wpg = env_int("ACG_FIR_WAVES_PER_WG", a->shares_cus ? 1 : 4);
+    if (wpg != 1 && wpg != 2 && wpg != 4) wpg = 4;
+    const size_t lds = (size_t)wpg * F::WAVE_LDS;
     int per_cu = (int)((160 * 1024) / lds);
-    if (per_cu > 2) per_cu = 2;
+    if (per_cu > 8 / wpg) per_cu = 8 / wpg;
+    if (a->shares_cus && wpg == 1 && per_cu > 7) per_cu = 7;
     if (per_cu < 1) return (int)hipErrorInvalidValue;
     per_cu = env_int("ACG_FIR_WG_PER_CU", per_cu);
     const long long nrun = (long long)a->nch * (a->nwin / W / FIRD_R);
     long long grid = (long long)(a->ncu > 0 ? a->ncu : num_cu) * per_cu;
-    const long long need = (nrun + ACG_WG_FIR / 64 - 1) / (ACG_WG_FIR / 64);
+    const long long need = (nrun + wpg - 1) / wpg;
     if (grid > need) grid = need;
-    FIR_LAUNCH((fir_fmt_direct_kernel<FMT, CPR, W>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds, stream, *a, a->iq, a->taps,
+    FIR_LAUNCH((fir_fmt_direct_kernel<FMT, CPR, W>), dim3((unsigned int)grid), dim3(64 * wpg), lds, stream, *a, a->iq, a->taps,
                        a->stream_of, a->dm);
     return (int)hipGetLastError();
 }
@@ -2040,6 +2052,10 @@ extern "C" int acg_launch_fir_fmt(const FirArgs* a, int fmt, void* stream)
 // razor-edge soft decision of the demodulator; with this kernel in front the whole GPU path is bit-identical end to end.
 __global__ void fir_u8_generic_kernel(const FirArgs a)
 {
+    // no fused multiply-add anywhere in this kernel: HIP's __fmul_rn / __fadd_rn are plain operators and contract like any
+    // other under the default -ffp-contract=fast (round 2's fallback kernel did: dm was 1e-8 off the oracle, inside the
+    // tolerance nobody looked under).  tests/test_host_logic.py disassembles the kernel and checks.
+#pragma clang fp contract(off)
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = (long long)a.nch * a.nwin;
     if (gid >= total) return;
@@ -2049,11 +2065,14 @@ __global__ void fir_u8_generic_kernel(const FirArgs a)
     const float* w = a.taps + (size_t)ch * a.ntaps_pad * 2;
     float Dr = 0.f, Di = 0.f;
     for (int k = 0; k < a.ntaps; ++k) {
-        const float r = __fsub_rn((float)p[2 * k], 127.37f);
-        const float g = __fsub_rn((float)p[2 * k + 1], 127.37f);
+        // plain operators on purpose: the pragma governs the operations written HERE, not the bodies of header inlines
+        const float r = (float)p[2 * k] - 127.37f;                         // rtl.c:338
+        const float g = (float)p[2 * k + 1] - 127.37f;                     // rtl.c:339
         const float wr = w[2 * k], wi = w[2 * k + 1];
-        Dr = __fadd_rn(Dr, __fsub_rn(__fmul_rn(r, wr), __fmul_rn(g, wi)));
-        Di = __fadd_rn(Di, __fadd_rn(__fmul_rn(r, wi), __fmul_rn(g, wr)));
+        const float pr = r * wr - g * wi;                                  // rtl.c:351 vb[ind] * wf[ind]
+        const float pi = r * wi + g * wr;
+        Dr = Dr + pr;                                                      // D +=
+        Di = Di + pi;
     }
     a.dm[(size_t)ch * a.dm_pitch + m] = cabs_like_glibc(Dr, Di);
 }

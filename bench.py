@@ -111,6 +111,8 @@ CASES = {
     "wide": dict(tag="north star (>= 10 000 channels per GPU)", channels=16384, decim=200, ntaps=200, blocks=8, content="acars"),
     # BASELINE.json configs[4]: 1 GPU stress, 192-tap LPF FIR, 2.5 Msps, 4096 channels
     "stress": dict(tag="BASELINE configs[4]", channels=4096, decim=200, ntaps=192, blocks=32, content="random+acars"),
+    # the soapy.c front end's sample format (interleaved int16 I/Q) through the same pipeline
+    "cs16": dict(tag="soapy.c CS16 front end (SURVEY 8f.2)", channels=4096, decim=200, ntaps=200, blocks=16, content="format+acars", format="cs16"),
     # BASELINE.json configs[3] per-GPU share: 16384 channels over 8 GPUs
     "shard2048": dict(tag="BASELINE configs[3], per-GPU share", channels=2048, decim=200, ntaps=200, blocks=64, content="acars"),
 }
@@ -189,14 +191,14 @@ def run_case(J, name, case, args, steps, warmup, headline):
     from acarsdec_amd import decoder as D, synth as S, _capi as K, shard
     L, dist, world, rank, dev, cdev = J.L, J.dist, J.world, J.rank, J.dev, J.cdev
     nch, M, ntaps, nblk, content = case["channels"], case["decim"], case["ntaps"], case["blocks"], case["content"]
-    fmt_name = args.format if headline else "u8"
+    fmt_name = case.get("format") or (args.format if headline else "u8")
     fmt = {"u8": 0, "cs16": K.FMT_CS16, "split16": K.FMT_S16_SPLIT, "f32": K.FMT_F32_REAL}[fmt_name]
     bps = 2 if fmt == 0 else 4
     share = max(1, args.share) if headline else 1
     if share > 1:
         assert fmt == 0 and nch % share == 0, "--share needs the u8 format and a channel count divisible by it"
         content = "random"
-    if fmt != 0:
+    if fmt != 0 and content != "format+acars":
         content = "format"
     nstreams = nch // share
     nout = nblk * 1024
@@ -256,6 +258,28 @@ def run_case(J, name, case, args, steps, warmup, headline):
         data_desc = ("uniform random bytes, seeded per stream (SURVEY 8d config 5: the value distribution is irrelevant to bandwidth); "
                      "the first %d channels (the ones the parity gate looks at) carry ACARS/MSK traffic as in the other cases, so "
                      "that the gate compares decoded blocks and not only magnitudes" % nacars)
+    elif content == "format+acars":
+        assert fmt == K.FMT_CS16
+        assert L.acg_fill_random_u8_dev(iq.data_ptr(), row, nstreams, row, 0xACA25 + rank, None) == 0
+        iq.view(torch.int16).bitwise_and_(0x0FFF)
+        nacars = min(nch, max(64, args.check_channels))
+        # the gate's channels: ACARS/MSK traffic as in the u8 cases, up-converted and quantised to int16 (rint(32767 * 0.9 x),
+        # acarsdec_amd/synth.py iq_s16_from_envelopes) with torch on the device, a few channels at a time
+        tt = torch.arange(nout * M, dtype=torch.float64, device=dev) * (2.0 * np.pi / (12500.0 * M))
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(0xACA25 + rank)
+        v16 = iq.view(torch.int16).view(nstreams, -1)
+        for c in range(nacars):
+            a, _ = S.channel_audio(np.random.default_rng(0xACA25 + int(own[c])), nout, gap=(3125, 12500), text_len=(20, 220))
+            env = torch.from_numpy((SCALE * CARRIER * (1.0 + DEPTH * a)).astype(np.float32)).to(dev).repeat_interleave(M)
+            ph = torch.remainder(tt * float(offs[c]) + float(phases[c]), 2.0 * np.pi).to(torch.float32)
+            xi = env * torch.cos(ph) + sigma * torch.randn(nout * M, device=dev, generator=gen)
+            xq = env * torch.sin(ph) + sigma * torch.randn(nout * M, device=dev, generator=gen)
+            v16[c, 0::2] = torch.round(32767.0 * 0.9 * xi).clamp_(-32768, 32767).to(torch.int16)
+            v16[c, 1::2] = torch.round(32767.0 * 0.9 * xq).clamp_(-32768, 32767).to(torch.int16)
+        del tt, env, ph, xi, xq
+        data_desc = ("uniform random 12-bit int16 samples; the first %d channels (the ones the parity gate looks at) carry ACARS/MSK traffic "
+                     "as in the u8 cases (AM depth %.1f, %.0f dB SNR in the channel), quantised to int16 on the device" % (nacars, DEPTH, SNR_DB))
     elif content == "random":
         assert L.acg_fill_random_u8_dev(iq.data_ptr(), row, nstreams, row, 0xACA25 + rank, None) == 0
         data_desc = "uniform random bytes, seeded per stream (SURVEY 8d config 5: the value distribution is irrelevant to bandwidth)"
@@ -742,12 +766,14 @@ def main():
     elif overridden or args.format != "u8" or args.share > 1:
         also = []
     else:
-        also = ["wide", "stress"] if world == 1 else ["shard2048"]
+        also = ["wide", "stress", "cs16"] if world == 1 else ["shard2048"]
         also = [a for a in also if a != args.config]
     cases = [(args.config, case)] + [(a, dict(CASES[a])) for a in also]
     # with several ranks sharing one GPU (gloo rehearsal) keep the footprint small
-    bps = 2 if args.format == "u8" else 4
-    need = max(c["channels"] // (max(1, args.share) if i == 0 else 1) * c["blocks"] * 1024 * c["decim"] * (bps if i == 0 else 2)
+    def case_bps(i, c):
+        f = c.get("format") or (args.format if i == 0 else "u8")
+        return 2 if f == "u8" else 4
+    need = max(c["channels"] // (max(1, args.share) if i == 0 else 1) * c["blocks"] * 1024 * c["decim"] * case_bps(i, c)
                for i, (_, c) in enumerate(cases))
     J.iq_all = torch.empty(need, dtype=torch.uint8, device=dev)
 

@@ -277,6 +277,14 @@ def test_async_ticket_register_is_left_alone_until_its_wait():
         checked += 1
         i = j + 1
     assert checked >= 6, checked       # direct kernel x3 rates, persist x2, shared x2, dma
+    # the exact-order kernel (ACG_F_EXACT_FIR, and the fallback for M % 8 != 0) must not fuse: every product, difference and
+    # sum of rtl.c:349-351 is rounded on its own, as an IEEE build of the reference does it
+    start = next(k for k, l in enumerate(lines) if re.match(r"^_Z\d+fir_u8_generic_kernel\w*:", l))
+    end = next(k for k in range(start, len(lines)) if "s_endpgm" in lines[k])
+    body = [l for l in lines[start:end] if not l.lstrip().startswith((";", "."))]
+    assert not [l for l in body if re.search(r"\bv_(pk_)?(fma|fmac|mac|mad)_(f32|legacy_f32)", l)], "fused multiply-add in the exact-order kernel"
+    # (re, im) ride in packed pairs: two packed products, their packed difference / sum, one packed accumulate per tap
+    assert sum("v_pk_mul_f32" in l for l in body) >= 2 and sum("v_pk_add_f32" in l for l in body) >= 3, "\n".join(body)
 
 
 def test_host_side_under_address_and_undefined_behaviour_sanitizers(tmp_path):
