@@ -754,7 +754,7 @@ extern "C" int acg_process_iq_u8_dev(acg_ctx* ctx, const uint8_t* iq_dev, size_t
     // channel state -- each waiting for its chunk of dm.  A dm chunk slot is rewritten by the
     // next call only after the demodulator launch that read it has finished.  So FIR(k+1) overlaps
     // MSK(k) inside a call, and FIR of call i+1 overlaps the MSK tail of call i.
-    int cb = ctx->pipe_blocks;
+    int cb = acg_tune_get("ACG_PIPE_BLOCKS_LIVE", ctx->pipe_blocks);      // (per call: same-context A/B of the chunk size)
     if (cb <= 0 || cb > nblocks) cb = nblocks;
     int k = 0;
     for (int b0 = 0; b0 < nblocks; b0 += cb, ++k) {

@@ -806,14 +806,14 @@ def main():
             "dtype": "f32",
         }
         for k in ("data", "config", "roofline", "whole_job_frac_of_hbm", "whole_job_GBs_per_gpu", "time_dominant_kernel",
-                  "timed_region_s", "kernels", "parity", "per_gpu", "valu", "ab_same_process", "placement_trials"):
+                  "timed_region_s", "sustain", "burst", "kernels", "parity", "per_gpu", "valu", "ab_same_process", "placement_trials"):
             if k in head:
                 out[k] = head[k]
         if out["time_dominant_kernel"] != out["roofline"]["kernel"]:
             out["roofline"]["note_dominance"] = ("the roofline kernel is the HBM-bound stage; in this case the step time is set by %s (a per-channel "
                                                  "serial recurrence, latency-bound), see whole_job_frac_of_hbm" % out["time_dominant_kernel"])
         if len(res) > 1:
-            out["also"] = {name: {k: r[k] for k in ("value", "ms_per_step", "timed_region_s", "whole_job_frac_of_hbm", "whole_job_GBs_per_gpu",
+            out["also"] = {name: {k: r[k] for k in ("value", "ms_per_step", "timed_region_s", "sustain", "burst", "whole_job_frac_of_hbm", "whole_job_GBs_per_gpu",
                                                     "time_dominant_kernel", "roofline", "kernels", "parity", "config", "data") if k in r}
                            for (name, _), r in zip(cases[1:], res[1:])}
             for name, r in zip([n for n, _ in cases[1:]], res[1:]):
