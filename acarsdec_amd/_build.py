@@ -46,7 +46,8 @@ def build_lib(force=False, stamp=False):
     tag = "_stamp" if stamp else ""
     extra = ["-DACG_MSK_STAMP"] if stamp else []
     out_lib = LIB_STAMP if stamp else LIB
-    hdrs = [os.path.join(CSRC, "acg_internal.h"), os.path.join(INC, "acarsdec_amd.h"), os.path.abspath(__file__)]   # flags live here
+    hdrs = [os.path.join(CSRC, "acg_internal.h"), os.path.join(CSRC, "msk_common.h"), os.path.join(INC, "acarsdec_amd.h"),
+            os.path.abspath(__file__)]   # flags live here
     units = [
         ("fir.hip", ["-O3"]),
         # -ffp-contract=off keeps the reference's separate mul/add roundings.  The -mllvm switches only move

@@ -33,7 +33,7 @@ PY
 }
 for st in "$@"; do
   case $st in
-    tests) timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -15 | tee $O/pytest_gpu.txt ;;
+    tests) timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -25 | tee $O/pytest_gpu.txt ;;
     bench) timeout 900 python bench.py --steps 20 --warmup 3 > $O/bench_line.json 2> $O/bench_err.txt; line $O/bench_line.json bench; tail -5 $O/bench_err.txt ;;
     stats|pmc)
       cd /tmp
