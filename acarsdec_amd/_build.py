@@ -58,6 +58,9 @@ def build_lib(force=False, stamp=False):
         ("msk.hip", ["-O3", "-ffp-contract=off", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-disable-machine-sink",
                      "-mllvm", "-disable-branch-fold", "-mllvm", "-disable-tail-duplicate",
                      "-mllvm", "-structurizecfg-skip-uniform-regions", "-mllvm", "-phi-node-folding-threshold=4"]),
+        ("msk2.hip", ["-O3", "-ffp-contract=off", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-disable-machine-sink",
+                      "-mllvm", "-disable-branch-fold", "-mllvm", "-disable-tail-duplicate",
+                      "-mllvm", "-structurizecfg-skip-uniform-regions", "-mllvm", "-phi-node-folding-threshold=4"]),
         ("synth.hip", ["-O3"]),
         ("blk.hip", ["-O3"]),
         ("acg_api.cpp", ["-O2"]),
@@ -66,7 +69,7 @@ def build_lib(force=False, stamp=False):
     hc = hipcc()
     for name, flags in units:
         src = os.path.join(CSRC, name)
-        if stamp and name not in ("msk.hip", "acg_api.cpp"):
+        if stamp and name not in ("msk.hip", "acg_api.cpp"):   # (msk2.hip has no stamps)
             objs.append(os.path.join(OBJDIR, name + ".o"))          # unchanged units are shared with the product build
             continue
         obj = os.path.join(OBJDIR, name + tag + ".o")

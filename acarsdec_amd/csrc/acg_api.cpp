@@ -141,6 +141,7 @@ struct acg_ctx {
     int last_len = 0;               // samples per channel of the last demod call
     int msk_lpc = 8;                // lanes per channel in the MSK kernel
     int msk_high_prio = 1;
+    int msk_split = 0;              // demodulator as wave pairs (msk2.hip)
     int timing_mode = 0;            // 0 none, 1 both stages, 2 down-converter only (acg_set_timing)
     int msk_cus_default = 0;        // CUs reserved for the demodulator (0 = no partition)
     bool last_had_demod = false;
@@ -672,7 +673,10 @@ static int launch_msk(acg_ctx* c, const float* dm_dev, size_t pitch_floats, int 
     int e;
     {
         RoctxRange range("acg:demodulator");
-        e = acg_launch_msk(&a, lpc, s);
+        // few channels: the two-wave kernel (msk2.hip: the per-bit instruction stream split over a wave pair on two SIMDs);
+        // bit-identical to the one-wave kernel, so the switch may change from launch to launch
+        if (lpc == 8 && acg_tune_get("ACG_MSK_SPLIT", c->msk_split)) e = acg_launch_msk2(&a, c->fir_stream ? 2 : 1, s);
+        else e = acg_launch_msk(&a, lpc, s);
     }
     if (e != 0) {
         c->err = std::string("MSK launch: ") + hipGetErrorString((hipError_t)e);

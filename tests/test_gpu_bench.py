@@ -62,7 +62,7 @@ def test_bench_also_cases_in_one_line():
         assert 0 < a["roofline"]["frac"] < 1 and 0 < a["whole_job_frac_of_hbm"] < 1 and a["value"] > 0
         # sustained timing: a step is several passes, the timed region lasts what --sustain asked for, value follows from it
         su = a["sustain"]
-        assert su["passes_per_step"] >= 1 and a["timed_region_s"] >= 0.45 and len(su["step_ms_min_median_max"]) == 3
+        assert su["passes_per_step"] >= 1 and a["timed_region_s"] >= 0.25 and len(su["step_ms_min_median_max"]) == 3     # (reps come from the burst rate)
         c = a["config"]
         want = c["channels_per_gpu"] * c["blocks_per_step"] * 1024 * c["decim"] * 3 / a["timed_region_s"] / 1e6
         assert abs(a["value"] - want) < 2e-3 * want and c["blocks_per_step"] == c["blocks_per_pass"] * su["passes_per_step"]

@@ -747,6 +747,85 @@ def test_msk_lane_layouts_are_bit_identical(D, O, S, lpc, tune):
     dec.close()
 
 
+def test_msk_two_wave_kernel_is_bit_identical_to_the_one_wave_kernel(D, O, S, tune):
+    """msk2.hip splits the demodulator's per-bit instruction stream over a wave pair (mixer chain / clock + framing) that
+    meet at three barriers per bit; the framing state machine's write-back into the loop (MskDf = 0, acars.c:242) crosses as a
+    precomputed verdict.  Same operations in the same order: every soft bit, the loop state (doubles included) and every
+    block must equal the one-wave kernel's EXACTLY -- on ragged call lengths (periods straddling calls: the per-sample tail),
+    empty and tiny calls, noise-only channels (resets fire ~19 times a second), and the in_callback pipeline (vector refills,
+    two pairs per workgroup on the CU-masked stream).  Blocks also against the oracle."""
+    rng = np.random.default_rng(2024)
+    nch, n = 19, 12000                      # not a multiple of the channels per wave pair
+    x = np.zeros((nch, n), dtype=np.float32)
+    for c in range(nch):
+        a, _ = S.channel_audio(rng, n, gap=(800, 2000), text_len=(5, 40))
+        x[c] = S.envelope(a, carrier=0.3, noise=0.02, rng=rng)
+    x[3] = rng.normal(0.2, 0.1, n)          # noise only
+    x[7] = 0.0                              # exact silence
+    cuts = [0, 2999, 2999, 3000, 3005, 3006, 3013, 3077, 7173, 7173 + 4096, n]        # calls of 2999, 0, 1, 5, 1, 7, 64, 4096, 4096, rest
+
+    def run_dm(split):
+        tune("ACG_MSK_SPLIT", split)
+        dec = D.Decoder(nch, decim=8, ntaps=8, max_blocks=8)
+        fr, bits = [], [[] for _ in range(nch)]
+        for a0, a1 in zip(cuts[:-1], cuts[1:]):
+            if a1 > a0:
+                dec.demod_msk(x[:, a0:a1])
+                fr += dec.drain_frames()
+                cnt, vo, lvl = dec.bits_all()
+                for c in range(nch):
+                    bits[c].append((vo[c, :cnt[c]].copy(), lvl[c, :cnt[c]].copy()))
+        st = [dec.state(c) for c in range(nch)]
+        dec.close()
+        return blocks_by_channel(fr, D.frame_tuple), bits, st
+
+    one, two = run_dm("0"), run_dm("1")
+    assert one[0] == two[0]
+    for c in range(nch):
+        for (v1, l1), (v2, l2) in zip(one[1][c], two[1][c]):
+            assert np.array_equal(v1.view(np.uint32), v2.view(np.uint32)) and np.array_equal(l1.view(np.uint32), l2.view(np.uint32)), c
+        for k, v in one[2][c].items():
+            assert np.array_equal(np.asarray(v), np.asarray(two[2][c][k])), (c, k, v, two[2][c][k])
+        ch = O.Channel(c)
+        ch.demod(x[c])
+        assert two[0].get(c, []) == [O.frame_tuple(f) for f in ch.frames], c
+    assert sum(len(v) for v in two[0].values()) >= nch - 4
+
+    # the in_callback pipeline: 2.5 Msps u8 input, 20 channels on 3 streams, calls of 1..3 callbacks
+    M, nblk = 200, 6
+    env = []
+    for c in range(20):
+        a, _ = S.channel_audio(rng, nblk * 1024, gap=(1500, 3000), text_len=(5, 40))
+        env.append(0.5 * (1 + 0.5 * a))
+    smap = np.arange(20) % 3
+    off = [25000.0 * (2 + c // 3) * (-1) ** c for c in range(20)]
+    rows = [S.iq_u8_from_envelopes(np.array([env[c] for c in range(20) if smap[c] == s_]), M, [off[c] for c in range(20) if smap[c] == s_],
+                                   scale=0.12, noise=0.02, rng=rng) for s_ in range(3)]
+    iq = np.stack(rows)
+    taps = np.stack([D.rtl_taps(131000000 + int(off[c]), 131000000, M) for c in range(20)])
+    row1 = 1024 * M * 2
+
+    def run_iq(split):
+        tune("ACG_MSK_SPLIT", split)
+        dec = D.Decoder(20, decim=M, nstreams=3, max_blocks=3)
+        dec.set_taps(taps)
+        dec.set_channel_streams(smap)
+        fr, b0 = [], 0
+        for nb_ in (1, 3, 2):
+            dec.in_callback(iq[:, b0 * row1:(b0 + nb_) * row1])
+            fr += dec.drain_frames()
+            b0 += nb_
+        st = [dec.state(c) for c in range(20)]
+        dec.close()
+        return blocks_by_channel(fr, D.frame_tuple), st
+
+    one, two = run_iq("0"), run_iq("1")
+    assert one[0] == two[0] and sum(len(v) for v in two[0].values()) >= 10
+    for c in range(20):
+        for k, v in one[1][c].items():
+            assert np.array_equal(np.asarray(v), np.asarray(two[1][c][k])), (c, k)
+
+
 def test_streaming_collect_equals_blocking_drain(D, O, S):
     """acg_collect_frames(lag=1) (one call in flight) delivers exactly the blocks of acg_drain_frames,
     in the same per-channel order, over many calls on the rtl path with the stream pipeline on."""
