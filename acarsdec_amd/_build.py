@@ -69,7 +69,7 @@ def build_lib(force=False, stamp=False):
     hc = hipcc()
     for name, flags in units:
         src = os.path.join(CSRC, name)
-        if stamp and name not in ("msk.hip", "acg_api.cpp"):   # (msk2.hip has no stamps)
+        if stamp and name not in ("msk.hip", "msk2.hip", "acg_api.cpp"):
             objs.append(os.path.join(OBJDIR, name + ".o"))          # unchanged units are shared with the product build
             continue
         obj = os.path.join(OBJDIR, name + tag + ".o")

@@ -112,6 +112,27 @@ __device__ __forceinline__ Decision decide(const float2 (*ring)[CPW], int slot, 
     return d;
 }
 
+// ACG_MSK_STAMP (measurement build only): s_memtime around every barrier of the per-period loop, summed per wave:
+// [0] B1 -> B2 work, [1] wait at B2, [2] B2 -> B3 work, [3] wait at B3, [4] B3 -> B1 work, [5] wait at B1; [8] periods
+#ifdef ACG_MSK_STAMP
+#define STAMP2_DECL unsigned long long st2_acc[6] = {0, 0, 0, 0, 0, 0}, st2_n = 0, st2_prev = __builtin_amdgcn_s_memtime();
+#define STAMP2(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st2_acc[k] += t_ - st2_prev; st2_prev = t_; } while (0)
+#define STAMP2_WRITE() do { if (a.stamp && tid == 0) { unsigned long long* o_ = a.stamp + (size_t)(blockIdx.x * 2 * PAIRS + wv) * 10; \
+        for (int k_ = 0; k_ < 6; ++k_) o_[k_] = st2_acc[k_]; o_[6] = 0; o_[7] = 0; o_[8] = st2_n; o_[9] = st2_n; } } while (0)
+#else
+#define STAMP2_DECL
+#define STAMP2(k) do { } while (0)
+#define STAMP2_WRITE() do { } while (0)
+#endif
+
+// The per-period barriers only order LDS traffic between the waves of the pair: wait for this wave's LDS operations, then
+// the hardware barrier.  (__syncthreads() also waits for the wave's GLOBAL operations -- wave H's bit-record and text stores,
+// its window loads: hundreds of cycles of store acknowledgement per period that the other wave would spend waiting.)
+__device__ __forceinline__ void pair_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // what decodeAcars (acars.c:246-375) would do to the loop if the byte register became r in this state: reset_acars() or not
 __device__ __forceinline__ bool would_reset(int astate, int blen, int berr, unsigned int r)
 {
@@ -191,7 +212,11 @@ __global__ __launch_bounds__(128 * PAIRS) void msk_demod2_kernel(const MskArgs a
         int n = 0;
         cont_post(n + 6 <= len);
         __syncthreads();                                                   // P0: tables, ring, window (H) are in place
+        STAMP2_DECL
         while (cont_any()) {
+#ifdef ACG_MSK_STAMP
+            ++st2_n;
+#endif
             const bool act = n + 6 <= len;
             // this period's mixer input: lane g takes sample n + g (msk.c:86)
             const float in = P.win[slot][(n + g) & (2 * WB - 1)];
@@ -208,8 +233,15 @@ __global__ __launch_bounds__(128 * PAIRS) void msk_demod2_kernel(const MskArgs a
             double sn, cs;
             sincos_tab(myp, lds.sc, &sn, &cs);
             const double ind = (double)in;
-            const float2 x = make_float2((float)(ind * cs), (float)(ind * (-sn)));              // msk.c:90
-            __syncthreads();                                               // B2: H's {samples, fired, o} of this period
+            float2 x = make_float2((float)(ind * cs), (float)(ind * (-sn)));                    // msk.c:90
+            // (the mixer output exists BEFORE the barrier: this interval is where wave H computes the clock steps and the tap
+            //  phase, about as long as the phase chain + sin/cos; left alone the scheduler sinks the sin/cos behind the barrier,
+            //  into the interval that is M's longest)
+            asm volatile("" : "+v"(x.x), "+v"(x.y));
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP2(0);
+            pair_barrier();                                                 // B2: H's {samples, fired, o} of this period
+            STAMP2(1);
             const int per = act ? mg->per : 0;
             const int cnt = per & 7;
             const bool fired = (per & 8) != 0;
@@ -223,11 +255,11 @@ __global__ __launch_bounds__(128 * PAIRS) void msk_demod2_kernel(const MskArgs a
             }
             // the phase after cnt steps: 5 or 6 in a locked loop; anything else (the first period of a launch that began in
             // the previous call) is picked out of the lane that holds it
-            double pn = cnt == 6 ? p6 : p5;
-            if (__any(act & (cnt < 5))) {
+            double pn = cnt == 6 ? p6 : (cnt == 5 ? p5 : p);               // (0: a channel that has no whole period left)
+            if (__any((cnt > 0) & (cnt < 5))) {
                 const int src = (tid & ~(LPC - 1)) + (cnt > 0 ? cnt - 1 : 0);
                 const double pl = __shfl(myp, src, 64);
-                pn = cnt == 0 ? p : (cnt < 5 ? pl : pn);
+                pn = ((cnt > 0) & (cnt < 5)) ? pl : pn;
             }
             p = pn;
             idx += (unsigned int)cnt;
@@ -245,7 +277,9 @@ __global__ __launch_bounds__(128 * PAIRS) void msk_demod2_kernel(const MskArgs a
                 mg->lvl = d.lvl;
                 odd = !odd;                                                // MskS++ (msk.c:127); MskS ^= 2 leaves bit 0 alone
             }
-            __syncthreads();                                               // B3: H's verdict for this bit
+            STAMP2(2);
+            pair_barrier();                                                 // B3: H's verdict for this bit
+            STAMP2(3);
             if (fired) {
                 const int c = vo > 0 ? 2 : (vo < 0 ? 1 : 0);
                 const bool reset = ((mg->verdict >> c) & 1) != 0;          // acars.c:242, inside putbit, before msk.c:130
@@ -254,8 +288,11 @@ __global__ __launch_bounds__(128 * PAIRS) void msk_demod2_kernel(const MskArgs a
             }
             mg->df = df;
             cont_post(n + 6 <= len);
-            __syncthreads();                                               // B1: H may start the next period
+            STAMP2(4);
+            pair_barrier();                                                 // B1: H may start the next period
+            STAMP2(5);
         }
+        STAMP2_WRITE();
         __syncthreads();                                                   // T1: H's half of the state is in P.hst
         // ---- the last <= 5 samples of the launch: demodMSK() one sample at a time (msk.c:73-131), state merged
         Lane L;
@@ -369,7 +406,11 @@ __global__ __launch_bounds__(128 * PAIRS) void msk_demod2_kernel(const MskArgs a
         float pvo = 0.f, plvl = 0.f;             // ... its soft bit and level (read right after B1: M overwrites them after B2)
         cont_post(n + 6 <= len);
         __syncthreads();                                                   // P0
+        STAMP2_DECL
         while (cont_any()) {
+#ifdef ACG_MSK_STAMP
+            ++st2_n;
+#endif
             const bool act = n + 6 <= len;
             // ---- bit clock of this period, msk.c:95-100 (f32 accumulate, f64 compare) and the tap phase, msk.c:103
             const double s = K_VCO + df;
@@ -408,7 +449,9 @@ __global__ __launch_bounds__(128 * PAIRS) void msk_demod2_kernel(const MskArgs a
             if (o < 0) o = 0;
             L.clk = clk_f;
             mg->per = cnt | (fired ? 8 : 0) | (o << 4);
-            __syncthreads();                                               // B2
+            STAMP2(0);
+            pair_barrier();                                                 // B2
+            STAMP2(1);
             // ---- the PREVIOUS period's bit: level sums, bit record, putbit, decodeAcars (msk.c:112-126, 53-63; acars.c:246-375)
             if (prev_fired) {
                 const float lvl = plvl, vo = pvo;
@@ -451,7 +494,9 @@ __global__ __launch_bounds__(128 * PAIRS) void msk_demod2_kernel(const MskArgs a
             prev_fired = fired;
             n += cnt;
             prev_end = n;
-            __syncthreads();                                               // B3
+            STAMP2(2);
+            pair_barrier();                                                 // B3
+            STAMP2(3);
             // ---- dm window upkeep (once per 64 samples per channel)
             if (n >= refill_at && n < len) {
                 store_block(pend_blk);
@@ -460,11 +505,14 @@ __global__ __launch_bounds__(128 * PAIRS) void msk_demod2_kernel(const MskArgs a
                 fetch_block(pend_blk);
             }
             cont_post(n + 6 <= len);
-            __syncthreads();                                               // B1: M's df for the next period, and the bit it just decided
+            STAMP2(4);
+            pair_barrier();                                                 // B1: M's df for the next period, and the bit it just decided
+            STAMP2(5);
             df = mg->df;
             pvo = mg->vo;
             plvl = mg->lvl;
         }
+        STAMP2_WRITE();
         // the last period's bit
         if (prev_fired) {
             const float lvl = plvl, vo = pvo;

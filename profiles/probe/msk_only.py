@@ -1,5 +1,5 @@
 """Stand-alone timing of the demodulator launch on ACARS traffic (nothing running beside it):
-python profiles/probe/msk_only.py [channels] [blocks]"""
+python profiles/probe/msk_only.py [channels] [blocks] [ACG_MSK_SPLIT values, e.g. 0,1,0,1]"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
@@ -24,13 +24,21 @@ for _ in range(3):
     assert L.acg_process_dm_dev(dec.ctx, d.data_ptr(), n, n, st.cuda_stream) == 0
     dec.drain_frames_raw(65536)
 dec.timing()
-R = 10
-t0 = time.perf_counter()
-for _ in range(R):
+for split in ([None] if len(sys.argv) <= 3 else sys.argv[3].split(",")):
+  if split is not None:
+    K.tune("ACG_MSK_SPLIT", split)              # 0: one wave per channel group (msk.hip), 1: wave pairs (msk2.hip)
+    for _ in range(2):
+        assert L.acg_process_dm_dev(dec.ctx, d.data_ptr(), n, n, st.cuda_stream) == 0
+        dec.drain_frames_raw(65536)
+    dec.timing()
+  R = 10
+  t0 = time.perf_counter()
+  for _ in range(R):
     assert L.acg_process_dm_dev(dec.ctx, d.data_ptr(), n, n, st.cuda_stream) == 0
     nf = dec.drain_frames_raw(65536)[0]
-dt = (time.perf_counter() - t0) / R
-tim = dec.timing()
-bits = n / 5.2083
-print("msk_only nch=%d blk=%d lpc=%s: kernel %.4f ms per call (%.3f us/bit/wave), wall %.4f ms, %d blocks per call" % (
+  dt = (time.perf_counter() - t0) / R
+  tim = dec.timing()
+  bits = n / 5.2083
+  print("split %s  " % split, end="")
+  print("msk_only nch=%d blk=%d lpc=%s: kernel %.4f ms per call (%.3f us/bit/wave), wall %.4f ms, %d blocks per call" % (
     nch, nblk, os.environ.get("ACG_MSK_LPC", "auto"), tim["msk_ms"] / R, tim["msk_ms"] / R * 1e3 / bits, dt * 1e3, nf))
