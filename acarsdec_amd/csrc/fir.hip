@@ -1797,8 +1797,11 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_fmt_direct_kernel(const FirArg
     f2* Pw = P + lane;
     const f2* Pr = P + lane * F::EP;
 
+    // a run = `pairs` consecutive two-tile bodies of one channel (launcher: as many as leave every wave ~32 runs), so that the
+    // ticket, the row lookup and the tap table are paid once per run -- as in fir_u8_direct_kernel
+    const unsigned int pairs = (unsigned int)a.run_pairs;
     const unsigned int ntile = (unsigned int)a.nwin / W;                            // whole tiles only (launcher)
-    const unsigned int runs_per_ch = ntile / FIRD_R;
+    const unsigned int runs_per_ch = ntile / (FIRD_R * pairs);
     const unsigned int nrun = (unsigned int)a.nch * runs_per_ch;
     const unsigned int wpg = blockDim.x >> 6;                                       // the waves of a workgroup never talk to each other
     const unsigned int nwaves = gridDim.x * wpg;
@@ -1837,8 +1840,8 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_fmt_direct_kernel(const FirArg
     };
     auto run_base = [&](unsigned int run, unsigned int& ch, unsigned int& t0) -> const uint8_t* {
         ch = run / runs_per_ch;
-        t0 = (run - ch * runs_per_ch) * FIRD_R;
-        return in_base + (size_t)stream_of[ch] * a.pitch + (size_t)t0 * F::TILE_BYTES;
+        t0 = (run - ch * runs_per_ch) * FIRD_R * pairs;
+        return in_base + (size_t)(a.stream_identity ? (int)ch : stream_of[ch]) * a.pitch + (size_t)t0 * F::TILE_BYTES;
     };
     // taps of channel ch: lane takes columns lane, lane + 64, ... (16 * NPL bytes each)
     auto fetch_taps = [&](unsigned int ch, float4 (&tp)[F::NPASS][F::NPL]) {
@@ -1895,30 +1898,38 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_fmt_direct_kernel(const FirArg
         unsigned int tk;
         if (lane == 0) ticket_request(ctr + s * ACG_DISP_STRIDE, tk);
         float* __restrict__ dm_out = dm_base + (size_t)ch * a.dm_pitch + (size_t)t0 * W;
-        static_assert(FIRD_R == 2, "the run is unrolled by hand: first tile, last tile");
-        firx_tile<FMT, CPR, W, 0>(st, cur0, cur1, cur0, cur1, voff, Tl, Pw, Pr, dm_out, lane, a.out_scale);
-        unsigned int nrun_ = run_of_ticket(s, ticket_take<F::NLD * F::U + 1>(tk));
-        if (nrun_ == NONE) {
-            s = (s + 1 == ACG_DISP_SHARDS) ? 0 : s + 1;
-            nrun_ = probe(s);
-        }
-        const bool has_next = nrun_ != NONE;
-        unsigned int nch_ = ch, nt0 = t0;
-        const uint8_t* nbase = base;
-        if (has_next) nbase = run_base(nrun_, nch_, nt0);
-        const __amdgpu_buffer_rsrc_t nxt0 = fird_rsrc(nbase, has_next ? run_bytes : 0u);
-        const __amdgpu_buffer_rsrc_t nxt1 = fird_rsrc(nbase + (F::NLD == 2 ? a.plane : 0), has_next ? run_bytes : 0u);
+        static_assert(FIRD_R == 2, "a body is unrolled by hand: first tile, second tile");
+        bool has_next = true;
+        unsigned int nrun_ = NONE, nch_ = ch, nt0 = t0;
         float4 tp[F::NPASS][F::NPL];
-        fetch_taps(nch_, tp);
-        firx_tile<FMT, CPR, W, 1>(st, cur0, cur1, nxt0, nxt1, voff, Tl, Pw, Pr, dm_out + W, lane, a.out_scale);
+        for (unsigned int j = 0; j < pairs; ++j) {
+            firx_tile<FMT, CPR, W, 0>(st, cur0, cur1, cur0, cur1, voff, Tl, Pw, Pr, dm_out, lane, a.out_scale);
+            // second tile of the body: where does the stream go next -- the next body of this run, or the next run's first
+            const uint8_t* nbase = base + run_bytes;
+            if (j + 1 == pairs) {
+                nrun_ = run_of_ticket(s, ticket_take<F::NLD * F::U + 1>(tk));
+                if (nrun_ == NONE) {
+                    s = (s + 1 == ACG_DISP_SHARDS) ? 0 : s + 1;
+                    nrun_ = probe(s);
+                }
+                has_next = nrun_ != NONE;
+                nbase = base;
+                if (has_next) nbase = run_base(nrun_, nch_, nt0);
+                fetch_taps(nch_, tp);
+            }
+            const __amdgpu_buffer_rsrc_t nxt0 = fird_rsrc(nbase, has_next ? run_bytes : 0u);
+            const __amdgpu_buffer_rsrc_t nxt1 = fird_rsrc(nbase + (F::NLD == 2 ? a.plane : 0), has_next ? run_bytes : 0u);
+            firx_tile<FMT, CPR, W, 1>(st, cur0, cur1, nxt0, nxt1, voff, Tl, Pw, Pr, dm_out + W, lane, a.out_scale);
+            dm_out += FIRD_R * W;
+            base = nbase;
+            cur0 = nxt0;
+            cur1 = nxt1;
+        }
         if (!has_next) break;
         write_taps(tp);
         run = nrun_;
         ch = nch_;
         t0 = nt0;
-        base = nbase;
-        cur0 = nxt0;
-        cur1 = nxt1;
     }
     sign_off();
 }
@@ -1994,11 +2005,19 @@ static int launch_fmt_direct(const FirArgs* a, int num_cu, hipStream_t stream)
     if (a->shares_cus && wpg == 1 && per_cu > 7) per_cu = 7;
     if (per_cu < 1) return (int)hipErrorInvalidValue;
     per_cu = env_int("ACG_FIR_WG_PER_CU", per_cu);
-    const long long nrun = (long long)a->nch * (a->nwin / W / FIRD_R);
     long long grid = (long long)(a->ncu > 0 ? a->ncu : num_cu) * per_cu;
+    const long long bodies_per_ch = a->nwin / W / FIRD_R;
+    const long long bodies = (long long)a->nch * bodies_per_ch;
+    int pairs = 1;
+    while (pairs < 8 && bodies_per_ch % (2 * pairs) == 0 && bodies / (2 * pairs) >= 32 * grid * wpg) pairs *= 2;
+    pairs = env_int("ACG_FIR_RUN_PAIRS", pairs);
+    if (pairs < 1 || pairs > 8 || (pairs & (pairs - 1)) || bodies_per_ch % pairs) pairs = 1;      // 1, 2, 4 or 8
+    const long long nrun = bodies / pairs;
     const long long need = (nrun + wpg - 1) / wpg;
     if (grid > need) grid = need;
-    FIR_LAUNCH((fir_fmt_direct_kernel<FMT, CPR, W>), dim3((unsigned int)grid), dim3(64 * wpg), lds, stream, *a, a->iq, a->taps,
+    FirArgs b = *a;
+    b.run_pairs = pairs;
+    FIR_LAUNCH((fir_fmt_direct_kernel<FMT, CPR, W>), dim3((unsigned int)grid), dim3(64 * wpg), lds, stream, b, a->iq, a->taps,
                        a->stream_of, a->dm);
     return (int)hipGetLastError();
 }
