@@ -338,6 +338,7 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
     c->ntaps_pad = c->tile_path ? ((cfg->ntaps + 7) & ~7) : cfg->ntaps;
     c->max_len = cfg->max_blocks * ACG_BLOCK;
     c->dm_pitch = ((size_t)c->max_len + 63) & ~(size_t)63;
+    c->dm_pitch += (size_t)(std::max(0, acg_tune_get("ACG_DM_PAD", 0)) & ~63);      // (experiment) rows staggered against each other
     c->bit_cap = c->max_len / 4 + 8;
     // shortest possible block: SYN SYN SOH ETX CRC CRC + END byte = 56 bits ~ 291 samples.  The ring holds the worst case of
     // lag_max + 1 calls (a collect that stays `lag` calls behind leaves lag + 1 calls' blocks in it), so a host that

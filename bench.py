@@ -544,8 +544,17 @@ def run_case(J, name, case, args, steps, warmup, headline):
         # input, timed the same way -- how much of the run-to-run spread is where the decoder's buffers happen to lie
         trials = [round(nch * nout * M * steps * reps / dt_local / 1e6, 0)]
         others, spacers = [], []
+        dummies = []
         for k in range(1, args.decoders):
-            spacers.append(torch.empty((((k * 53) << 20) + 4096 * k,), dtype=torch.uint8, device=dev))
+            # (probe switches: ACG_BENCH_SPACER_MB changes where the next decoder's buffers land without touching its streams;
+            #  ACG_BENCH_DUMMY_STREAMS creates streams in between, which shifts the decoder's streams to other hardware queues
+            #  without touching its memory)
+            sp = int(os.environ.get("ACG_BENCH_SPACER_MB", "53"))
+            if sp:
+                spacers.append(torch.empty((((k * sp) << 20) + 4096 * k,), dtype=torch.uint8, device=dev))
+            for _ in range(int(os.environ.get("ACG_BENCH_DUMMY_STREAMS", "0"))):
+                dummies.append(torch.cuda.Stream(priority=-1))
+                dummies.append(torch.cuda.Stream())
             d2 = make_decoder()
             others.append(d2)
             for _ in range(2):

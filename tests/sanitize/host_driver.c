@@ -17,7 +17,7 @@ void acg_host_crc_tables_n(unsigned short *crc, unsigned short *synd, int nk);
 
 #define STUB(name) int name() { fprintf(stderr, "launcher " #name " reached without a GPU\n"); abort(); return -1; }
 STUB(acg_launch_fir) STUB(acg_launch_fir_generic) STUB(acg_launch_fir_shared) STUB(acg_launch_regroup_taps)
-STUB(acg_launch_fir_fmt) STUB(acg_launch_msk) STUB(acg_launch_blk_repair) STUB(acg_launch_sincos_selftest)
+STUB(acg_launch_fir_fmt) STUB(acg_launch_msk) STUB(acg_launch_msk2) STUB(acg_launch_blk_repair) STUB(acg_launch_sincos_selftest)
 STUB(acg_launch_div2_selftest) STUB(acg_launch_msg_split) STUB(acg_launch_synth_iq) STUB(acg_launch_fill_random) STUB(acg_launch_read_probe)
 size_t acg_fir_lds_bytes() { return 0; }
 
@@ -111,6 +111,9 @@ int main(void)
 		CHECK(acg_feed_samples_host(NULL, ACG_FMT_CS16, buf, NULL, 4, 4) == ACG_EINVAL);
 		CHECK(acg_drain_frames(NULL, fr, 2, &n) == ACG_EINVAL && acg_collect_frames(NULL, 1, fr, 2, &n) == ACG_EINVAL);
 		CHECK(acg_drain_msgs(NULL, NULL, 0, &n) == ACG_EINVAL && acg_collect_msgs(NULL, 1, NULL, 0, &n) == ACG_EINVAL);
+		CHECK(acg_max_lag(NULL) == 0);
+		CHECK(acg_tune("PATH", "x") == ACG_EINVAL && acg_tune(NULL, "1") == ACG_EINVAL);
+		CHECK(acg_tune("ACG_FIR_VARIANT", "55") == ACG_OK && acg_tune("ACG_FIR_VARIANT", NULL) == ACG_OK && acg_tune("ACG_NOT_SET", NULL) == ACG_OK);
 		CHECK(acg_read_bits(NULL, 0, buf, buf, 4, &n) == ACG_EINVAL && acg_read_bits_all(NULL, &n, buf, buf) == ACG_EINVAL);
 		CHECK(acg_bit_capacity(NULL) == 0 && acg_read_dm(NULL, 0, buf, 4) == ACG_EINVAL);
 		CHECK(acg_get_state(NULL, 0, &st) == ACG_EINVAL && acg_set_state(NULL, 0, &st) == ACG_EINVAL);
