@@ -66,14 +66,16 @@ def run_cpu_baseline(M, seconds=12.0):
         so = os.path.join(ROOT, "oracle", "_ref", "libacarsref%s.so" % variant)
         if not os.path.exists(so):
             continue
-        cmd = [sys.executable, me, "--cpu-child", variant, str(M), "4", str(seconds)]
+        # 96 distinct callbacks = 39 MB per pass at rtlMult 200: the input streams from memory, as it does from a dongle (round 2
+        # cycled through 4 cache-resident buffers, which flattered the CPU)
+        cmd = [sys.executable, me, "--cpu-child", variant, str(M), "96", str(seconds)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode == 0 and r.stdout.strip():
             d = json.loads(r.stdout.strip().splitlines()[-1])
             out = dict(value=round(d["value"], 2), unit="channel*Msamples/s", cores=1, kind="reference",
                        sample="unmodified reference rtl.c in_callback + msk.c + acars.c (%s), 1 channel per stream, "
                               "rtlMult=%d, %d callbacks of 1024 outputs in %.1f s on one host core (the reference is "
-                              "single-threaded; 4 cache-resident 410 KB buffers)" % (label, M, d["blocks"], d["seconds"]))
+                              "single-threaded; cycling through 96 distinct 410 KB callbacks = 39 MB, beyond the per-core caches)" % (label, M, d["blocks"], d["seconds"]))
             # the fair "all host cores" number: one independent reference process per core
             ncpu = min(os.cpu_count() or 1, 64)
             if ncpu > 1:
@@ -692,7 +694,9 @@ def main():
                     help="channels per input stream (rtl.c's own shape: one dongle feeds up to 16 channels); >1 = shared-stream "
                          "mode, VALU-bound, reported separately and never as the roofline figure (SURVEY 8d)")
     ap.add_argument("--bitlog", type=int, default=1, help="1: the demodulator also writes its per-bit soft symbols (vo, level: 8 B per bit) to HBM")
-    ap.add_argument("--placements", type=int, default=4, help="contexts tried for placement before the run (1 = take the first)")
+    ap.add_argument("--placements", type=int, default=1,
+                    help="diagnostic: contexts tried with acg_placement_trial before the run, the fastest kept (round 3: inside one process the "
+                         "contexts lie within 1 % of each other bar one outlier, and the level is the box's -- so the bench takes the first)")
     ap.add_argument("--decoders", type=int, default=1, help="measurement aid: time this many decoders (separate allocations) in the same process")
     ap.add_argument("--ab", default=None, help="measurement aid: comma-separated ACG_FIR_VARIANT values (or NAME=v1,v2 for another per-launch "
                                                "switch, e.g. ACG_MSK_LPC_LIVE=2,4) timed after the run in the same process, same decoder")

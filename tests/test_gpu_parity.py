@@ -532,6 +532,61 @@ def test_device_message_split_matches_reference_json_and_oracle(D, O, msgsplit_g
     dec.close()
 
 
+def test_message_drain_keeps_what_does_not_fit_and_records_are_fully_defined(D, msgsplit_golden):
+    """a drain into a buffer that is too small hands out the OLDEST messages that fit, reports ACG_EOVERFLOW
+    ("call again") and keeps the rest queued -- nothing is lost; and every byte of a record is defined (the device staging
+    buffer comes from hipMalloc: the split clears the record before it fills it)."""
+    from acarsdec_amd import _capi as K
+    pcm, want = msgsplit_golden
+    x = pcm.astype(np.float32) / 32768.0
+    chunk = 8192
+    x = np.concatenate([x, np.zeros((-x.size) % chunk, dtype=np.float32)])
+    dec = D.Decoder(2, decim=8, ntaps=8, max_blocks=chunk // 1024, repair=True, bitlog=False)
+    for s in range(0, x.size, chunk):
+        dec.demod_msk(np.tile(x[s:s + chunk], (2, 1)))          # nothing drained in between: everything queues up
+    total = 2 * len(want)
+    got, rounds = [], 0
+    while True:
+        buf = (K.Msg * 7)()
+        n = C.c_int(0)
+        rc = dec.L.acg_drain_msgs(dec.ctx, buf, 7, C.byref(n))
+        assert rc in (K.OK, K.EOVERFLOW), rc
+        got += [K.Msg.from_buffer_copy(buf[i]) for i in range(n.value)]
+        rounds += 1
+        if rc == K.OK:
+            break
+        assert n.value == 7                                     # a full buffer every time there is more
+    assert len(got) == total and rounds == (total + 6) // 7
+    ref = dec2 = None
+    dec2 = D.Decoder(2, decim=8, ntaps=8, max_blocks=chunk // 1024, repair=True, bitlog=False)
+    for s in range(0, x.size, chunk):
+        dec2.demod_msk(np.tile(x[s:s + chunk], (2, 1)))
+    ref = dec2.drain_msgs(4096)
+    key = lambda m: (int(m.chn), int(m.end_bit))
+    assert sorted(bytes(m) for m in got) == sorted(bytes(m) for m in ref) and len({key(m) for m in got}) == total
+    for m in got:                                               # text beyond txt_len and the reserved fields are zero
+        assert bytes(m.txt[m.txt_len:]) == bytes(242 - m.txt_len) and m.reserved0 == 0.0 and m.reserved1 == 0
+    dec.close()
+    dec2.close()
+
+
+def test_collect_lag_is_bounded_by_what_the_block_queue_was_sized_for(D):
+    """acg_max_lag(): the block queue holds the worst case of max_lag + 1 calls (it held two calls' worth while
+    the API allowed a lag of 6), 6 where that costs <= 512 MiB, fewer for very wide contexts; a larger lag is refused."""
+    from acarsdec_amd import _capi as K
+    dec = D.Decoder(64, decim=8, ntaps=8, max_blocks=2, bitlog=False)
+    assert dec.max_lag == 6
+    n = C.c_int(0)
+    buf = (K.Frame * 4)()
+    assert dec.L.acg_collect_frames(dec.ctx, 6, buf, 4, C.byref(n)) == K.OK and dec.L.acg_collect_frames(dec.ctx, 7, buf, 4, C.byref(n)) == K.EINVAL
+    dec.close()
+    wide = D.Decoder(16384, decim=200, max_blocks=8, bitlog=False)
+    assert 1 <= wide.max_lag < 6
+    assert wide.L.acg_collect_frames(wide.ctx, wide.max_lag + 1, buf, 4, C.byref(n)) == K.EINVAL
+    assert b"acg_max_lag" in wide.L.acg_last_error(wide.ctx)
+    wide.close()
+
+
 def assert_state_close(got, want, what):
     """The loop's continuous state against the reference's.  The device differs from glibc only in the last bit of
     the mixer's f64 sin/cos (< 1 ulp, and only the float-rounded product is kept, msk.c:90): a product moves by one
