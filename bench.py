@@ -144,20 +144,50 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def gpu_clock_mhz(local):
-    """current shader clock of GPU `local` from sysfs (amdgpu pp_dpm_sclk: the starred level), or None"""
+def _amdgpu_cards():
     import glob
+    return sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+
+
+def _starred(path):
     try:
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
-        if not cards:
-            return None
-        with open(cards[min(local, len(cards) - 1)]) as f:
+        with open(path) as f:
             for line in f:
                 if "*" in line:
                     return int(float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip()))
     except Exception:
         return None
     return None
+
+
+def gpu_clock_mhz(local):
+    """current shader clock of GPU `local` from sysfs (amdgpu pp_dpm_sclk: the starred level), or None.  With several cards
+    in sysfs (a one-GPU slice of an 8-GPU box) the busy one is the card whose clock is highest."""
+    cards = _amdgpu_cards()
+    vals = [v for v in (_starred(c) for c in cards) if v is not None]
+    return max(vals) if vals else None
+
+
+def gpu_telemetry(local):
+    """{sclk, fclk, mclk (MHz), power (W)} of the busiest card in sysfs, values that cannot be read are None"""
+    import glob
+    import os as _os
+    best, out = -1, dict(sclk=None, fclk=None, mclk=None, power_w=None)
+    for c in _amdgpu_cards():
+        d = _os.path.dirname(c)
+        sclk = _starred(c)
+        if sclk is None or sclk <= best:
+            continue
+        best = sclk
+        pw = None
+        for h in glob.glob(_os.path.join(d, "hwmon", "hwmon*", "power1_average")) + glob.glob(_os.path.join(d, "hwmon", "hwmon*", "power1_input")):
+            try:
+                pw = round(int(open(h).read().strip()) / 1e6, 1)
+                break
+            except Exception:
+                pass
+        out = dict(sclk=sclk, fclk=_starred(_os.path.join(d, "pp_dpm_fclk")), mclk=_starred(_os.path.join(d, "pp_dpm_mclk")), power_w=pw)
+    return out
 
 
 class Job:
@@ -505,13 +535,14 @@ def run_case(J, name, case, args, steps, warmup, headline):
     t0 = time.perf_counter()
     nfr = 0
     marks = [t0]
-    clk_mid = None
+    clk_mid, tele_mid = None, None
     for k_ in range(steps):
         for _ in range(reps):
             nfr += step()
         marks.append(time.perf_counter())
         if k_ == steps // 2:
             clk_mid = gpu_clock_mhz(J.local)
+            tele_mid = gpu_telemetry(J.local)
     clk1 = gpu_clock_mhz(J.local)              # the last call(s) are still running
     nfr += dec.drain_frames_raw(maxfr)[0]      # the last call's blocks: all K steps fully delivered inside the timed region
     barrier()
@@ -534,11 +565,15 @@ def run_case(J, name, case, args, steps, warmup, headline):
                 dec.drain_frames_raw(maxfr)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                for _ in range(steps):
+                clk_ab = None
+                for i_ in range(steps):
                     step()
+                    if i_ == steps - 2:
+                        clk_ab = gpu_telemetry(J.local)
                 dec.drain_frames_raw(maxfr)
                 torch.cuda.synchronize()
                 ab.setdefault(v, []).append(round(nch * nout * M * steps / (time.perf_counter() - t1) / 1e6, 0))
+                ab.setdefault(v + " telemetry", []).append(clk_ab)
         K.tune(ab_name, os.environ.get(ab_name))
     trials = None
     if args.decoders > 1 and world == 1:
@@ -615,7 +650,7 @@ def run_case(J, name, case, args, steps, warmup, headline):
         "ms_per_step": round(dt / steps * 1e3, 4),
         "timed_region_s": round(dt, 4),
         "sustain": {"passes_per_step": reps, "step_ms_min_median_max": [round(step_ms[0], 3), round(step_ms[len(step_ms) // 2], 3), round(step_ms[-1], 3)],
-                    "shader_clock_mhz_start_mid_end": [clk0, clk_mid, clk1],
+                    "shader_clock_mhz_start_mid_end": [clk0, clk_mid, clk1], "telemetry_mid_run": tele_mid,
                     "note": "a step = passes_per_step passes over the resident batch (chosen from the burst rate so that the timed region lasts "
                             ">= --sustain seconds); step times from host time stamps at the step boundaries (the host runs at most one call ahead "
                             "of the device); clocks from sysfs while the device is busy (null where the box does not expose them)"},
