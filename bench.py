@@ -144,9 +144,28 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
-def _amdgpu_cards():
+_CARD_DIR = {}
+
+
+def _card_dir(local):
+    """sysfs directory of HIP device `local`: by PCI address where torch exposes it, else the first amdgpu card"""
+    if local in _CARD_DIR:
+        return _CARD_DIR[local]
     import glob
-    return sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+    d = None
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(local)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        if os.path.exists("/sys/bus/pci/devices/%s/pp_dpm_sclk" % bdf):
+            d = "/sys/bus/pci/devices/%s" % bdf
+    except Exception:
+        d = None
+    if d is None:
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+        d = os.path.dirname(cards[min(local, len(cards) - 1)]) if cards else None
+    _CARD_DIR[local] = d
+    return d
 
 
 def _starred(path):
@@ -161,33 +180,26 @@ def _starred(path):
 
 
 def gpu_clock_mhz(local):
-    """current shader clock of GPU `local` from sysfs (amdgpu pp_dpm_sclk: the starred level), or None.  With several cards
-    in sysfs (a one-GPU slice of an 8-GPU box) the busy one is the card whose clock is highest."""
-    cards = _amdgpu_cards()
-    vals = [v for v in (_starred(c) for c in cards) if v is not None]
-    return max(vals) if vals else None
+    """current shader clock of GPU `local` from sysfs (amdgpu pp_dpm_sclk: the starred level), or None"""
+    d = _card_dir(local)
+    return _starred(os.path.join(d, "pp_dpm_sclk")) if d else None
 
 
 def gpu_telemetry(local):
-    """{sclk, fclk, mclk (MHz), power (W)} of the busiest card in sysfs, values that cannot be read are None"""
+    """{sclk, fclk, mclk (MHz), power (W)} of GPU `local` from sysfs; what cannot be read is None"""
     import glob
-    import os as _os
-    best, out = -1, dict(sclk=None, fclk=None, mclk=None, power_w=None)
-    for c in _amdgpu_cards():
-        d = _os.path.dirname(c)
-        sclk = _starred(c)
-        if sclk is None or sclk <= best:
-            continue
-        best = sclk
-        pw = None
-        for h in glob.glob(_os.path.join(d, "hwmon", "hwmon*", "power1_average")) + glob.glob(_os.path.join(d, "hwmon", "hwmon*", "power1_input")):
-            try:
-                pw = round(int(open(h).read().strip()) / 1e6, 1)
-                break
-            except Exception:
-                pass
-        out = dict(sclk=sclk, fclk=_starred(_os.path.join(d, "pp_dpm_fclk")), mclk=_starred(_os.path.join(d, "pp_dpm_mclk")), power_w=pw)
-    return out
+    d = _card_dir(local)
+    if not d:
+        return dict(sclk=None, fclk=None, mclk=None, power_w=None)
+    pw = None
+    for h in glob.glob(os.path.join(d, "hwmon", "hwmon*", "power1_average")) + glob.glob(os.path.join(d, "hwmon", "hwmon*", "power1_input")):
+        try:
+            pw = round(int(open(h).read().strip()) / 1e6, 1)
+            break
+        except Exception:
+            pass
+    return dict(sclk=_starred(os.path.join(d, "pp_dpm_sclk")), fclk=_starred(os.path.join(d, "pp_dpm_fclk")),
+                mclk=_starred(os.path.join(d, "pp_dpm_mclk")), power_w=pw)
 
 
 class Job:
