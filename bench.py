@@ -593,7 +593,7 @@ def run_case(J, name, case, args, steps, warmup, headline):
         # input, timed the same way -- how much of the run-to-run spread is where the decoder's buffers happen to lie
         trials = [round(nch * nout * M * steps * reps / dt_local / 1e6, 0)]
         others, spacers = [], []
-        dummies = []
+        dummies, trials_alt = [], []
         for k in range(1, args.decoders):
             # (probe switches: ACG_BENCH_SPACER_MB changes where the next decoder's buffers land without touching its streams;
             #  ACG_BENCH_DUMMY_STREAMS creates streams in between, which shifts the decoder's streams to other hardware queues
@@ -616,8 +616,23 @@ def run_case(J, name, case, args, steps, warmup, headline):
             d2.drain_frames_raw(maxfr)
             torch.cuda.synchronize()
             trials.append(round(nch * nout * M * steps / (time.perf_counter() - t1) / 1e6, 0))
+            alt = os.environ.get("ACG_BENCH_DECODERS_ALT")        # probe: the same decoder once more under another FIR variant
+            if alt:
+                K.tune("ACG_FIR_VARIANT", alt)
+                step(dec=d2)
+                d2.drain_frames_raw(maxfr)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(steps):
+                    step(dec=d2)
+                d2.drain_frames_raw(maxfr)
+                torch.cuda.synchronize()
+                trials_alt.append(round(nch * nout * M * steps / (time.perf_counter() - t1) / 1e6, 0))
+                K.tune("ACG_FIR_VARIANT", os.environ.get("ACG_FIR_VARIANT"))
         for d2 in others:
             d2.close()
+        if trials_alt:
+            trials = dict(default=trials, alt_variant=trials_alt)
     dec.close()
     if rank != 0:
         return None
