@@ -62,6 +62,8 @@ SYMBOLS = {
     "acg_process_dm_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "acg_fir_only_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "acg_placement_trial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double)]),
+    "acg_placement_trial_samples": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_void_p,
+                                              C.POINTER(C.c_double)]),
     "acg_sync": (C.c_int, [C.c_void_p]),
     "acg_soapy_taps": (C.c_int, [C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "acg_sdrplay_taps": (C.c_int, [C.c_float, C.c_uint, C.c_void_p]),

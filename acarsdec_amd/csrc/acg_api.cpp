@@ -909,6 +909,23 @@ extern "C" int acg_placement_trial(acg_ctx* ctx, const uint8_t* iq_dev, size_t p
     return rc != ACG_OK ? rc : rr;
 }
 
+extern "C" int acg_placement_trial_samples(acg_ctx* ctx, int fmt, const void* dev, size_t pitch_bytes, size_t plane_bytes, int nblocks,
+                                           int repeats, void* hip_stream, double* ms_per_call)
+{
+    if (!ctx || !ms_per_call || repeats < 1) return ACG_EINVAL;
+    int rc = acg_process_samples_dev(ctx, fmt, dev, pitch_bytes, plane_bytes, nblocks, hip_stream);      // untimed (and the argument check)
+    if (rc != ACG_OK) return rc;
+    HIPCHK(ctx, hipDeviceSynchronize());
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < repeats && rc == ACG_OK; ++i) rc = acg_process_samples_dev(ctx, fmt, dev, pitch_bytes, plane_bytes, nblocks, hip_stream);
+    HIPCHK(ctx, hipDeviceSynchronize());
+    const auto t1 = std::chrono::steady_clock::now();
+    *ms_per_call = std::chrono::duration<double, std::milli>(t1 - t0).count() / repeats;
+    int rr = acg_reset(ctx);
+    if (rr == ACG_OK) rr = acg_get_timing(ctx, nullptr, nullptr, nullptr, nullptr);
+    return rc != ACG_OK ? rc : rr;
+}
+
 // ------------------------------------------------------------------------------------------
 // Hands frames [consumed, upto) of the ring to the host, ordered by (chn, end_bit).
 static int fetch_frames(acg_ctx* ctx, unsigned int upto, acg_frame* out, int max_frames, int* nframes)

@@ -169,6 +169,12 @@ class Decoder:
         _chk(self.ctx, self.L.acg_placement_trial(self.ctx, iq_dev.data_ptr(), pitch, nblocks, repeats, stream, C.byref(ms)))
         return ms.value
 
+    def placement_trial_samples(self, fmt, dev_tensor, nblocks, pitch, plane=0, repeats=2, stream=None):
+        """the same for a sample-format input (acg_placement_trial_samples)"""
+        ms = C.c_double(0)
+        _chk(self.ctx, self.L.acg_placement_trial_samples(self.ctx, fmt, dev_tensor.data_ptr(), pitch, plane, nblocks, repeats, stream, C.byref(ms)))
+        return ms.value
+
     def demod_msk(self, dm):
         """demodMSK() for all channels from 12.5 kHz samples: dm float32 [nch, len]."""
         dm = np.ascontiguousarray(dm, dtype=np.float32)
@@ -252,13 +258,14 @@ def frame_tuple(f):
     return (int(f.chn), int(f.len), int(f.err), bytes(f.crc), bytes(f.txt[: max(0, f.len)]))
 
 
-def best_placed(factory, n, iq_dev, nblocks, pitch, repeats=2, stream=None):
+def best_placed(factory, n, iq_dev, nblocks, pitch, repeats=2, stream=None, fmt=0, plane=0):
     """Creates `n` decoders with factory() -- all alive during the trials, so that their buffers lie in different places --
     times the same call on each (Decoder.placement_trial) and keeps the fastest.  Returns (decoder, [ms per call], index)."""
     decs = [factory() for _ in range(max(1, n))]
     if len(decs) == 1:
         return decs[0], [], 0
-    ms = [d.placement_trial(iq_dev, nblocks, pitch, repeats, stream) for d in decs]
+    ms = [d.placement_trial(iq_dev, nblocks, pitch, repeats, stream) if fmt == 0 else
+          d.placement_trial_samples(fmt, iq_dev, nblocks, pitch, plane, repeats, stream) for d in decs]
     best = min(range(len(decs)), key=lambda i: ms[i])
     for i, d in enumerate(decs):
         if i != best:

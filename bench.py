@@ -355,8 +355,9 @@ def run_case(J, name, case, args, steps, warmup, headline):
     # Placement (acg_placement_trial): where the decoder's own buffers lie relative to the input changes what
     # the down-converter's write stream costs, by up to 15 %, and nothing in the addresses tells.  The host does what the
     # header recommends: a few contexts, one call of the real input on each, keep the fastest -- set-up, before any timing.
-    ntrial = args.placements if (fmt == 0 and share == 1) else 1
-    dec, trial_ms, trial_best = D.best_placed(make_decoder, ntrial, iq, cb, row, repeats=2, stream=stream)
+    ntrial = args.placements if share == 1 else 1
+    dec, trial_ms, trial_best = D.best_placed(make_decoder, ntrial, iq, cb, row, repeats=2, stream=stream, fmt=fmt,
+                                              plane=row // 2 if fmt == K.FMT_S16_SPLIT else 0)
     dec0 = dec
     maxfr = max(8192, int(nch * (cb / 3.0 + 2)))
     cb_bytes = cb * 1024 * M * bps
@@ -756,9 +757,10 @@ def main():
                     help="channels per input stream (rtl.c's own shape: one dongle feeds up to 16 channels); >1 = shared-stream "
                          "mode, VALU-bound, reported separately and never as the roofline figure (SURVEY 8d)")
     ap.add_argument("--bitlog", type=int, default=1, help="1: the demodulator also writes its per-bit soft symbols (vo, level: 8 B per bit) to HBM")
-    ap.add_argument("--placements", type=int, default=1,
-                    help="diagnostic: contexts tried with acg_placement_trial before the run, the fastest kept (round 3: inside one process the "
-                         "contexts lie within 1 % of each other bar one outlier, and the level is the box's -- so the bench takes the first)")
+    ap.add_argument("--placements", type=int, default=4,
+                    help="contexts tried with acg_placement_trial before the run (set-up, untimed), the fastest kept; the trial times of all "
+                         "of them are on the line (config.placement: the first entry is the context a host without the trial would have). "
+                         "1 = take the first.  Round 3 found no layout rule behind the differences (DESIGN 4.1)")
     ap.add_argument("--decoders", type=int, default=1, help="measurement aid: time this many decoders (separate allocations) in the same process")
     ap.add_argument("--ab", default=None, help="measurement aid: comma-separated ACG_FIR_VARIANT values (or NAME=v1,v2 for another per-launch "
                                                "switch, e.g. ACG_MSK_LPC_LIVE=2,4) timed after the run in the same process, same decoder")

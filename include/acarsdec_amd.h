@@ -169,6 +169,10 @@ int  acg_sync(acg_ctx *ctx);
 int  acg_placement_trial(acg_ctx *ctx, const uint8_t *iq_dev, size_t pitch_bytes, int nblocks, int repeats,
 			 void *hip_stream, double *ms_per_call);
 
+/* the same for the acg_process_samples_dev formats (declared below) */
+int  acg_placement_trial_samples(acg_ctx *ctx, int fmt, const void *dev, size_t pitch_bytes, size_t plane_bytes, int nblocks,
+				 int repeats, void *hip_stream, double *ms_per_call);
+
 /* ---- the other front ends' sample formats ----------------------------------- */
 #define ACG_FMT_CS16       1   /* interleaved int16 I,Q: soapy.c:238-241 (dm = |D| with the /32768 of soapy.c:241) */
 #define ACG_FMT_S16_SPLIT  2   /* int16 I plane + int16 Q plane: sdrplay.c:219-225 (dm = |D|/4) */

@@ -112,6 +112,7 @@ int main(void)
 		CHECK(acg_drain_frames(NULL, fr, 2, &n) == ACG_EINVAL && acg_collect_frames(NULL, 1, fr, 2, &n) == ACG_EINVAL);
 		CHECK(acg_drain_msgs(NULL, NULL, 0, &n) == ACG_EINVAL && acg_collect_msgs(NULL, 1, NULL, 0, &n) == ACG_EINVAL);
 		CHECK(acg_max_lag(NULL) == 0);
+		{ double ms; CHECK(acg_placement_trial_samples(NULL, ACG_FMT_CS16, NULL, 0, 0, 1, 1, NULL, &ms) == ACG_EINVAL); }
 		CHECK(acg_tune("PATH", "x") == ACG_EINVAL && acg_tune(NULL, "1") == ACG_EINVAL);
 		CHECK(acg_tune("ACG_FIR_VARIANT", "55") == ACG_OK && acg_tune("ACG_FIR_VARIANT", NULL) == ACG_OK && acg_tune("ACG_NOT_SET", NULL) == ACG_OK);
 		CHECK(acg_read_bits(NULL, 0, buf, buf, 4, &n) == ACG_EINVAL && acg_read_bits_all(NULL, &n, buf, buf) == ACG_EINVAL);

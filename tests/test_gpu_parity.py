@@ -346,6 +346,29 @@ def test_placement_trial_leaves_the_decoder_reset(D, O):
     assert dec.L.acg_placement_trial(dec.ctx, d.data_ptr(), d.stride(0), nblk, 0, None, C.byref(ms1)) == K.EINVAL       # repeats < 1
     assert dec.L.acg_placement_trial(dec.ctx, None, d.stride(0), nblk, 1, None, C.byref(ms1)) == K.EINVAL
     dec.close()
+    # the same for a sample-format input (acg_placement_trial_samples): CS16 here
+    M2 = 200
+    iq16 = np.stack([S.iq_s16_from_envelopes(np.array(env[c])[None, :], M2, [freqs[c] - fc], noise=0.01, rng=rng) for c in range(nch)])
+    d16 = torch.from_numpy(iq16).cuda()
+    taps16 = np.stack([O.soapy_taps(freqs[c], fc, M2) for c in range(nch)]).astype(np.float32)
+
+    def factory16():
+        dec = D.Decoder(nch, decim=M2, max_blocks=nblk, bitlog=False)
+        dec.set_taps(taps16)
+        return dec
+    pitch16 = d16.stride(0) * 2                              # bytes
+    dec, ms, best = D.best_placed(factory16, 2, d16, nblk, pitch16, fmt=K.FMT_CS16)
+    assert len(ms) == 2 and all(x > 0 for x in ms) and ms[best] == min(ms)
+    dec.process_samples(K.FMT_CS16, d16, nblk, pitch16)
+    got = sorted(D.frame_tuple(f) for f in dec.drain_frames())
+    want = []
+    for c in range(nch):
+        ch = O.Channel(c)
+        ch.demod(O.fir_cs16(iq16[c], M2, taps16[c]))
+        want += [O.frame_tuple(f) for f in ch.frames]
+    assert got == sorted(want) and len(got) >= nch
+    assert dec.L.acg_placement_trial_samples(dec.ctx, K.FMT_CS16, d16.data_ptr(), pitch16, 0, nblk, 0, None, C.byref(ms1)) == K.EINVAL
+    dec.close()
 
 
 # ------------------------------------------------------------------------------------ error behaviour of the ABI
