@@ -185,6 +185,7 @@ struct acg_ctx {
     std::vector<EvPair> fir_ev, msk_ev;
     std::vector<hipEvent_t> ev_pool;
     // ACG_ARENA=1 (measurement switch): every device buffer of acg_create carved out of ONE allocation, 2 MiB aligned
+    std::vector<hipStream_t> dummy_streams;
     char* arena = nullptr;
     size_t arena_cap = 0, arena_off = 0;
 };
@@ -274,6 +275,7 @@ static void free_all(acg_ctx* c)
     if (c->in_ev) hipEventDestroy(c->in_ev);
     if (c->fir_in) hipEventDestroy(c->fir_in);
     if (c->fir_out) hipEventDestroy(c->fir_out);
+    for (auto ds : c->dummy_streams) hipStreamDestroy(ds);
     if (c->fir_stream) hipStreamDestroy(c->fir_stream);
     if (c->msk_stream) hipStreamDestroy(c->msk_stream);
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
@@ -406,7 +408,12 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
                 // a stream of its own priority class gets a hardware queue of its own
                 int lo = 0, hi = 0;
                 HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
-                HIPCHK(c, hipStreamCreateWithPriority(&c->msk_stream, hipStreamNonBlocking, hi));
+                for (int k = acg_tune_get("ACG_MSK_STREAM_SKIP", 0); k > 0; --k) {      // (experiment: which hardware queue the stream lands on)
+                    hipStream_t dummy = nullptr;
+                    HIPCHK(c, hipStreamCreateWithPriority(&dummy, hipStreamNonBlocking, hi));
+                    c->dummy_streams.push_back(dummy);
+                }
+                HIPCHK(c, hipStreamCreateWithPriority(&c->msk_stream, hipStreamNonBlocking, acg_tune_get("ACG_MSK_STREAM_PRIO_NORMAL", 0) ? lo : hi));
             }
         }
         HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));

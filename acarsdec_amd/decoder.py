@@ -264,8 +264,12 @@ def best_placed(factory, n, iq_dev, nblocks, pitch, repeats=2, stream=None, fmt=
     decs = [factory() for _ in range(max(1, n))]
     if len(decs) == 1:
         return decs[0], [], 0
-    ms = [d.placement_trial(iq_dev, nblocks, pitch, repeats, stream) if fmt == 0 else
-          d.placement_trial_samples(fmt, iq_dev, nblocks, pitch, plane, repeats, stream) for d in decs]
+    def trial(d):
+        return (d.placement_trial(iq_dev, nblocks, pitch, repeats, stream) if fmt == 0 else
+                d.placement_trial_samples(fmt, iq_dev, nblocks, pitch, plane, repeats, stream))
+    for d in decs:                      # a round for nothing: the first context timed is otherwise timed on a cold device (clocks,
+        trial(d)                        # first touch of its buffers) and loses by 10-15 % to that alone (round 3, queue_probe.sh)
+    ms = [trial(d) for d in decs]
     best = min(range(len(decs)), key=lambda i: ms[i])
     for i, d in enumerate(decs):
         if i != best:
