@@ -77,6 +77,7 @@ class Decoder:
         rc = self.L.acg_create(C.byref(self.ctx), C.byref(cfg))
         if rc != K.OK:
             raise K.AcgError(rc, "acg_create")
+        self.timing_flag = bool(timing)
         self.bit_cap = self.L.acg_bit_capacity(self.ctx)
         self.max_lag = self.L.acg_max_lag(self.ctx)
         self.Fc = None
@@ -271,6 +272,23 @@ def best_placed(factory, n, iq_dev, nblocks, pitch, repeats=2, stream=None, fmt=
         trial(d)                        # first touch of its buffers) and loses by 10-15 % to that alone (round 3, queue_probe.sh)
     ms = [trial(d) for d in decs]
     best = min(range(len(decs)), key=lambda i: ms[i])
+    # Where the call is set by the demodulator (few channels: CU partition) the whole-call time says nothing about the
+    # down-converter, which is what differs between contexts: rank those by the down-converter's own (event-timed) launches.
+    if fmt == 0 and max(ms) <= 1.03 * min(ms) and all(getattr(d, "timing_flag", False) for d in decs):
+        fir = []
+        for d in decs:
+            d.set_timing(2)
+            d.timing()
+            for _ in range(3):
+                d.in_callback(iq_dev, nblocks=nblocks, pitch=pitch, stream=stream)
+            t = d.timing()
+            fir.append(t["fir_ms"] / max(1, t["fir_launches"]))
+            d.reset()
+            d.set_timing(1)
+        best = min(range(len(decs)), key=lambda i: fir[i])
+        best_placed.last_fir_ms = fir
+    else:
+        best_placed.last_fir_ms = None
     for i, d in enumerate(decs):
         if i != best:
             d.close()
