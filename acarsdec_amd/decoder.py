@@ -274,7 +274,7 @@ def best_placed(factory, n, iq_dev, nblocks, pitch, repeats=2, stream=None, fmt=
     best = min(range(len(decs)), key=lambda i: ms[i])
     # Where the call is set by the demodulator (few channels: CU partition) the whole-call time says nothing about the
     # down-converter, which is what differs between contexts: rank those by the down-converter's own (event-timed) launches.
-    if fmt == 0 and max(ms) <= 1.06 * min(ms) and all(getattr(d, "timing_flag", False) for d in decs):
+    if fmt == 0 and all(getattr(d, "timing_flag", False) and d.nch <= 2048 for d in decs):      # (<= 2048 channels: CU partition)
         fir = []
         for d in decs:
             d.set_timing(2)

@@ -698,8 +698,8 @@ def run_case(J, name, case, args, steps, warmup, headline):
                    "placement": ({"contexts_tried": len(trial_ms), "ms_per_call": [round(x, 3) for x in trial_ms], "kept": trial_best,
                                   "fir_ms_per_launch": ([round(x, 4) for x in D.best_placed.last_fir_ms] if getattr(D.best_placed, "last_fir_ms", None) else None),
                                   "note": "set-up, untimed: acg_placement_trial on each context (after a warm-up round) with the first call of the batch, the fastest "
-                                          "kept; where the calls are within 6 % of each other (the demodulator sets them) the contexts are ranked by "
-                                          "their down-converter launches instead (fir_ms_per_launch)"}
+                                          "kept; up to 2048 channels (CU partition: the demodulator sets the call) the contexts are ranked by their "
+                                          "down-converter launches instead (fir_ms_per_launch)"}
                                  if trial_ms else None)},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
