@@ -261,7 +261,8 @@ def frame_tuple(f):
 
 def best_placed(factory, n, iq_dev, nblocks, pitch, repeats=2, stream=None, fmt=0, plane=0):
     """Creates `n` decoders with factory() -- all alive during the trials, so that their buffers lie in different places --
-    times the same call on each (Decoder.placement_trial) and keeps the fastest.  Returns (decoder, [ms per call], index)."""
+    runs the same call on each once for nothing, then times it (Decoder.placement_trial) and keeps the fastest.  Returns
+    (decoder, [ms per call], index); best_placed.last_fir_ms holds the down-converter tie-break figures where it was used."""
     decs = [factory() for _ in range(max(1, n))]
     if len(decs) == 1:
         return decs[0], [], 0
@@ -272,9 +273,11 @@ def best_placed(factory, n, iq_dev, nblocks, pitch, repeats=2, stream=None, fmt=
         trial(d)                        # first touch of its buffers) and loses by 10-15 % to that alone (round 3, queue_probe.sh)
     ms = [trial(d) for d in decs]
     best = min(range(len(decs)), key=lambda i: ms[i])
-    # Where the call is set by the demodulator (few channels: CU partition) the whole-call time says nothing about the
-    # down-converter, which is what differs between contexts: rank those by the down-converter's own (event-timed) launches.
-    if fmt == 0 and all(getattr(d, "timing_flag", False) and d.nch <= 2048 for d in decs):      # (<= 2048 channels: CU partition)
+    # Up to 2048 channels (CU partition) the demodulator sets the call, so the calls of all contexts are nearly alike while their
+    # down-converters differ by a few per cent: among the contexts within 1 % of the fastest call keep the one whose
+    # down-converter launches (event-timed) are the shortest.
+    best_placed.last_fir_ms = None
+    if fmt == 0 and all(getattr(d, "timing_flag", False) and d.nch <= 2048 for d in decs):
         fir = []
         for d in decs:
             d.set_timing(2)
@@ -285,10 +288,9 @@ def best_placed(factory, n, iq_dev, nblocks, pitch, repeats=2, stream=None, fmt=
             fir.append(t["fir_ms"] / max(1, t["fir_launches"]))
             d.reset()
             d.set_timing(1)
-        best = min(range(len(decs)), key=lambda i: fir[i])
+        near = [i for i in range(len(decs)) if ms[i] <= 1.01 * min(ms)]
+        best = min(near, key=lambda i: fir[i])
         best_placed.last_fir_ms = fir
-    else:
-        best_placed.last_fir_ms = None
     for i, d in enumerate(decs):
         if i != best:
             d.close()

@@ -356,7 +356,7 @@ def run_case(J, name, case, args, steps, warmup, headline):
     # the down-converter's write stream costs, by up to 15 %, and nothing in the addresses tells.  The host does what the
     # header recommends: a few contexts, one call of the real input on each, keep the fastest -- set-up, before any timing.
     ntrial = args.placements if share == 1 else 1
-    dec, trial_ms, trial_best = D.best_placed(make_decoder, ntrial, iq, cb, row, repeats=2, stream=stream, fmt=fmt,
+    dec, trial_ms, trial_best = D.best_placed(make_decoder, ntrial, iq, cb, row, repeats=2 if nch > 2048 else 12, stream=stream, fmt=fmt,
                                               plane=row // 2 if fmt == K.FMT_S16_SPLIT else 0)
     dec0 = dec
     maxfr = max(8192, int(nch * (cb / 3.0 + 2)))
@@ -698,8 +698,8 @@ def run_case(J, name, case, args, steps, warmup, headline):
                    "placement": ({"contexts_tried": len(trial_ms), "ms_per_call": [round(x, 3) for x in trial_ms], "kept": trial_best,
                                   "fir_ms_per_launch": ([round(x, 4) for x in D.best_placed.last_fir_ms] if getattr(D.best_placed, "last_fir_ms", None) else None),
                                   "note": "set-up, untimed: acg_placement_trial on each context (after a warm-up round) with the first call of the batch, the fastest "
-                                          "kept; up to 2048 channels (CU partition: the demodulator sets the call) the contexts are ranked by their "
-                                          "down-converter launches instead (fir_ms_per_launch)"}
+                                          "kept; up to 2048 channels (CU partition: the demodulator sets the call) the contexts within 1 % of the "
+                                          "fastest call are ranked by their down-converter launches (fir_ms_per_launch)"}
                                  if trial_ms else None)},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
