@@ -387,6 +387,11 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
     int rc = ACG_OK;
     auto body = [&]() -> int {
         HIPCHK(c, hipSetDevice(cfg->device));
+        for (int k = acg_tune_get("ACG_STREAM_SKIP_NORMAL", 0); k > 0; --k) {      // (experiment: which hardware queue c->stream lands on)
+            hipStream_t dummy = nullptr;
+            HIPCHK(c, hipStreamCreateWithFlags(&dummy, hipStreamNonBlocking));
+            c->dummy_streams.push_back(dummy);
+        }
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         {
             // CU partition (ACG_MSK_CUS=n): the demodulator's few long-lived waves get n CUs of their own
