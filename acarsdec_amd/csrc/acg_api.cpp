@@ -184,10 +184,6 @@ struct acg_ctx {
 
     std::vector<EvPair> fir_ev, msk_ev;
     std::vector<hipEvent_t> ev_pool;
-    // ACG_ARENA=1 (measurement switch): every device buffer of acg_create carved out of ONE allocation, 2 MiB aligned
-    std::vector<hipStream_t> dummy_streams;
-    char* arena = nullptr;
-    size_t arena_cap = 0, arena_off = 0;
 };
 
 #define HIPCHK(ctx, call)                                                                  \
@@ -198,23 +194,6 @@ struct acg_ctx {
             return ACG_EHIP;                                                               \
         }                                                                                  \
     } while (0)
-
-static bool in_arena(const acg_ctx* c, const void* p)
-{
-    return c->arena && (const char*)p >= c->arena && (const char*)p < c->arena + c->arena_cap;
-}
-static void dev_free(acg_ctx* c, void* p) { if (p && !in_arena(c, p)) hipFree(p); }
-template <typename T>
-static hipError_t dev_alloc(acg_ctx* c, T** p, size_t bytes)
-{
-    if (!c->arena) return hipMalloc((void**)p, bytes);
-    const size_t al = (size_t)2 << 20;
-    const size_t a = (c->arena_off + al - 1) & ~(al - 1);
-    if (a + bytes > c->arena_cap) return hipErrorOutOfMemory;
-    *p = (T*)(c->arena + a);
-    c->arena_off = a + bytes;
-    return hipSuccess;
-}
 
 static int fail(acg_ctx* ctx, int code, const char* msg)
 {
@@ -258,12 +237,11 @@ extern "C" int acg_device_count(void)
 static void free_all(acg_ctx* c)
 {
     if (!c) return;
-    dev_free(c, c->d_taps); dev_free(c, c->d_stream_of); dev_free(c, c->d_groups); dev_free(c, c->d_group_ch); dev_free(c, c->d_gtaps); dev_free(c, c->d_dm_all); dev_free(c, c->d_st);
-    dev_free(c, c->d_h); dev_free(c, c->d_sctab); dev_free(c, c->d_txt); dev_free(c, c->d_frames); dev_free(c, c->d_frame_count);
-    dev_free(c, c->d_stamp);
-    dev_free(c, c->d_msgs); std::free(c->h_msgs);
-    dev_free(c, c->d_bits); dev_free(c, c->d_nbits); dev_free(c, c->d_stage); dev_free(c, c->d_work); dev_free(c, c->d_msk_done); std::free(c->h_stage); dev_free(c, c->d_crctab); dev_free(c, c->d_rep_upto);
-    if (c->arena) hipFree(c->arena);
+    hipFree(c->d_taps); hipFree(c->d_stream_of); hipFree(c->d_groups); hipFree(c->d_group_ch); hipFree(c->d_gtaps); hipFree(c->d_dm_all); hipFree(c->d_st);
+    hipFree(c->d_h); hipFree(c->d_sctab); hipFree(c->d_txt); hipFree(c->d_frames); hipFree(c->d_frame_count);
+    hipFree(c->d_stamp);
+    hipFree(c->d_msgs); std::free(c->h_msgs);
+    hipFree(c->d_bits); hipFree(c->d_nbits); hipFree(c->d_stage); hipFree(c->d_work); hipFree(c->d_msk_done); std::free(c->h_stage); hipFree(c->d_crctab); hipFree(c->d_rep_upto);
     for (auto& p : c->fir_ev) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto& p : c->msk_ev) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : c->ev_pool) hipEventDestroy(e);
@@ -275,7 +253,6 @@ static void free_all(acg_ctx* c)
     if (c->in_ev) hipEventDestroy(c->in_ev);
     if (c->fir_in) hipEventDestroy(c->fir_in);
     if (c->fir_out) hipEventDestroy(c->fir_out);
-    for (auto ds : c->dummy_streams) hipStreamDestroy(ds);
     if (c->fir_stream) hipStreamDestroy(c->fir_stream);
     if (c->msk_stream) hipStreamDestroy(c->msk_stream);
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
@@ -340,7 +317,6 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
     c->ntaps_pad = c->tile_path ? ((cfg->ntaps + 7) & ~7) : cfg->ntaps;
     c->max_len = cfg->max_blocks * ACG_BLOCK;
     c->dm_pitch = ((size_t)c->max_len + 63) & ~(size_t)63;
-    c->dm_pitch += (size_t)(std::max(0, acg_tune_get("ACG_DM_PAD", 0)) & ~63);      // (experiment) rows staggered against each other
     c->bit_cap = c->max_len / 4 + 8;
     // shortest possible block: SYN SYN SOH ETX CRC CRC + END byte = 56 bits ~ 291 samples.  The ring holds the worst case of
     // lag_max + 1 calls (a collect that stays `lag` calls behind leaves lag + 1 calls' blocks in it), so a host that
@@ -387,11 +363,6 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
     int rc = ACG_OK;
     auto body = [&]() -> int {
         HIPCHK(c, hipSetDevice(cfg->device));
-        for (int k = acg_tune_get("ACG_STREAM_SKIP_NORMAL", 0); k > 0; --k) {      // (experiment: which hardware queue c->stream lands on)
-            hipStream_t dummy = nullptr;
-            HIPCHK(c, hipStreamCreateWithFlags(&dummy, hipStreamNonBlocking));
-            c->dummy_streams.push_back(dummy);
-        }
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         {
             // CU partition (ACG_MSK_CUS=n): the demodulator's few long-lived waves get n CUs of their own
@@ -413,12 +384,7 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
                 // a stream of its own priority class gets a hardware queue of its own
                 int lo = 0, hi = 0;
                 HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
-                for (int k = acg_tune_get("ACG_MSK_STREAM_SKIP", 0); k > 0; --k) {      // (experiment: which hardware queue the stream lands on)
-                    hipStream_t dummy = nullptr;
-                    HIPCHK(c, hipStreamCreateWithPriority(&dummy, hipStreamNonBlocking, hi));
-                    c->dummy_streams.push_back(dummy);
-                }
-                HIPCHK(c, hipStreamCreateWithPriority(&c->msk_stream, hipStreamNonBlocking, acg_tune_get("ACG_MSK_STREAM_PRIO_NORMAL", 0) ? lo : hi));
+                HIPCHK(c, hipStreamCreateWithPriority(&c->msk_stream, hipStreamNonBlocking, hi));
             }
         }
         HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
@@ -433,47 +399,38 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
         HIPCHK(c, hipHostMalloc((void**)&c->h_call_count, sizeof(unsigned int) * acg_ctx::NCALL, hipHostMallocDefault));
         std::memset(c->h_call_count, 0, sizeof(unsigned int) * acg_ctx::NCALL);
         HIPCHK(c, hipHostGetDevicePointer((void**)&c->d_call_count, c->h_call_count, 0));
-        if (acg_tune_get("ACG_ARENA", 0)) {
-            const size_t nch_ = (size_t)cfg->nch;
-            size_t need = nch_ * c->ntaps_pad * 2 * sizeof(float) * 2 + 2 * nch_ * c->dm_pitch * sizeof(float) + nch_ * (sizeof(AcgChan) + 256 + 64) +
-                          (size_t)c->frame_cap * sizeof(AcgFrameRec) + ((cfg->flags & ACG_F_BITLOG) ? nch_ * (size_t)c->bit_cap * sizeof(float2) : 0) +
-                          sizeof(unsigned int) * ACG_DISP_WORDS * (size_t)(cfg->max_blocks + 1) + (nch_ + 64) * 80;
-            need += (size_t)32 * ((size_t)2 << 20);                  // alignment slack for ~20 sub-blocks
-            HIPCHK(c, hipMalloc((void**)&c->arena, need));
-            c->arena_cap = need;
-        }
-        HIPCHK(c, dev_alloc(c, &c->d_msk_done, sizeof(unsigned int)));
+        HIPCHK(c, hipMalloc(&c->d_msk_done, sizeof(unsigned int)));
         HIPCHK(c, hipMemset(c->d_msk_done, 0, sizeof(unsigned int)));
         const size_t nch = (size_t)cfg->nch;
-        HIPCHK(c, dev_alloc(c, &c->d_taps, nch * c->ntaps_pad * 2 * sizeof(float)));
+        HIPCHK(c, hipMalloc(&c->d_taps, nch * c->ntaps_pad * 2 * sizeof(float)));
         HIPCHK(c, hipMemset(c->d_taps, 0, nch * c->ntaps_pad * 2 * sizeof(float)));
-        HIPCHK(c, dev_alloc(c, &c->d_stream_of, nch * sizeof(int)));
-        HIPCHK(c, dev_alloc(c, &c->d_dm_all, 2 * nch * c->dm_pitch * sizeof(float)));
+        HIPCHK(c, hipMalloc(&c->d_stream_of, nch * sizeof(int)));
+        HIPCHK(c, hipMalloc(&c->d_dm_all, 2 * nch * c->dm_pitch * sizeof(float)));
         c->d_dm = c->d_dm_all;
-        HIPCHK(c, dev_alloc(c, &c->d_st, nch * sizeof(AcgChan)));
-        HIPCHK(c, dev_alloc(c, &c->d_h, 136 * sizeof(float)));
-        HIPCHK(c, dev_alloc(c, &c->d_txt, nch * 256));
+        HIPCHK(c, hipMalloc(&c->d_st, nch * sizeof(AcgChan)));
+        HIPCHK(c, hipMalloc(&c->d_h, 136 * sizeof(float)));
+        HIPCHK(c, hipMalloc(&c->d_txt, nch * 256));
         HIPCHK(c, hipMemset(c->d_txt, 0, nch * 256));
-        HIPCHK(c, dev_alloc(c, &c->d_frames, (size_t)c->frame_cap * sizeof(AcgFrameRec)));
-        HIPCHK(c, dev_alloc(c, &c->d_frame_count, sizeof(unsigned int)));
+        HIPCHK(c, hipMalloc(&c->d_frames, (size_t)c->frame_cap * sizeof(AcgFrameRec)));
+        HIPCHK(c, hipMalloc(&c->d_frame_count, sizeof(unsigned int)));
         HIPCHK(c, hipMemset(c->d_frame_count, 0, sizeof(unsigned int)));
         if (cfg->flags & ACG_F_BITLOG)
-            HIPCHK(c, dev_alloc(c, &c->d_bits, nch * (size_t)c->bit_cap * sizeof(float2)));
-        HIPCHK(c, dev_alloc(c, &c->d_nbits, nch * sizeof(int)));
+            HIPCHK(c, hipMalloc(&c->d_bits, nch * (size_t)c->bit_cap * sizeof(float2)));
+        HIPCHK(c, hipMalloc(&c->d_nbits, nch * sizeof(int)));
 #ifdef ACG_MSK_STAMP
-        HIPCHK(c, dev_alloc(c, &c->d_stamp, (nch + 64) * 10 * sizeof(unsigned long long)));      // <= one wave per channel
+        HIPCHK(c, hipMalloc(&c->d_stamp, (nch + 64) * 10 * sizeof(unsigned long long)));      // <= one wave per channel
         HIPCHK(c, hipMemset(c->d_stamp, 0, (nch + 64) * 10 * sizeof(unsigned long long)));
 #endif
-        HIPCHK(c, dev_alloc(c, &c->d_work, sizeof(unsigned int) * ACG_DISP_WORDS * (size_t)(cfg->max_blocks + 1)));
+        HIPCHK(c, hipMalloc(&c->d_work, sizeof(unsigned int) * ACG_DISP_WORDS * (size_t)(cfg->max_blocks + 1)));
         HIPCHK(c, hipMemset(c->d_work, 0, sizeof(unsigned int) * ACG_DISP_WORDS * (size_t)(cfg->max_blocks + 1)));   // dispensers re-arm themselves
         HIPCHK(c, hipMemset(c->d_nbits, 0, nch * sizeof(int)));
 
         if (cfg->flags & ACG_F_REPAIR) {
             std::vector<unsigned short> tabs(256 + 8 * 243);          // one row beyond the reference's table, see host_setup.c
             acg_host_crc_tables_n(tabs.data(), tabs.data() + 256, 243);
-            HIPCHK(c, dev_alloc(c, &c->d_crctab, tabs.size() * sizeof(unsigned short)));
+            HIPCHK(c, hipMalloc(&c->d_crctab, tabs.size() * sizeof(unsigned short)));
             HIPCHK(c, hipMemcpy(c->d_crctab, tabs.data(), tabs.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
-            HIPCHK(c, dev_alloc(c, &c->d_rep_upto, sizeof(unsigned int)));
+            HIPCHK(c, hipMalloc(&c->d_rep_upto, sizeof(unsigned int)));
             HIPCHK(c, hipMemset(c->d_rep_upto, 0, sizeof(unsigned int)));
         }
         float h[136] = {0};
@@ -481,11 +438,11 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
         HIPCHK(c, hipMemcpy(c->d_h, h, sizeof(h), hipMemcpyHostToDevice));
         double sct[2 * ACG_SINCOS_N];
         acg_host_sincos_table(sct);                      // the mixer's cexp(-p*I), msk.c:86-91
-        HIPCHK(c, dev_alloc(c, &c->d_sctab, sizeof(sct)));
+        HIPCHK(c, hipMalloc(&c->d_sctab, sizeof(sct)));
         HIPCHK(c, hipMemcpy(c->d_sctab, sct, sizeof(sct), hipMemcpyHostToDevice));
-        HIPCHK(c, dev_alloc(c, &c->d_groups, nch * sizeof(int4)));
-        HIPCHK(c, dev_alloc(c, &c->d_group_ch, nch * sizeof(int)));
-        HIPCHK(c, dev_alloc(c, &c->d_gtaps, nch * (size_t)c->ntaps_pad * 2 * sizeof(float)));
+        HIPCHK(c, hipMalloc(&c->d_groups, nch * sizeof(int4)));
+        HIPCHK(c, hipMalloc(&c->d_group_ch, nch * sizeof(int)));
+        HIPCHK(c, hipMalloc(&c->d_gtaps, nch * (size_t)c->ntaps_pad * 2 * sizeof(float)));
         if (acg_tune_has("ACG_DEBUG_ADDR"))                    // placement probes (profiles/probe/placement_probe.py)
             fprintf(stderr, "acg_create: taps %p (%zu B)  dm %p (%zu B)  st %p  work %p  stream_of %p  txt %p\n", (void*)c->d_taps,
                     nch * c->ntaps_pad * 2 * sizeof(float), (void*)c->d_dm_all, 2 * nch * c->dm_pitch * sizeof(float), (void*)c->d_st,
