@@ -39,13 +39,19 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def build_lib(force=False, stamp=False):
+LIB_POLY = os.path.join(LIBDIR, "libacarsdec_amd_poly.so")
+
+
+def build_lib(force=False, stamp=False, poly=False):
     """stamp=True: the measurement build (lib/libacarsdec_amd_stamp.so, -DACG_MSK_STAMP: s_memtime stamps in the
-    demodulator's per-bit loop, read by profiles/probe/msk_phase_stamps.py); never loaded by the product."""
+    demodulator's per-bit loop, read by profiles/probe/msk_phase_stamps.py); never loaded by the product.
+    poly=True: the checking build (lib/libacarsdec_amd_poly.so, -DACG_MSK_SINCOS_POLY: the mixer's sin/cos as the < 1 ulp
+    Cody-Waite + fdlibm-kernel evaluation instead of table + rotation); a GPU test runs it beside the product build and
+    wants identical bits and state (tests/test_gpu_parity.py); never loaded by the product either."""
     os.makedirs(OBJDIR, exist_ok=True)
-    tag = "_stamp" if stamp else ""
-    extra = ["-DACG_MSK_STAMP"] if stamp else []
-    out_lib = LIB_STAMP if stamp else LIB
+    tag = "_stamp" if stamp else "_poly" if poly else ""
+    extra = ["-DACG_MSK_STAMP"] if stamp else ["-DACG_MSK_SINCOS_POLY"] if poly else []
+    out_lib = LIB_STAMP if stamp else LIB_POLY if poly else LIB
     hdrs = [os.path.join(CSRC, "acg_internal.h"), os.path.join(CSRC, "msk_common.h"), os.path.join(INC, "acarsdec_amd.h"),
             os.path.abspath(__file__)]   # flags live here
     units = [
@@ -69,6 +75,9 @@ def build_lib(force=False, stamp=False):
     hc = hipcc()
     for name, flags in units:
         src = os.path.join(CSRC, name)
+        if poly and name not in ("msk.hip", "msk2.hip"):
+            objs.append(os.path.join(OBJDIR, name + ".o"))
+            continue
         if stamp and name not in ("msk.hip", "msk2.hip", "acg_api.cpp"):
             objs.append(os.path.join(OBJDIR, name + ".o"))          # unchanged units are shared with the product build
             continue
@@ -122,6 +131,7 @@ def build_demo_rtl(force=False):
 
 def build_all(force=False):
     lib = build_lib(force)
+    build_lib(force, poly=True)
     demo = build_demo(force)
     build_demo_rtl(force)
     return lib, demo

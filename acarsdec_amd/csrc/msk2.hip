@@ -30,6 +30,13 @@
 #include "acg_internal.h"
 #include "msk_common.h"
 
+// the mixer's sin/cos: table + rotation, or (checking build, -DACG_MSK_SINCOS_POLY) the < 1 ulp polynomial version -- as in msk.hip
+#ifdef ACG_MSK_SINCOS_POLY
+#define MIXER_SINCOS(x, tab, sn, cs) sincos_2pi((x), (sn), (cs))
+#else
+#define MIXER_SINCOS(x, tab, sn, cs) sincos_tab((x), (tab), (sn), (cs))
+#endif
+
 namespace {
 
 constexpr int LPC = 8;                         // lanes per channel
@@ -231,7 +238,7 @@ __global__ __launch_bounds__(128 * PAIRS) void msk_demod2_kernel(const MskArgs a
                 if (u == 5) p6 = q;
             }
             double sn, cs;
-            sincos_tab(myp, lds.sc, &sn, &cs);
+            MIXER_SINCOS(myp, lds.sc, &sn, &cs);
             const double ind = (double)in;
             float2 x = make_float2((float)(ind * cs), (float)(ind * (-sn)));                    // msk.c:90
             // (the mixer output exists BEFORE the barrier: this interval is where wave H computes the clock steps and the tap
@@ -310,7 +317,7 @@ __global__ __launch_bounds__(128 * PAIRS) void msk_demod2_kernel(const MskArgs a
                 const double s = K_VCO + L.df;
                 p = wrap_2pi(p + s);                                       // msk.c:82-83
                 double sn, cs;
-                sincos_tab(p, lds.sc, &sn, &cs);
+                MIXER_SINCOS(p, lds.sc, &sn, &cs);
                 const double ind = (double)in;
                 const float2 x = make_float2((float)(ind * cs), (float)(ind * (-sn)));
                 P.ring[idx][slot] = x;                                     // (all lanes of the group write the same value)

@@ -904,6 +904,68 @@ def test_msk_two_wave_kernel_is_bit_identical_to_the_one_wave_kernel(D, O, S, tu
             assert np.array_equal(np.asarray(v), np.asarray(two[1][c][k])), (c, k)
 
 
+SINCOS_AB_CHILD = r'''
+import sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+from acarsdec_amd import decoder as D, synth as S, _capi as K
+pcm = np.load(%(wav)r)["pcm"]
+x = (pcm.astype(np.float32) / np.float32(32768.0)).T.copy()            # [4, n] the golden recording's four channels
+rng = np.random.default_rng(5)
+noise = rng.normal(0.2, 0.1, (2, x.shape[1])).astype(np.float32)        # + two noise-only channels (resets, razor-edge decisions)
+x = np.concatenate([x, noise])
+n = (x.shape[1] // 4096) * 4096
+out = {}
+for split in ("0", "1"):
+    K.tune("ACG_MSK_SPLIT", split)
+    dec = D.Decoder(x.shape[0], decim=8, ntaps=8, max_blocks=4)
+    vo, lv, fr = [[] for _ in range(x.shape[0])], [[] for _ in range(x.shape[0])], []
+    for s in range(0, n, 4096):
+        dec.demod_msk(x[:, s:s + 4096])
+        fr += [D.frame_tuple(f) for f in dec.drain_frames()]
+        cnt, v, l = dec.bits_all()
+        for c in range(x.shape[0]):
+            vo[c].append(v[c, :cnt[c]].copy()); lv[c].append(l[c, :cnt[c]].copy())
+    for c in range(x.shape[0]):
+        out["vo%%s_%%d" %% (split, c)] = np.concatenate(vo[c]); out["lv%%s_%%d" %% (split, c)] = np.concatenate(lv[c])
+        st = dec.state(c)
+        out["st%%s_%%d" %% (split, c)] = np.array([st["MskPhi"], st["MskDf"], st["MskClk"], st["MskLvlSum"], st["MskS"], st["idx"]], dtype=np.float64)
+    out["fr%%s" %% split] = np.array([repr(sorted(fr))])
+    dec.close()
+np.savez(sys.argv[1], **out)
+print("OK")
+'''
+
+
+def test_table_sincos_build_and_polynomial_sincos_build_agree_bit_for_bit(tmp_path):
+    """ADVICE r02: the product's mixer evaluates sin/cos as a 128-entry table + rotation (<= 2.1 ulp); the checking build
+    (-DACG_MSK_SINCOS_POLY, lib/libacarsdec_amd_poly.so) as a < 1 ulp polynomial.  What the loop keeps are the float-rounded
+    products, and those are claimed identical (tests/sincos_model.c on the CPU).  Here on the GPU: the golden recording's four
+    channels plus two noise-only channels through BOTH builds, one-wave and two-wave kernels: every soft bit, every level, the
+    loop state and every block identical."""
+    from acarsdec_amd import _build
+    if not os.path.exists(_build.LIB_POLY):
+        pytest.skip("checking build not present (build() makes it)")
+    res = {}
+    for name, lib in (("table", _build.LIB), ("poly", _build.LIB_POLY)):
+        out = str(tmp_path / (name + ".npz"))
+        r = subprocess.run([sys.executable, "-c", SINCOS_AB_CHILD % dict(root=ROOT, wav=os.path.join(ROOT, "tests", "golden", "testwav_pcm16.npz")), out],
+                           capture_output=True, text=True, timeout=600, env=dict(os.environ, ACARSDEC_AMD_LIB=lib))
+        assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+        res[name] = np.load(out)
+    a, b = res["table"], res["poly"]
+    assert sorted(a.files) == sorted(b.files) and len(a.files) >= 2 * (3 * 6 + 1)
+    nbits = 0
+    for k in a.files:
+        if k.startswith("fr"):
+            assert a[k][0] == b[k][0] and len(a[k][0]) > 100, k
+        else:
+            assert a[k].shape == b[k].shape and np.array_equal(a[k].view(np.uint8), b[k].view(np.uint8)), k
+            nbits += a[k].size if k.startswith("vo") else 0
+    assert a["fr0"][0] == a["fr1"][0]
+    assert nbits > 2 * 6 * 9000
+
+
 def test_streaming_collect_equals_blocking_drain(D, O, S):
     """acg_collect_frames(lag=1) (one call in flight) delivers exactly the blocks of acg_drain_frames,
     in the same per-channel order, over many calls on the rtl path with the stream pipeline on."""
