@@ -115,6 +115,8 @@ CASES = {
     "stress": dict(tag="BASELINE configs[4]", channels=4096, decim=200, ntaps=192, blocks=32, content="random+acars"),
     # the soapy.c front end's sample format (interleaved int16 I/Q) through the same pipeline
     "cs16": dict(tag="soapy.c CS16 front end (SURVEY 8f.2)", channels=4096, decim=200, ntaps=200, blocks=16, content="format+acars", format="cs16"),
+    # ... and the air.c front end's (real float32 samples against complex taps)
+    "f32": dict(tag="air.c real-f32 front end (SURVEY 8f.2)", channels=4096, decim=200, ntaps=200, blocks=16, content="format+acars", format="f32"),
     # BASELINE.json configs[3] per-GPU share: 16384 channels over 8 GPUs
     "shard2048": dict(tag="BASELINE configs[3], per-GPU share", channels=2048, decim=200, ntaps=200, blocks=64, content="acars"),
 }
@@ -303,27 +305,37 @@ def run_case(J, name, case, args, steps, warmup, headline):
                      "the first %d channels (the ones the parity gate looks at) carry ACARS/MSK traffic as in the other cases, so "
                      "that the gate compares decoded blocks and not only magnitudes" % nacars)
     elif content == "format+acars":
-        assert fmt == K.FMT_CS16
-        assert L.acg_fill_random_u8_dev(iq.data_ptr(), row, nstreams, row, 0xACA25 + rank, None) == 0
-        iq.view(torch.int16).bitwise_and_(0x0FFF)
+        assert fmt in (K.FMT_CS16, K.FMT_F32_REAL)
+        if fmt == K.FMT_CS16:
+            assert L.acg_fill_random_u8_dev(iq.data_ptr(), row, nstreams, row, 0xACA25 + rank, None) == 0
+            iq.view(torch.int16).bitwise_and_(0x0FFF)
+        else:
+            iq.view(torch.float32).normal_(0.0, 0.1)
         nacars = min(nch, max(64, args.check_channels))
-        # the gate's channels: ACARS/MSK traffic as in the u8 cases, up-converted and quantised to int16 (rint(32767 * 0.9 x),
-        # acarsdec_amd/synth.py iq_s16_from_envelopes) with torch on the device, a few channels at a time
+        # the gate's channels: ACARS/MSK traffic as in the u8 cases, up-converted with torch on the device, a few channels at a time:
+        # CS16 = complex baseband quantised to int16 (rint(32767 * 0.9 x), synth.iq_s16_from_envelopes); real f32 = 2 x env x cos
+        # at the channel's offset from 0 Hz of the real spectrum (synth.real_f32_from_envelopes)
         tt = torch.arange(nout * M, dtype=torch.float64, device=dev) * (2.0 * np.pi / (12500.0 * M))
         gen = torch.Generator(device=dev)
         gen.manual_seed(0xACA25 + rank)
         v16 = iq.view(torch.int16).view(nstreams, -1)
+        v32 = iq.view(torch.float32).view(nstreams, -1)
         for c in range(nacars):
             a, _ = S.channel_audio(np.random.default_rng(0xACA25 + int(own[c])), nout, gap=(3125, 12500), text_len=(20, 220))
             env = torch.from_numpy((SCALE * CARRIER * (1.0 + DEPTH * a)).astype(np.float32)).to(dev).repeat_interleave(M)
-            ph = torch.remainder(tt * float(offs[c]) + float(phases[c]), 2.0 * np.pi).to(torch.float32)
-            xi = env * torch.cos(ph) + sigma * torch.randn(nout * M, device=dev, generator=gen)
-            xq = env * torch.sin(ph) + sigma * torch.randn(nout * M, device=dev, generator=gen)
-            v16[c, 0::2] = torch.round(32767.0 * 0.9 * xi).clamp_(-32768, 32767).to(torch.int16)
-            v16[c, 1::2] = torch.round(32767.0 * 0.9 * xq).clamp_(-32768, 32767).to(torch.int16)
-        del tt, env, ph, xi, xq
-        data_desc = ("uniform random 12-bit int16 samples; the first %d channels (the ones the parity gate looks at) carry ACARS/MSK traffic "
-                     "as in the u8 cases (AM depth %.1f, %.0f dB SNR in the channel), quantised to int16 on the device" % (nacars, DEPTH, SNR_DB))
+            ph = torch.remainder(tt * abs(float(offs[c])) + float(phases[c]), 2.0 * np.pi).to(torch.float32) if fmt == K.FMT_F32_REAL else \
+                torch.remainder(tt * float(offs[c]) + float(phases[c]), 2.0 * np.pi).to(torch.float32)
+            if fmt == K.FMT_CS16:
+                xi = env * torch.cos(ph) + sigma * torch.randn(nout * M, device=dev, generator=gen)
+                xq = env * torch.sin(ph) + sigma * torch.randn(nout * M, device=dev, generator=gen)
+                v16[c, 0::2] = torch.round(32767.0 * 0.9 * xi).clamp_(-32768, 32767).to(torch.int16)
+                v16[c, 1::2] = torch.round(32767.0 * 0.9 * xq).clamp_(-32768, 32767).to(torch.int16)
+            else:
+                v32[c] = 2.0 * env * torch.cos(ph) + sigma * torch.randn(nout * M, device=dev, generator=gen)
+        del tt, env, ph
+        data_desc = ("%s; the first %d channels (the ones the parity gate looks at) carry ACARS/MSK traffic "
+                     "as in the u8 cases (AM depth %.1f, %.0f dB SNR in the channel), generated on the device"
+                     % ("uniform random 12-bit int16 samples" if fmt == K.FMT_CS16 else "gaussian float32 samples", nacars, DEPTH, SNR_DB))
     elif content == "random":
         assert L.acg_fill_random_u8_dev(iq.data_ptr(), row, nstreams, row, 0xACA25 + rank, None) == 0
         data_desc = "uniform random bytes, seeded per stream (SURVEY 8d config 5: the value distribution is irrelevant to bandwidth)"
@@ -846,7 +858,7 @@ def main():
     elif overridden or args.format != "u8" or args.share > 1:
         also = []
     else:
-        also = ["wide", "stress", "cs16"] if world == 1 else ["shard2048"]
+        also = ["wide", "stress", "cs16", "f32"] if world == 1 else ["shard2048"]
         also = [a for a in also if a != args.config]
     cases = [(args.config, case)] + [(a, dict(CASES[a])) for a in also]
     # with several ranks sharing one GPU (gloo rehearsal) keep the footprint small

@@ -49,15 +49,15 @@ def test_bench_also_cases_in_one_line():
     roofline and whole-job fraction of HBM bandwidth (here at reduced sizes through the case table)."""
     code = ("import sys, bench; bench.CASES['throughput'].update(channels=128, blocks=12); "
             "bench.CASES['wide'].update(channels=512, blocks=2); bench.CASES['stress'].update(channels=256, blocks=2); "
-            "bench.CASES['cs16'].update(channels=256, blocks=2); "
+            "bench.CASES['cs16'].update(channels=256, blocks=2); bench.CASES['f32'].update(channels=256, blocks=2); "
             "sys.argv = ['bench.py', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--sustain', '0.5']; bench.main()")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     d = last_json(r.stdout)
-    assert set(d["also"]) == {"wide", "stress", "cs16"}
+    assert set(d["also"]) == {"wide", "stress", "cs16", "f32"}
     for name, a in d["also"].items():
         assert a["parity"]["dm_within_1e5_rel"] is True and a["parity"]["blocks_exact_given_gpu_dm"] is True and a["parity"]["channels_checked"] == 64
-        if name != "cs16":                                # (the exact-order mode restates rtl.c's u8 loop)
+        if name not in ("cs16", "f32"):                   # (the exact-order mode restates rtl.c's u8 loop)
             assert a["parity"]["exact_order_mode"]["blocks_identical_end_to_end"] is True
         assert 0 < a["roofline"]["frac"] < 1 and 0 < a["whole_job_frac_of_hbm"] < 1 and a["value"] > 0
         # sustained timing: a step is several passes, the timed region lasts what --sustain asked for, value follows from it
@@ -70,6 +70,7 @@ def test_bench_also_cases_in_one_line():
     # test's 0.16 s of signal a block may or may not complete)
     assert "ACARS" in d["also"]["stress"]["data"] and "filter" in d["also"]["stress"]["config"]
     assert "ACARS" in d["also"]["cs16"]["data"] and d["also"]["cs16"]["config"]["input_format"] == "cs16"
+    assert "ACARS" in d["also"]["f32"]["data"] and d["also"]["f32"]["config"]["input_format"] == "f32"
     assert d["parity"]["blocks"] > 0
 
 
