@@ -323,8 +323,9 @@ def run_case(J, name, case, args, steps, warmup, headline):
         for c in range(nacars):
             a, _ = S.channel_audio(np.random.default_rng(0xACA25 + int(own[c])), nout, gap=(3125, 12500), text_len=(20, 220))
             env = torch.from_numpy((SCALE * CARRIER * (1.0 + DEPTH * a)).astype(np.float32)).to(dev).repeat_interleave(M)
-            ph = torch.remainder(tt * abs(float(offs[c])) + float(phases[c]), 2.0 * np.pi).to(torch.float32) if fmt == K.FMT_F32_REAL else \
-                torch.remainder(tt * float(offs[c]) + float(phases[c]), 2.0 * np.pi).to(torch.float32)
+            # (real f32: air.c mixes with Fc - Fr + rate / 4, air.c:278, i.e. the channel sits at its offset + a quarter of the rate)
+            f_c = float(offs[c]) + (12500.0 * M / 4.0 if fmt == K.FMT_F32_REAL else 0.0)
+            ph = torch.remainder(tt * f_c + float(phases[c]), 2.0 * np.pi).to(torch.float32)
             if fmt == K.FMT_CS16:
                 xi = env * torch.cos(ph) + sigma * torch.randn(nout * M, device=dev, generator=gen)
                 xq = env * torch.sin(ph) + sigma * torch.randn(nout * M, device=dev, generator=gen)
