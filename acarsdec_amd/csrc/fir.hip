@@ -730,7 +730,7 @@ __device__ __forceinline__ unsigned int ticket_take(unsigned int& ticket)
 // (a fifth of the loop's vector instructions) become one subtraction per window.  x - 127.37f is exact in f32 either
 // way; what changes is the order of the roundings in the sum, at the 1e-7 level of full scale like any re-association
 // (rtl.c builds with -Ofast and re-associates itself; the parity bar for dm is 1e-5).
-template <int CPR, int UU, int BB, int TILE, bool FOLD, bool WT = false>
+template <int CPR, int UU, int BB, int TILE, bool FOLD, bool WT = false, bool NOMAC = false>
 __device__ __forceinline__ void fird_tile(u4v_t* st /* [U] */, __amdgpu_buffer_rsrc_t cur, __amdgpu_buffer_rsrc_t nxt,
                                           unsigned int voff, const float4* Tl, f2* Pw, const f2* Pr, float* __restrict__ dm_out, int lane,
                                           f2 dc)
@@ -759,6 +759,10 @@ __device__ __forceinline__ void fird_tile(u4v_t* st /* [U] */, __amdgpu_buffer_r
         const float w[16] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w, w2.x, w2.y, w2.z, w2.w, w3.x, w3.y, w3.z, w3.w};
         f2 accA = {0.f, 0.f};       // (sum tr*wr, sum ti*wi)
         f2 accB = {0.f, 0.f};       // (sum tr*wi, sum ti*wr)
+        if (NOMAC) {                // measurement variant 56: the loads are consumed, nothing is converted or multiplied, no tap reads
+            accA.x = __uint_as_float((d[0] ^ d[1]) & 0x3fffffffu);
+            accB.x = __uint_as_float((d[2] ^ d[3]) & 0x3fffffffu);
+        } else
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const unsigned int word = d[j >> 1];
@@ -797,7 +801,7 @@ __device__ __forceinline__ void fird_tile(u4v_t* st /* [U] */, __amdgpu_buffer_r
     }
 }
 
-template <int CPR, int UU, int BB, bool FOLD, bool WT = false>
+template <int CPR, int UU, int BB, bool FOLD, bool WT = false, bool NOMAC = false>
 __device__ __forceinline__ void fird_body(const FirArgs& a, const uint8_t* __restrict__ iq_base, const float* __restrict__ taps_base,
                                           const int* __restrict__ stream_of, float* __restrict__ dm_base)
 {
@@ -931,7 +935,7 @@ __device__ __forceinline__ void fird_body(const FirArgs& a, const uint8_t* __res
         unsigned int nrun_ = NONE, nch_ = ch, nt0 = t0;
         float4 tp[4];
         for (unsigned int j = 0; j < pairs; ++j) {
-            fird_tile<CPR, UU, BB, 0, FOLD, WT>(st, cur, cur, voff, Tl, Pw, Pr, dm_out, lane, dc);
+            fird_tile<CPR, UU, BB, 0, FOLD, WT, NOMAC>(st, cur, cur, voff, Tl, Pw, Pr, dm_out, lane, dc);
             // second tile of the body: where does the stream go next?
             const uint8_t* nbase = base + run_bytes;                // the next body of this run ...
             if (j + 1 == pairs) {                                   // ... or the first body of the next run
@@ -947,7 +951,7 @@ __device__ __forceinline__ void fird_body(const FirArgs& a, const uint8_t* __res
                 fetch_taps(nch_, tp);
             }
             const __amdgpu_buffer_rsrc_t nxt = fird_rsrc(nbase, has_next ? run_bytes : 0u);
-            fird_tile<CPR, UU, BB, 1, FOLD, WT>(st, cur, nxt, voff, Tl, Pw, Pr, dm_out + ACG_TILE_WIN, lane, dc);
+            fird_tile<CPR, UU, BB, 1, FOLD, WT, NOMAC>(st, cur, nxt, voff, Tl, Pw, Pr, dm_out + ACG_TILE_WIN, lane, dc);
             dm_out += FIRD_R * ACG_TILE_WIN;
             base = nbase;
             cur = nxt;
@@ -961,14 +965,14 @@ __device__ __forceinline__ void fird_body(const FirArgs& a, const uint8_t* __res
     sign_off();
 }
 
-template <int CPR, int UU = 0, int BB = 0, bool FOLD = true, bool WT = false>
+template <int CPR, int UU = 0, int BB = 0, bool FOLD = true, bool WT = false, bool NOMAC = false>
 __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_direct_kernel(const FirArgs a,
                                                                     const uint8_t* __restrict__ iq_base,
                                                                     const float* __restrict__ taps_base,
                                                                     const int* __restrict__ stream_of,
                                                                     float* __restrict__ dm_base)
 {
-    fird_body<CPR, UU, BB, FOLD, WT>(a, iq_base, taps_base, stream_of, dm_base);
+    fird_body<CPR, UU, BB, FOLD, WT, NOMAC>(a, iq_base, taps_base, stream_of, dm_base);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2102,7 +2106,7 @@ extern "C" size_t acg_fir_lds_bytes(const FirArgs* a)
 }
 
 // wave-private streaming kernel: whole tiles, runs inside one channel, a rate it is instantiated for
-template <int CPR, int UU = 0, int BB = 0, bool FOLD = true, bool WT = false>
+template <int CPR, int UU = 0, int BB = 0, bool FOLD = true, bool WT = false, bool NOMAC = false>
 static int launch_direct(const FirArgs* a, int num_cu, hipStream_t stream)
 {
     // The waves of a workgroup are independent, so the workgroup size only decides in what pieces LDS is handed out
@@ -2136,7 +2140,7 @@ static int launch_direct(const FirArgs* a, int num_cu, hipStream_t stream)
     if (acg_tune_has("ACG_FIR_DEBUG_SHAPE"))
         fprintf(stderr, "fir_u8_direct<%d>: nch %d nwin %d  wpg %d per_cu %d grid %lld  bodies/ch %lld pairs %d runs %lld  shares_cus %d prio %d\n",
                 CPR, a->nch, a->nwin, wpg, per_cu, grid, bodies_per_ch, pairs, nrun, a->shares_cus, a->high_prio);
-    FIR_LAUNCH((fir_u8_direct_kernel<CPR, UU, BB, FOLD, WT>), dim3((unsigned int)grid), dim3(64 * wpg), lds, stream, b, a->iq, a->taps,
+    FIR_LAUNCH((fir_u8_direct_kernel<CPR, UU, BB, FOLD, WT, NOMAC>), dim3((unsigned int)grid), dim3(64 * wpg), lds, stream, b, a->iq, a->taps,
                        a->stream_of, a->dm);
     return (int)hipGetLastError();
 }
@@ -2226,7 +2230,7 @@ extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
     if (variant == 6 && a->cpr == 25 && a->nwin > 0 && a->nwin % ACG_TILE_WIN == 0 && (a->nwin / ACG_TILE_WIN) % FIRD_R == 0 &&
         (long long)a->nch * (a->nwin / ACG_TILE_WIN) < (1ll << 31) && a->ntaps_pad <= a->decim)
         return launch_mfma<25>(a, num_cu, (hipStream_t)stream);
-    if ((variant == 5 || (variant >= 50 && variant <= 55)) && a->nwin > 0 && a->nwin % ACG_TILE_WIN == 0 && (a->nwin / ACG_TILE_WIN) % FIRD_R == 0 &&
+    if ((variant == 5 || (variant >= 50 && variant <= 56)) && a->nwin > 0 && a->nwin % ACG_TILE_WIN == 0 && (a->nwin / ACG_TILE_WIN) % FIRD_R == 0 &&
         (long long)a->nch * (a->nwin / ACG_TILE_WIN) < (1ll << 31) && a->ntaps_pad <= a->decim) {
         switch (a->cpr) {
         // (dm is stored write-through: beside the streaming reads a write-back line costs more, see firc_flush)
@@ -2238,6 +2242,7 @@ extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
             if (variant == 52) return launch_direct<25, 25, 10>(a, num_cu, (hipStream_t)stream);
             if (variant == 53) return launch_direct<25, 10, 10>(a, num_cu, (hipStream_t)stream);
             if (variant == 54) return launch_direct<25, 0, 0, false>(a, num_cu, (hipStream_t)stream);      // 127.37 subtracted per sample
+            if (variant == 56) return launch_direct<25, 0, 0, true, true, true>(a, num_cu, (hipStream_t)stream);   // measurement: no arithmetic (dm is garbage)
             if (variant == 55) return launch_direct<25>(a, num_cu, (hipStream_t)stream);                    // dm stored write-back (round 2a)
             return launch_direct<25, 0, 0, true, true>(a, num_cu, (hipStream_t)stream);
         default: break;
