@@ -2215,7 +2215,7 @@ extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
     // ACG_FIR_VARIANT: 5 (default) wave-private streaming kernel where it applies (dm stored write-through), else 3;
     // 0 one workgroup per segment; 1 / 2 static persistent partition without / with non-temporal loads; 3 workgroup-
     // granular dynamic dispenser; 4 LDS-DMA double buffering; 6 matrix pipe; 7 taps in registers; 8 = 7 with the results
-    // parked in LDS and written in chip-wide bursts; 50..55, 70..73 measurement knobs of 5 and 7 (55: write-back stores)
+    // parked in LDS and written in chip-wide bursts; 50..56, 70..73 measurement knobs of 5 and 7 (55: write-back stores; 56: no arithmetic, dm is garbage)
     const int variant = env_int("ACG_FIR_VARIANT", 5);
     if ((variant == 7 || variant == 8 || (variant >= 70 && variant <= 73)) && a->cpr == 25 && a->nwin > 0 && a->nwin % ACG_TILE_WIN == 0 && (a->nwin / ACG_TILE_WIN) % FIRD_R == 0 &&
         (long long)a->nch * (a->nwin / ACG_TILE_WIN) < (1ll << 31) && a->ntaps_pad <= a->decim)
