@@ -2136,7 +2136,7 @@ static int launch_direct(const FirArgs* a, int num_cu, hipStream_t stream)
     if (grid > need) grid = need;
     FirArgs b = *a;
     b.run_pairs = pairs;
-    if (acg_tune_has("ACG_FIR_DEBUG_DMPITCH0")) b.dm_pitch = 0;          // measurement aid: every channel's dm lands in the first row (no write stream to HBM)
+    if (acg_tune_get("ACG_FIR_DEBUG_DMPITCH0", 0)) b.dm_pitch = 0;          // measurement aid: every channel's dm lands in the first row (no write stream to HBM)
     if (acg_tune_has("ACG_FIR_DEBUG_SHAPE"))
         fprintf(stderr, "fir_u8_direct<%d>: nch %d nwin %d  wpg %d per_cu %d grid %lld  bodies/ch %lld pairs %d runs %lld  shares_cus %d prio %d\n",
                 CPR, a->nch, a->nwin, wpg, per_cu, grid, bodies_per_ch, pairs, nrun, a->shares_cus, a->high_prio);
