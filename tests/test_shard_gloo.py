@@ -101,7 +101,9 @@ def test_bench_gpus_flag_launches_ranks_itself():
     assert r.returncode != 0 and "only 0 GPU(s) visible" in r.stderr, r.stderr[-800:]
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-cpu-baseline"], capture_output=True, text=True,
                        env=dict(env, ACG_BENCH_BACKEND="gloo"), timeout=600)
-    assert r.returncode != 0 and r.stderr.count("bench.py needs a GPU") >= 2, r.stderr[-1500:]     # both ranks got that far
+    # the ranks were started (torch.distributed.run reports a failed child) and got as far as the GPU check; the elastic agent may
+    # kill the second rank before it has printed its own message, so one is enough
+    assert r.returncode != 0 and r.stderr.count("bench.py needs a GPU") >= 1 and "ChildFailedError" in r.stderr, r.stderr[-1500:]
     # a rank count that contradicts the flag is an error, not a silent override
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"], capture_output=True, text=True,
                        env=dict(env, WORLD_SIZE="2", RANK="0"), timeout=300)
