@@ -173,6 +173,16 @@ def test_exact_order_mode_dm_is_bit_identical_to_oracle(D, O, M, ntaps):
         got = dec.dm(c, nout)
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (c, float(np.abs(got - want).max()))
     dec.close()
+    # rtl.c's own shape: all channels on one dongle stream (scrambled channel -> stream map on two streams)
+    smap = np.array([1, 0, 0, 1, 0])
+    dec = D.Decoder(nch, decim=M, ntaps=ntaps, nstreams=2, max_blocks=nblk, exact_fir=True)
+    dec.set_taps(taps)
+    dec.set_channel_streams(smap)
+    dec.in_callback(iq[:2])
+    for c in range(nch):
+        want = O.fir_u8(iq[smap[c]], M, taps[c], nout=nout, ntaps=ntaps)
+        assert np.array_equal(dec.dm(c, nout).view(np.uint32), want.view(np.uint32)), c
+    dec.close()
 
 
 def test_exact_order_mode_is_bit_identical_end_to_end(D, O, S):
