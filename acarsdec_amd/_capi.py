@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # ACARSDEC_AMD_LIB: measurement aid (A/B timing of two builds on one box, the stamp build); the product is the in-tree path
 LIB_PATH = os.environ.get("ACARSDEC_AMD_LIB") or os.path.join(HERE, "lib", "libacarsdec_amd.so")
 
-OK, EINVAL, ENOMEM, EHIP, ENODEV, EOVERFLOW, ESTATE = 0, -1, -2, -3, -4, -5, -6
+OK, EINVAL, ENOMEM, EHIP, ENODEV, EOVERFLOW, ESTATE, EAGAIN = 0, -1, -2, -3, -4, -5, -6, -7
 F_BITLOG, F_TIMING, F_REPAIR, F_EXACT_FIR = 1, 2, 4, 8
 INTRATE, BLOCK, MAXDECIM, FLEN, TXTMAX = 12500, 1024, 320, 11, 250
 MAXDECIM_SAMPLES = 1024
@@ -16,7 +16,7 @@ FMT_CS16, FMT_S16_SPLIT, FMT_F32_REAL = 1, 2, 3
 
 class Config(C.Structure):
     _fields_ = [("device", C.c_int), ("nch", C.c_int), ("nstreams", C.c_int), ("decim", C.c_int),
-                ("ntaps", C.c_int), ("max_blocks", C.c_int), ("flags", C.c_uint32)]
+                ("ntaps", C.c_int), ("max_blocks", C.c_int), ("flags", C.c_uint32), ("max_lag", C.c_int)]
 
 
 class ChanState(C.Structure):

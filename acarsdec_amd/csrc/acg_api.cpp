@@ -221,6 +221,7 @@ extern "C" const char* acg_strerror(int code)
     case ACG_ENODEV: return "no GPU available (this library has no CPU fallback)";
     case ACG_EOVERFLOW: return "output queue overflow";
     case ACG_ESTATE: return "bad call sequence";
+    case ACG_EAGAIN: return "more results queued than fit: call again (nothing lost)";
     default: return "unknown error";
     }
 }
@@ -304,7 +305,8 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
     if (!out || !cfg) return ACG_EINVAL;
     *out = nullptr;
     if (cfg->nch < 1 || cfg->nstreams < 1 || cfg->nstreams > cfg->nch || cfg->decim < 1 ||
-        cfg->decim > ACG_MAXDECIM_SAMPLES || cfg->ntaps < 1 || cfg->ntaps > cfg->decim || cfg->max_blocks < 1)
+        cfg->decim > ACG_MAXDECIM_SAMPLES || cfg->ntaps < 1 || cfg->ntaps > cfg->decim || cfg->max_blocks < 1 ||
+        cfg->max_lag < 0 || cfg->max_lag > acg_ctx::NCALL - 2)
         return ACG_EINVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || cfg->device < 0 || cfg->device >= ndev)
@@ -320,12 +322,14 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
     c->bit_cap = c->max_len / 4 + 8;
     // shortest possible block: SYN SYN SOH ETX CRC CRC + END byte = 56 bits ~ 291 samples.  The ring holds the worst case of
     // lag_max + 1 calls (a collect that stays `lag` calls behind leaves lag + 1 calls' blocks in it), so a host that
-    // collects after every call can never be lapped: lag up to NCALL - 2 = 6 where that costs <= 512 MiB (1024 channels x
-    // 8 callbacks: 66 MB for all seven), fewer calls for very wide contexts (16 384 channels x 8 callbacks: three calls).
+    // collects after every call can never be lapped.  acg_config.max_lag = 0: lag up to NCALL - 2 = 6 where that costs
+    // <= 512 MiB (1024 channels x 8 callbacks: 66 MB for all seven), fewer calls for very wide contexts (16 384 channels
+    // x 8 callbacks: three calls); a host that names its lag gets exactly that (lag 1: two calls' worth).
     {
         const unsigned long long per_call = (unsigned long long)cfg->nch * (unsigned long long)(c->max_len / 291 + 2);
         unsigned long long calls = (512ull << 20) / (per_call * sizeof(AcgFrameRec));
         calls = std::max<unsigned long long>(2, std::min<unsigned long long>(acg_ctx::NCALL - 1, calls));
+        if (cfg->max_lag > 0) calls = (unsigned long long)cfg->max_lag + 1;       // the host says how far behind it collects
         if (per_call * calls > 0xffffffffull) { delete c; return ACG_EINVAL; }
         c->frame_cap = (unsigned int)(per_call * calls);
         c->lag_max = (int)calls - 1;
@@ -896,18 +900,22 @@ extern "C" int acg_placement_trial_samples(acg_ctx* ctx, int fmt, const void* de
 }
 
 // ------------------------------------------------------------------------------------------
-// Hands frames [consumed, upto) of the ring to the host, ordered by (chn, end_bit).
+// Hands blocks of the ring to the host: the oldest min(pending, max_frames) records of [consumed, upto), ordered by
+// (chn, end_bit) within the call.  What does not fit STAYS queued (ACG_EAGAIN: call again, nothing lost); only a ring
+// that the device has lapped loses blocks (ACG_EOVERFLOW, the count is in acg_last_error).
 static int fetch_frames(acg_ctx* ctx, unsigned int upto, acg_frame* out, int max_frames, int* nframes)
 {
-    const unsigned int pending = upto - ctx->consumed;            // monotonic counters, wrap-safe
+    unsigned int pending = upto - ctx->consumed;                  // monotonic counters, wrap-safe
     int rc = ACG_OK;
-    unsigned int take = pending;
     if (pending > ctx->frame_cap) {                               // the device lapped the host: oldest lost
+        char msg[96];
+        std::snprintf(msg, sizeof(msg), "block queue lapped: the %u oldest blocks are lost", pending - ctx->frame_cap);
+        ctx->err = msg;
         ctx->consumed = upto - ctx->frame_cap;
-        take = ctx->frame_cap;
+        pending = ctx->frame_cap;
         rc = ACG_EOVERFLOW;
     }
-    if ((unsigned int)max_frames < take) { take = (unsigned int)max_frames; rc = ACG_EOVERFLOW; }
+    unsigned int take = std::min(pending, (unsigned int)std::max(0, max_frames));
     if (take > ctx->h_stage_cap) {                                // host staging, grown on demand
         // Pageable on purpose: with a pinned destination (one SDMA transfer) the same copy, issued while the
         // down-converter saturates HBM, made every step 0.9 ms slower at 16 384 channels (10.3 -> 11.2 ms);
@@ -933,7 +941,6 @@ static int fetch_frames(acg_ctx* ctx, unsigned int upto, acg_frame* out, int max
         HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
     }
     ctx->consumed += take;
-    if (rc == ACG_EOVERFLOW) ctx->consumed = upto;                // drop what did not fit
     // per channel in order (the contract); sort an index, not the 304-byte records
     std::vector<unsigned int> order(take);
     for (unsigned int i = 0; i < take; ++i) order[i] = i;
@@ -957,9 +964,9 @@ static int fetch_frames(acg_ctx* ctx, unsigned int upto, acg_frame* out, int max
         f.end_bit = r.end_bit;
         f.end_sample = r.end_sample;
     }
-    take = kept;
-    *nframes = (int)take;
-    if (rc != ACG_OK) return fail(ctx, rc, "frame queue overflow");
+    *nframes = (int)kept;
+    if (rc != ACG_OK) return rc;                                  // (the text is already in ctx->err)
+    if (take < pending) return fail(ctx, ACG_EAGAIN, "more blocks queued than fit: call again");
     return ACG_OK;
 }
 
@@ -997,46 +1004,42 @@ static int fetch_msgs(acg_ctx* ctx, unsigned int upto, acg_msg* out, int max_msg
     unsigned int pending = upto - ctx->consumed;
     int rc = ACG_OK;
     if (pending > ctx->frame_cap) {                               // the device lapped the host: oldest lost
+        char msg[96];
+        std::snprintf(msg, sizeof(msg), "block queue lapped: the %u oldest blocks are lost", pending - ctx->frame_cap);
+        ctx->err = msg;
         ctx->consumed = upto - ctx->frame_cap;
         pending = ctx->frame_cap;
         rc = ACG_EOVERFLOW;
     }
-    if (pending > ctx->msgs_cap) {
+    // A call splits and copies the oldest min(pending, max_msgs) blocks only (a block yields at most one message, so they
+    // all fit) and consumes exactly those: draining a long queue through a small buffer costs what it hands out, not the
+    // square of it, and the staging follows the caller's buffer, not the ring.
+    const unsigned int take = std::min(pending, (unsigned int)std::max(0, max_msgs));
+    if (take > ctx->msgs_cap) {
         hipFree(ctx->d_msgs);
         std::free(ctx->h_msgs);
         ctx->d_msgs = nullptr;
         ctx->h_msgs = nullptr;
         ctx->msgs_cap = 0;
-        const size_t want = std::max<size_t>(pending, 4096);
+        const size_t want = std::max<size_t>(take, 4096);
         HIPCHK(ctx, hipMalloc(&ctx->d_msgs, want * sizeof(AcgMsgRec)));
         ctx->h_msgs = (AcgMsgRec*)std::malloc(want * sizeof(AcgMsgRec));
         if (!ctx->h_msgs) return fail(ctx, ACG_ENOMEM, "message staging");
         ctx->msgs_cap = want;
     }
-    if (pending) {
+    if (take) {
         // the split writes every byte of a record (text tail zeroed), so nothing stale crosses the ABI
-        if (acg_launch_msg_split(ctx->d_frames, ctx->frame_cap, ctx->consumed, pending, ctx->d_msgs, ctx->copy_stream) != 0)
+        if (acg_launch_msg_split(ctx->d_frames, ctx->frame_cap, ctx->consumed, take, ctx->d_msgs, ctx->copy_stream) != 0)
             return fail(ctx, ACG_EHIP, "message split launch failed");
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_msgs, ctx->d_msgs, (size_t)pending * sizeof(AcgMsgRec), hipMemcpyDeviceToHost, ctx->copy_stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_msgs, ctx->d_msgs, (size_t)take * sizeof(AcgMsgRec), hipMemcpyDeviceToHost, ctx->copy_stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
     }
-    // Queue order is completion order.  If the caller's buffer is too small, hand out the longest PREFIX of the queue
-    // whose valid messages fit and consume only that prefix: the rest stays queued for the next call (ACG_EOVERFLOW tells
-    // the caller to come again) -- nothing is dropped.
     const AcgMsgRec* rec = ctx->h_msgs;
-    unsigned int take = 0, nvalid = 0;
-    while (take < pending) {
-        if (rec[take].valid) {
-            if ((int)nvalid >= max_msgs) { rc = ACG_EOVERFLOW; break; }
-            ++nvalid;
-        }
-        ++take;
-    }
     ctx->consumed += take;
     std::vector<unsigned int> order;
-    order.reserve(nvalid);
+    order.reserve(take);
     for (unsigned int i = 0; i < take; ++i)
-        if (rec[i].valid) order.push_back(i);
+        if (rec[i].valid) order.push_back(i);                     // (blocks the repair dropped yield nothing)
     std::sort(order.begin(), order.end(), [rec](unsigned int x, unsigned int y) {
         return rec[x].chn != rec[y].chn ? rec[x].chn < rec[y].chn : rec[x].end_bit < rec[y].end_bit;
     });
@@ -1050,7 +1053,8 @@ static int fetch_msgs(acg_ctx* ctx, unsigned int upto, acg_msg* out, int max_msg
         m.reserved2 = 0;
     }
     *nmsgs = (int)kept;
-    if (rc != ACG_OK) return fail(ctx, rc, pending == take ? "block queue lapped: oldest messages lost" : "more messages queued than fit: call again");
+    if (rc != ACG_OK) return rc;
+    if (take < pending) return fail(ctx, ACG_EAGAIN, "more messages queued than fit: call again");
     return ACG_OK;
 }
 

@@ -64,7 +64,7 @@ def parse_freq_mhz(s):
 
 class Decoder:
     def __init__(self, nch, decim=160, ntaps=None, nstreams=None, max_blocks=1, device=0,
-                 bitlog=True, timing=False, repair=False, exact_fir=False):
+                 bitlog=True, timing=False, repair=False, exact_fir=False, max_lag=0):
         self.L = K.load()
         self.nch, self.decim = int(nch), int(decim)
         self.ntaps = int(ntaps if ntaps is not None else decim)
@@ -72,7 +72,7 @@ class Decoder:
         self.max_blocks = int(max_blocks)
         cfg = K.Config(device, self.nch, self.nstreams, self.decim, self.ntaps, self.max_blocks,
                        (K.F_BITLOG if bitlog else 0) | (K.F_TIMING if timing else 0) | (K.F_REPAIR if repair else 0) |
-                       (K.F_EXACT_FIR if exact_fir else 0))
+                       (K.F_EXACT_FIR if exact_fir else 0), int(max_lag))
         self.ctx = C.c_void_p()
         rc = self.L.acg_create(C.byref(self.ctx), C.byref(cfg))
         if rc != K.OK:
@@ -187,34 +187,76 @@ class Decoder:
 
     # ---- results ------------------------------------------------------------------------
     def drain_frames(self, max_frames=4096):
-        """Blocks completed since the last drain as a list of ctypes Frame objects."""
-        n, buf = self.drain_frames_raw(max_frames)
-        return [K.Frame.from_buffer_copy(buf[i]) for i in range(n)]      # copies: the array is reused
+        """Blocks completed since the last drain as a list of ctypes Frame objects (loops while the C side says ACG_EAGAIN)."""
+        out = []
+        while True:
+            n, buf, more = self._frames_call(self.L.acg_drain_frames, max_frames)
+            out += [K.Frame.from_buffer_copy(buf[i]) for i in range(n)]      # copies: the array is reused
+            if not more:
+                return out
 
-    def drain_frames_raw(self, max_frames=4096):
-        """(count, ctypes array): no per-block Python objects; the array is reused by the next call."""
+    def _frames_call(self, fn, max_frames, *lead):
         if getattr(self, "_fbuf_cap", 0) < max_frames:
             self._fbuf = (K.Frame * max_frames)()
             self._fbuf_cap = max_frames
         n = C.c_int(0)
-        _chk(self.ctx, self.L.acg_drain_frames(self.ctx, self._fbuf, self._fbuf_cap, C.byref(n)))
-        return n.value, self._fbuf
+        rc = _chk(self.ctx, fn(self.ctx, *lead, self._fbuf, self._fbuf_cap, C.byref(n)), allow=(K.EAGAIN,))
+        return n.value, self._fbuf, rc == K.EAGAIN
+
+    def drain_frames_raw(self, max_frames=4096):
+        """(count, ctypes array): no per-block Python objects; the array is reused by the next call.  Blocks beyond
+        max_frames stay queued (the next drain / collect hands them out)."""
+        n, buf, _ = self._frames_call(self.L.acg_drain_frames, max_frames)
+        return n, buf
 
     def collect_frames_raw(self, lag=1, max_frames=4096):
         """Streaming drain: blocks of all calls but the `lag` newest; waits only for those calls."""
-        if getattr(self, "_fbuf_cap", 0) < max_frames:
-            self._fbuf = (K.Frame * max_frames)()
-            self._fbuf_cap = max_frames
-        n = C.c_int(0)
-        _chk(self.ctx, self.L.acg_collect_frames(self.ctx, lag, self._fbuf, self._fbuf_cap, C.byref(n)))
-        return n.value, self._fbuf
+        n, buf, _ = self._frames_call(self.L.acg_collect_frames, max_frames, lag)
+        return n, buf
+
+    def _msg_buf(self, max_msgs):
+        if getattr(self, "_mbuf_cap", 0) < max_msgs:
+            self._mbuf = (K.Msg * max_msgs)()
+            self._mbuf_cap = max_msgs
+        return self._mbuf
 
     def drain_msgs(self, max_msgs=4096):
-        """outputmsg()'s field split of every block completed since the last drain (needs repair=True): K.Msg records."""
-        buf = (K.Msg * max_msgs)()
+        """outputmsg()'s field split of every block completed since the last drain (needs repair=True): K.Msg records.
+        The C side hands out the oldest messages that fit and says ACG_EAGAIN ("call again, nothing lost") while more are
+        queued: this wrapper calls again until the queue is empty, so the list is complete whatever max_msgs is (per call the
+        records are ordered by (chn, end_bit); across calls the order is completion order)."""
+        buf = self._msg_buf(max(1, max_msgs))
+        out = []
+        while True:
+            n = C.c_int(0)
+            rc = _chk(self.ctx, self.L.acg_drain_msgs(self.ctx, buf, self._mbuf_cap, C.byref(n)), allow=(K.EAGAIN,))
+            out += [K.Msg.from_buffer_copy(buf[i]) for i in range(n.value)]
+            if rc == K.OK:
+                return out
+
+    def drain_msgs_raw(self, max_msgs=4096):
+        """(count, ctypes array, more): one acg_drain_msgs call, no per-message Python objects"""
+        buf = self._msg_buf(max(1, max_msgs))
         n = C.c_int(0)
-        _chk(self.ctx, self.L.acg_drain_msgs(self.ctx, buf, max_msgs, C.byref(n)))
-        return [K.Msg.from_buffer_copy(buf[i]) for i in range(n.value)]
+        rc = _chk(self.ctx, self.L.acg_drain_msgs(self.ctx, buf, self._mbuf_cap, C.byref(n)), allow=(K.EAGAIN,))
+        return n.value, buf, rc == K.EAGAIN
+
+    def collect_msgs_raw(self, lag=1, max_msgs=4096):
+        """Streaming variant (acg_collect_msgs): (count, ctypes array, more) -- messages of all calls but the `lag` newest; `more`
+        is True when the buffer was too small and the rest stays queued for the next collect (nothing is lost)."""
+        buf = self._msg_buf(max(1, max_msgs))
+        n = C.c_int(0)
+        rc = _chk(self.ctx, self.L.acg_collect_msgs(self.ctx, lag, buf, self._mbuf_cap, C.byref(n)), allow=(K.EAGAIN,))
+        return n.value, buf, rc == K.EAGAIN
+
+    def collect_msgs(self, lag=1, max_msgs=4096):
+        """list of K.Msg of all calls but the `lag` newest (loops while the C side says "call again")"""
+        out = []
+        while True:
+            n, buf, more = self.collect_msgs_raw(lag, max_msgs)
+            out += [K.Msg.from_buffer_copy(buf[i]) for i in range(n)]
+            if not more:
+                return out
 
     def bits(self, ch):
         vo = np.zeros(self.bit_cap, dtype=np.float32)
@@ -259,9 +301,10 @@ def frame_tuple(f):
     return (int(f.chn), int(f.len), int(f.err), bytes(f.crc), bytes(f.txt[: max(0, f.len)]))
 
 
-def best_placed(factory, n, iq_dev, nblocks, pitch, repeats=2, stream=None, fmt=0, plane=0):
+def best_placed(factory, n, iq_dev, nblocks, pitch, repeats=2, stream=None, fmt=0, plane=0, keep="best"):
     """Creates `n` decoders with factory() -- all alive during the trials, so that their buffers lie in different places --
-    runs the same call on each once for nothing, then times it (Decoder.placement_trial) and keeps the fastest.  Returns
+    runs the same call on each once for nothing, then times it (Decoder.placement_trial) and keeps the fastest (keep="best")
+    or the first (keep="first": the trial is then a diagnostic of how much the contexts of a process differ).  Returns
     (decoder, [ms per call], index); best_placed.last_fir_ms holds the down-converter tie-break figures where it was used."""
     decs = [factory() for _ in range(max(1, n))]
     if len(decs) == 1:
@@ -291,6 +334,8 @@ def best_placed(factory, n, iq_dev, nblocks, pitch, repeats=2, stream=None, fmt=
         near = [i for i in range(len(decs)) if ms[i] <= 1.01 * min(ms)]
         best = min(near, key=lambda i: fir[i])
         best_placed.last_fir_ms = fir
+    if keep == "first":
+        best = 0
     for i, d in enumerate(decs):
         if i != best:
             d.close()

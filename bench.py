@@ -8,9 +8,19 @@ of signal) per channel; every step ends with the decoded blocks delivered to the
 sized so that 20 steps make a timed region of >= 0.5 s.
 
 `value` is BASELINE.json configs[2] (1024 channels x 2.5 Msps).  The same invocation also times, under
-"also", the north-star regime (>= 10 000 independent channels on one GPU) and BASELINE configs[4]
-(4096 channels, 192-tap low-pass), each with its own parity gate, down-converter roofline and whole-job
-fraction of HBM bandwidth.
+"also", the north-star regime (>= 10 000 independent channels on one GPU), BASELINE configs[4]
+(4096 channels, 192-tap low-pass), configs[3]'s per-GPU share (2048 channels) and the other front ends'
+sample formats, each with its own parity gate, down-converter roofline and whole-job fraction of HBM
+bandwidth.
+
+What is timed is what the product DELIVERS: contexts are created with ACG_F_REPAIR and every step ends with
+acg_collect_msgs -- the block thread's check / repair (acars.c:93-215) and outputmsg()'s field split
+(output.c:486-560) run on the device inside the timed region, and the gate compares the acg_msg records with
+the oracle's orc_blk_process + orc_msg_split (--raw-blocks times the pre-repair blocks of rounds 1-3).
+
+Output: the LAST stdout line is the compact result (< 4 KB: the driver keeps a bounded tail of stdout);
+everything else -- per-case configuration, sustain / burst timing, telemetry, the full parity blocks -- is
+printed on an EARLIER line prefixed "# bench_detail: " and written to bench_detail.json.
 
 Multi-GPU: `python bench.py --gpus N` launches N ranks itself (torch.distributed.run, one rank per GPU,
 backend nccl = RCCL); started under torchrun it uses the ranks it is given.  Channels are independent
@@ -358,26 +368,29 @@ def run_case(J, name, case, args, steps, warmup, headline):
     ncall = nblk // cb
     if fmt == K.FMT_S16_SPLIT:
         cb, ncall = nblk, 1                                # (plane layout: one call)
+    repair = not args.raw_blocks
     def make_decoder():
-        d_ = D.Decoder(nch, decim=M, ntaps=ntaps, nstreams=nstreams, max_blocks=cb, device=J.local, bitlog=bool(args.bitlog), timing=True)
+        # max_lag = 1: this host collects one call behind, so the block queue holds two calls' worth
+        d_ = D.Decoder(nch, decim=M, ntaps=ntaps, nstreams=nstreams, max_blocks=cb, device=J.local, bitlog=bool(args.bitlog), timing=True,
+                       repair=repair, max_lag=1)
         d_.set_taps(taps)
         if share > 1:
             d_.set_channel_streams(np.arange(nch) // share)
         return d_
     stream = torch.cuda.current_stream().cuda_stream
-    # Placement (acg_placement_trial): where the decoder's own buffers lie relative to the input changes what
-    # the down-converter's write stream costs, by up to 15 %, and nothing in the addresses tells.  The host does what the
-    # header recommends: a few contexts, one call of the real input on each, keep the fastest -- set-up, before any timing.
+    # The context a host gets from acg_create is the one that is timed (--placements 1, the default).  --placements N is a
+    # DIAGNOSTIC: N contexts alive at once, acg_placement_trial on each, their times reported under config.placement; the
+    # FIRST is still the one timed unless --placement-keep best (rounds 2-3 kept the fastest of four: selection).
     ntrial = args.placements if share == 1 else 1
-    dec, trial_ms, trial_best = D.best_placed(make_decoder, ntrial, iq, cb, row, repeats=2 if nch > 2048 else 12, stream=stream, fmt=fmt,
-                                              plane=row // 2 if fmt == K.FMT_S16_SPLIT else 0)
+    dec, trial_ms, trial_best = D.best_placed(make_decoder, ntrial, iq, cb, row, repeats=8 if nch > 2048 else 24, stream=stream, fmt=fmt,
+                                              plane=row // 2 if fmt == K.FMT_S16_SPLIT else 0, keep=args.placement_keep)
     dec0 = dec
     maxfr = max(8192, int(nch * (cb / 3.0 + 2)))
     cb_bytes = cb * 1024 * M * bps
 
-    def step(lag=1, sink=None, dec=None, dm_sink=None):
-        """one pass of the hot path over the batch; decoded blocks are delivered to the host one call behind
-        (streaming double buffering: the newest call keeps the GPU busy while the host collects)"""
+    def step(lag=1, sink=None, dec=None, dm_sink=None, frames=False):
+        """one pass of the hot path over the batch; the results (acg_msg records; blocks with frames=True or --raw-blocks) are
+        delivered to the host one call behind (streaming double buffering: the newest call keeps the GPU busy while the host collects)"""
         n = 0
         dec = dec or dec0
         for k in range(ncall):
@@ -386,14 +399,37 @@ def run_case(J, name, case, args, steps, warmup, headline):
                 dec.in_callback(part, nblocks=cb, pitch=row, stream=stream)
             else:
                 dec.process_samples(fmt, part, cb, pitch=row, plane=row // 2 if fmt == K.FMT_S16_SPLIT else 0, stream=stream)
-            m, fb = dec.collect_frames_raw(lag, maxfr)
-            if sink is not None:
-                sink += [K.Frame.from_buffer_copy(fb[i]) for i in range(m)]
+            if repair and not frames:
+                # the delivered path: repaired blocks through outputmsg()'s field split, as acg_msg records
+                m = 0
+                while True:
+                    mm, fb, more = dec.collect_msgs_raw(lag, maxfr)
+                    if sink is not None:
+                        sink += [K.Msg.from_buffer_copy(fb[i]) for i in range(mm)]
+                    m += mm
+                    if not more:
+                        break
+            else:
+                m, fb = dec.collect_frames_raw(lag, maxfr)
+                if sink is not None:
+                    sink += [K.Frame.from_buffer_copy(fb[i]) for i in range(m)]
             if dm_sink is not None:                     # (gate only) the 12.5 kHz samples this call's demodulator consumed
                 for c in dm_sink:
                     dm_sink[c].append(dec.dm(c, cb * 1024))
             n += m
         return n
+
+    def drain(dec=None):
+        """everything still queued, through the delivered path; returns the count"""
+        dec = dec or dec0
+        if not repair:
+            return dec.drain_frames_raw(maxfr)[0]
+        m = 0
+        while True:
+            mm, _, more = dec.drain_msgs_raw(maxfr)
+            m += mm
+            if not more:
+                return m
 
     def barrier():
         torch.cuda.synchronize()
@@ -417,19 +453,38 @@ def run_case(J, name, case, args, steps, warmup, headline):
     #       other is MEASURED here: the same bytes and taps through the unmodified reference compiled -O2 (IEEE) and with its
     #       own flags (-Ofast -march=native), both from oracle/_ref.  The streaming path may differ from the oracle in no more
     #       blocks than those two builds differ from each other, plus one.
+    #   (5) the DELIVERED records: the pass once more from reset, collected as acg_msg (ACG_F_REPAIR + acg_collect_msgs), against
+    #       orc_blk_process + orc_msg_split of the oracle's blocks of (2): every field of every message, and no message of a
+    #       block that the reference's block thread drops (acars.c:124-207).
+    # With ACG_F_REPAIR (the default) "blocks" are what outputmsg() receives: checked / repaired, parity stripped, the dropped
+    # ones omitted -- on both sides (oracle: orc_blk_process; reference builds: what their blk_thread handed to outputmsg()).
     first = []
     ncheck = min(args.check_channels, nch) if rank == 0 else 0
     dm_gpu = {c: [] for c in range(ncheck)}
-    step(lag=0, sink=first, dm_sink=dm_gpu if ncheck else None)
+    step(lag=0, sink=first, dm_sink=dm_gpu if ncheck else None, frames=True)
+    msgs_first = []
+    if repair:
+        dec.reset()
+        step(lag=0, sink=msgs_first)
     parity = None
     if rank == 0:
         from oracle import oracle as O
+
+        def processed(frames):
+            """the oracle's block thread on raw blocks: kept ones as OrcFrame (ACG_F_REPAIR), or the raw blocks themselves"""
+            if not repair:
+                return list(frames)
+            return [b for b in (O.blk_process(f) for f in frames) if b is not None]
         got = {}
         got_end = {}
         for f in first:
             got.setdefault(int(f.chn), []).append(D.frame_tuple(f))
             got_end.setdefault(int(f.chn), []).append(int(f.end_bit))
+        got_msgs = {}
+        for m_ in msgs_first:
+            got_msgs.setdefault(int(m_.chn), []).append(O.msg_tuple(m_))
         ok, nblocks, dm_err, dm_ok = True, 0, 0.0, True
+        msgs_ok, nmsgs, nraw, first_bad_msg = True, 0, 0, None
         e2e_blocks_off, e2e_channels_off = 0, []
         first_bad = None
         # absolute floor of the dm tolerance: 1e-6 of the largest term of the sum.  u8: |x - 127.37| / 127.5 <= 1; CS16:
@@ -455,7 +510,9 @@ def run_case(J, name, case, args, steps, warmup, headline):
             dm_err = max(dm_err, float(e.max()))
             ch = O.Channel(c)
             ch.demod(g)                                         # (2): the oracle's demodulator on the GPU's dm
-            want = [O.frame_tuple(f) for f in ch.frames]
+            nraw += len(ch.frames)
+            kept = processed(ch.frames)
+            want = [O.frame_tuple(f) for f in kept]
             nblocks += len(want)
             mine = got.get(c, [])
             if mine != want and first_bad is None:
@@ -464,9 +521,16 @@ def run_case(J, name, case, args, steps, warmup, headline):
                                  gpu_end_bits=got_end.get(c, []), oracle_end_bits=[int(f.end_bit) for f in ch.frames],
                                  gpu=repr(mine[k_])[:300] if k_ < len(mine) else None, oracle=repr(want[k_])[:300] if k_ < len(want) else None)
             ok &= mine == want
+            if repair:                                          # (5): the delivered records, field for field
+                want_m = [O.msg_tuple(O.msg_split(b)) for b in kept]
+                nmsgs += len(want_m)
+                mine_m = got_msgs.get(c, [])
+                if mine_m != want_m and first_bad_msg is None:
+                    first_bad_msg = dict(channel=c, gpu_msgs=len(mine_m), oracle_msgs=len(want_m))
+                msgs_ok &= mine_m == want_m
             ch2 = O.Channel(c)
             ch2.demod(dm)                                       # (4): oracle down-converter -> oracle demodulator
-            want2 = [O.frame_tuple(f) for f in ch2.frames]
+            want2 = [O.frame_tuple(f) for f in processed(ch2.frames)]
             e2e_want.append(want2)
             if mine != want2:
                 e2e_channels_off.append(c)
@@ -474,7 +538,7 @@ def run_case(J, name, case, args, steps, warmup, headline):
         # (3) the exact-order mode of the library on the same channels
         exact = None
         if fmt == 0 and share == 1 and ncheck:
-            dx = D.Decoder(ncheck, decim=M, ntaps=ntaps, nstreams=ncheck, max_blocks=cb, device=J.local, bitlog=False, exact_fir=True)
+            dx = D.Decoder(ncheck, decim=M, ntaps=ntaps, nstreams=ncheck, max_blocks=cb, device=J.local, bitlog=False, exact_fir=True, repair=repair)
             dx.set_taps(taps[:ncheck])
             xfr, xdm_same = [], True
             for k in range(ncall):
@@ -498,10 +562,12 @@ def run_case(J, name, case, args, steps, warmup, headline):
             rows_ = [host_rows[c] for c in range(ncheck)]
             wf_ = [taps[c] for c in range(ncheck)]
             t_ref = time.perf_counter()
-            b_o2 = O.ref_blocks_forked("", rows_, M, wf_)
-            b_fast, fast_label = O.ref_blocks_forked("_fast", rows_, M, wf_), "-Ofast -march=native"
+            which = "out" if repair else "raw"
+            pick = lambda d: None if d is None else d[which]
+            b_o2 = pick(O.ref_blocks("", rows_, M, wf_))
+            b_fast, fast_label = pick(O.ref_blocks("_fast", rows_, M, wf_)), "-Ofast -march=native"
             if b_fast is None:
-                b_fast, fast_label = O.ref_blocks_forked("_v3", rows_, M, wf_), "-Ofast -march=x86-64-v3"
+                b_fast, fast_label = pick(O.ref_blocks("_v3", rows_, M, wf_)), "-Ofast -march=x86-64-v3"
             if b_o2 is not None and b_fast is not None:
                 strip = lambda lst: [t[1:] for t in lst]
                 refs = dict(o2_blocks=sum(len(x) for x in b_o2), ofast_blocks=sum(len(x) for x in b_fast),
@@ -510,11 +576,18 @@ def run_case(J, name, case, args, steps, warmup, headline):
                             gpu_vs_ref_o2_blocks_differing=sum(len(set(x) ^ set(strip(got.get(c, [])))) for c, x in enumerate(b_o2)),
                             gpu_vs_ref_ofast_blocks_differing=sum(len(set(x) ^ set(strip(got.get(c, [])))) for c, x in enumerate(b_fast)),
                             builds="oracle/_ref/libacarsref.so (-O2, IEEE) vs the reference's own flags (%s): unmodified rtl.c in_callback + msk.c + "
-                                   "acars.c on the GPU's input bytes and tap tables, one channel per pass" % fast_label,
+                                   "acars.c (%s) on the GPU's input bytes and tap tables, one channel per pass, each build in a child interpreter"
+                                   % (fast_label, "blocks as its blk_thread hands them to outputmsg()" if repair else "blocks as decodeAcars queues them"),
                             cpu_seconds=round(time.perf_counter() - t_ref, 1))
         allowed = (refs["ref_fast_vs_ref_o2_blocks_differing"] if refs else 0) + 1
         parity = dict(channels_checked=ncheck, blocks=nblocks, blocks_exact_given_gpu_dm=bool(ok),
-                      blocks_exact_given_gpu_dm_means="blocks identical to the oracle's demodulator + framing fed with the dm the GPU's demodulator consumed",
+                      blocks_are=("what outputmsg() receives: checked / repaired by the device (ACG_F_REPAIR, acars.c:93-215), parity stripped, "
+                                  "dropped blocks omitted" if repair else "as decodeAcars queues them (pre-repair, --raw-blocks)"),
+                      raw_blocks_before_repair=nraw,
+                      blocks_exact_given_gpu_dm_means="blocks identical to the oracle's demodulator + framing (+ block repair) fed with the dm the GPU's demodulator consumed",
+                      msgs=(dict(records=nmsgs, exact=bool(msgs_ok), delivered=len(msgs_first),
+                                 means="acg_msg records of acg_collect_msgs (a second pass from reset) == orc_msg_split(orc_blk_process(block)) field for field "
+                                       "(output.c:486-560)") if repair else None),
                       dm_within_1e5_rel=bool(dm_ok), dm_max_abs_err=dm_err, dm_samples_per_channel=nout,
                       exact_order_mode=exact,
                       end_to_end=dict(blocks_differing=e2e_blocks_off, channels=e2e_channels_off, exact=bool(e2e_blocks_off == 0),
@@ -523,10 +596,10 @@ def run_case(J, name, case, args, steps, warmup, headline):
                                            "block = a razor-edge soft decision (|vo| < 1e-3 in noise) flipped by the 1e-7 re-association of dm"),
                       reference_builds=refs,
                       blocks_first_pass_all_channels=len(first))
-        bad = (not (ok and dm_ok) or e2e_blocks_off > allowed or
+        bad = (not (ok and dm_ok and msgs_ok) or e2e_blocks_off > allowed or
                (exact is not None and not (exact["dm_bit_identical_to_oracle"] and exact["blocks_identical_end_to_end"])))
         if bad:
-            raise SystemExit("bench[%s]: GPU output differs from the oracle: %r; first mismatch: %r" % (name, parity, first_bad))
+            raise SystemExit("bench[%s]: GPU output differs from the oracle: %r; first mismatch: %r %r" % (name, parity, first_bad, first_bad_msg))
     del dm_gpu
 
     # ---- timing.  A "pass" = the hot path once over the resident batch (the step of rounds 1-2).  `burst`: `steps` single
@@ -537,7 +610,7 @@ def run_case(J, name, case, args, steps, warmup, headline):
     # max, the shader clock is read from sysfs while the device is still busy.
     for _ in range(warmup):
         step()
-    dec.drain_frames_raw(maxfr)       # flush: the timed region starts with empty queues
+    drain()                           # flush: the timed region starts with empty queues
     warm = dec.timing()               # event sums of warm-up: the demodulator's launches are timed here only --
     dec.set_timing(2)                 # in the timed region only the down-converter (roofline) is bracketed,
                                       # event records on the demodulator stream sit on its serial launch chain
@@ -546,7 +619,7 @@ def run_case(J, name, case, args, steps, warmup, headline):
     nfr_b = 0
     for _ in range(steps):
         nfr_b += step()
-    nfr_b += dec.drain_frames_raw(maxfr)[0]
+    nfr_b += drain()
     barrier()
     dt_burst = time.perf_counter() - t0
     tim_b = dec.timing()
@@ -570,7 +643,7 @@ def run_case(J, name, case, args, steps, warmup, headline):
             clk_mid = gpu_clock_mhz(J.local)
             tele_mid = gpu_telemetry(J.local)
     clk1 = gpu_clock_mhz(J.local)              # the last call(s) are still running
-    nfr += dec.drain_frames_raw(maxfr)[0]      # the last call's blocks: all K steps fully delivered inside the timed region
+    nfr += drain()                             # the last call's results: all K steps fully delivered inside the timed region
     barrier()
     dt_local = time.perf_counter() - t0
     tim = dec.timing()
@@ -588,7 +661,7 @@ def run_case(J, name, case, args, steps, warmup, headline):
             for v in ab_vals.split(","):
                 K.tune(ab_name, v)
                 step()
-                dec.drain_frames_raw(maxfr)
+                drain()
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 clk_ab = None
@@ -596,7 +669,7 @@ def run_case(J, name, case, args, steps, warmup, headline):
                     step()
                     if i_ == steps - 2:
                         clk_ab = gpu_telemetry(J.local)
-                dec.drain_frames_raw(maxfr)
+                drain()
                 torch.cuda.synchronize()
                 ab.setdefault(v, []).append(round(nch * nout * M * steps / (time.perf_counter() - t1) / 1e6, 0))
                 ab.setdefault(v + " telemetry", []).append(clk_ab)
@@ -622,24 +695,24 @@ def run_case(J, name, case, args, steps, warmup, headline):
             others.append(d2)
             for _ in range(2):
                 step(dec=d2)
-            d2.drain_frames_raw(maxfr)
+            drain(d2)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(steps):
                 step(dec=d2)
-            d2.drain_frames_raw(maxfr)
+            drain(d2)
             torch.cuda.synchronize()
             trials.append(round(nch * nout * M * steps / (time.perf_counter() - t1) / 1e6, 0))
             alt = os.environ.get("ACG_BENCH_DECODERS_ALT")        # probe: the same decoder once more under another FIR variant
             if alt:
                 K.tune("ACG_FIR_VARIANT", alt)
                 step(dec=d2)
-                d2.drain_frames_raw(maxfr)
+                drain(d2)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 for _ in range(steps):
                     step(dec=d2)
-                d2.drain_frames_raw(maxfr)
+                drain(d2)
                 torch.cuda.synchronize()
                 trials_alt.append(round(nch * nout * M * steps / (time.perf_counter() - t1) / 1e6, 0))
                 K.tune("ACG_FIR_VARIANT", os.environ.get("ACG_FIR_VARIANT"))
@@ -667,7 +740,7 @@ def run_case(J, name, case, args, steps, warmup, headline):
              "timed_region_s": round(dt_burst, 4), "whole_job_frac_of_hbm": round(pass_bytes * steps / dt_burst / 1e9 / HBM_PEAK_GBS, 4),
              "roofline_frac": round(fir_bytes / (tim_b["fir_ms"] / max(1, tim_b["fir_launches"]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
              "note": "`steps` single passes over the batch from a cold-ish device, as rounds 1-2 timed them; not the reported value"}
-    msk_ms_step = warm["msk_ms"] / (warmup + 1) * reps
+    msk_ms_step = warm["msk_ms"] / (warmup + (2 if repair else 1)) * reps      # (the gate's one or two passes are in the sum)
     if fmt == 0:
         kname = "fir_u8_shared_kernel" if share > 1 else J.fir_kernel_name(M, nout)
     else:
@@ -697,28 +770,34 @@ def run_case(J, name, case, args, steps, warmup, headline):
                             "of the device); clocks from sysfs while the device is busy (null where the box does not expose them)"},
         "burst": burst,
         "data": "synthetic: " + data_desc,
-        "config": {"workload": "%s: %d channels/GPU x %.1f Msps %s input, one stream per channel, rtlMult=%d, ntaps=%d, a step = %d pass(es) over a "
-                               "resident batch of %d callbacks (%.3f s of signal) per channel, streamed through the library in calls of %d callbacks; "
-                               "FIR decimate + MSK demod + framing, blocks delivered to the host (one call behind)"
+        "config": {"workload": "%s: %d channels/GPU x %.1f Msps %s, one stream per channel, rtlMult=%d, ntaps=%d; step = %d pass(es) over a resident batch of "
+                               "%d callbacks/channel in calls of %d; FIR decimate + MSK demod + framing%s, delivered to the host one call behind"
                                % (case["tag"], nch, 12500 * M / 1e6, {"u8": "u8 IQ", "cs16": "CS16 IQ", "split16": "split int16 I/Q", "f32": "real f32"}[fmt_name],
-                                  M, ntaps, reps, nblk, nblk * 0.08192, cb),
+                                  M, ntaps, reps, nblk, cb, " + block repair + message split" if repair else ""),
+                   "signal_seconds_per_pass": round(nblk * 0.08192, 3),
                    "callbacks_per_call": cb,
                    "case": name, "input_format": fmt_name, "channels_per_gpu": nch, "decim": M, "ntaps": ntaps, "blocks_per_step": nblk * reps, "blocks_per_pass": nblk, "passes_per_step": reps,
                    "input_bytes_per_gpu": int(nstreams * row),
                    "realtime_channels_equiv": int(value / (12500 * M / 1e6)),
-                   "arithmetic": "u8 in, f32 down-converter and matched filter, f64 VCO/PLL/normalisation (as the reference)",
+                   "arithmetic": "%s in, f32 down-converter and matched filter, f64 VCO/PLL/normalisation (as the reference)"
+                                 % {"u8": "u8 I/Q", "cs16": "int16 I/Q", "split16": "split int16 I/Q", "f32": "real f32"}[fmt_name],
+                   "delivered": ("acg_msg records: blocks checked / repaired on the device (ACG_F_REPAIR, acars.c:93-215) and split into outputmsg()'s fields "
+                                 "(output.c:486-560) by acg_collect_msgs, inside the timed region" if repair else
+                                 "pre-repair blocks (acg_collect_frames, --raw-blocks)"),
                    "channels_total": nch_total, "blocks_decoded_timed": int(nfr_total),
+                   "contexts": "one context from acg_create, as a host gets it (no placement selection)" if not trial_ms or trial_best == 0 else "best of %d contexts (--placement-keep best)" % len(trial_ms),
                    "placement": ({"contexts_tried": len(trial_ms), "ms_per_call": [round(x, 3) for x in trial_ms], "kept": trial_best,
+                                  "spread": round(max(trial_ms) / min(trial_ms) - 1.0, 4),
                                   "fir_ms_per_launch": ([round(x, 4) for x in D.best_placed.last_fir_ms] if getattr(D.best_placed, "last_fir_ms", None) else None),
-                                  "note": "set-up, untimed: acg_placement_trial on each context (after a warm-up round) with the first call of the batch, the fastest "
-                                          "kept; up to 2048 channels (CU partition: the demodulator sets the call) the contexts within 1 % of the "
-                                          "fastest call are ranked by their down-converter launches (fir_ms_per_launch)"}
+                                  "note": "diagnostic (--placements N), untimed: N contexts alive at once, acg_placement_trial on each after a warm-up round; "
+                                          "`kept` is the one timed (0 = the first, unless --placement-keep best)"}
                                  if trial_ms else None)},
         "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "traffic_source": (traffic_src + " (rocprofv3 PMC passes of the same launch shape: 2 x FETCH_SIZE + WRITE_SIZE; "
                                         "looked up by the full kernel signature, not collected in this run)") if traffic else None,
-                     "bytes_per_launch": int(fir_bytes), "avg_launch_ms": round(fir_avg_ms, 4), "launches_per_step": lps,
+                     "bytes_per_launch": int(fir_bytes), "avg_launch_ms": round(fir_avg_ms, 4), "launches_per_step": lps * reps,
+                     "launches_per_pass": lps,
                      "timing": "HIP events around every launch of the kernel on its own stream, inside the timed region "
                                "(the demodulator of the previous call / chunk runs beside it)",
                      "frac_of_measured_copy_ceiling_6290": round(achieved / COPY_CEILING_GBS, 4)},
@@ -752,6 +831,94 @@ def run_case(J, name, case, args, steps, warmup, headline):
     return out
 
 
+MULTI_GPU_NOTE = ("no N>1 run has been measured by the builder (1-GPU boxes only): --gpus N shards channel c to rank c mod N "
+                  "(weak scaling, no data-path collective; RCCL carries the 32 B/channel config scatter, barriers and reductions)")
+
+
+def _short(s, n):
+    s = str(s)
+    return s if len(s) <= n else s[: n - 3] + "..."
+
+
+def compact_line(full):
+    """The driver-facing result line (< 4 KB) out of the full detail dict: every key the contract names, the roofline of the
+    dominant kernel, the CPU baseline, the parity verdicts, and a five-number summary per "also" case.  Pure function (a CPU
+    test feeds it a worst-case detail and measures the line)."""
+    def parity_short(p):
+        if not p:
+            return None
+        refs = p.get("reference_builds") or {}
+        ex = p.get("exact_order_mode") or {}
+        ms = p.get("msgs") or {}
+        return {"channels": p.get("channels_checked"), "blocks": p.get("blocks"), "exact_given_gpu_dm": p.get("blocks_exact_given_gpu_dm"),
+                "msgs": ms.get("records"), "msgs_exact": ms.get("exact"), "dm_within_1e5_rel": p.get("dm_within_1e5_rel"),
+                "exact_order_identical": (bool(ex.get("dm_bit_identical_to_oracle") and ex.get("blocks_identical_end_to_end")) if ex else None),
+                "end_to_end_differing": (p.get("end_to_end") or {}).get("blocks_differing"), "allowed": (p.get("end_to_end") or {}).get("allowed"),
+                "ref_builds_differing": refs.get("ref_fast_vs_ref_o2_blocks_differing")}
+
+    def parity_ok(p):
+        if not p:
+            return None
+        e = p.get("end_to_end") or {}
+        ms = p.get("msgs")
+        return bool(p.get("blocks_exact_given_gpu_dm") and p.get("dm_within_1e5_rel") and (ms is None or ms.get("exact"))
+                    and e.get("blocks_differing", 0) <= e.get("allowed", 0))
+    cfg = full.get("config", {})
+    rf = full.get("roofline", {})
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                      "vs_baseline", "dtype")}
+    line["data"] = _short(full.get("data", "synthetic"), 160)
+    line["config"] = {"workload": _short(cfg.get("workload", ""), 300), "case": cfg.get("case"), "channels_per_gpu": cfg.get("channels_per_gpu"),
+                      "decim": cfg.get("decim"), "ntaps": cfg.get("ntaps"), "callbacks_per_call": cfg.get("callbacks_per_call"),
+                      "passes_per_step": cfg.get("passes_per_step"), "input_format": cfg.get("input_format"),
+                      "delivered": _short(cfg.get("delivered", ""), 60), "contexts": _short(cfg.get("contexts", ""), 60)}
+    if cfg.get("placement"):
+        line["config"]["placement_ms_per_call"] = cfg["placement"].get("ms_per_call")
+    line["roofline"] = {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_launch", "avg_launch_ms",
+                                                "launches_per_step", "pure_reader_GBs_measured_this_run")}
+    for k in ("whole_job_frac_of_hbm", "time_dominant_kernel", "timed_region_s", "per_gpu"):
+        if k in full:
+            line[k] = full[k]
+    line["parity"] = parity_short(full.get("parity"))
+    if full.get("also"):
+        line["also"] = {}
+        for name, a in full["also"].items():
+            ar = a.get("roofline", {})
+            e = {"value": a.get("value"), "ms_per_step": a.get("ms_per_step"), "channels": a.get("config", {}).get("channels_per_gpu"),
+                 "whole_job_frac": a.get("whole_job_frac_of_hbm"), "roofline_frac": ar.get("frac"), "traffic": ar.get("traffic"),
+                 "bytes_per_launch": ar.get("bytes_per_launch"), "parity_ok": parity_ok(a.get("parity")),
+                 "blocks": (a.get("parity") or {}).get("blocks"), "e2e_differing": ((a.get("parity") or {}).get("end_to_end") or {}).get("blocks_differing")}
+            if a.get("config", {}).get("placement"):
+                e["placement_ms_per_call"] = a["config"]["placement"].get("ms_per_call")
+            if "hostfed" in a:
+                e["hostfed"] = a["hostfed"]
+            if "per_gpu" in a:
+                e["per_gpu"] = a["per_gpu"]
+            line["also"][name] = e
+    cb = full.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                                "sample": _short(cb.get("sample", ""), 120), "all_cores": cb.get("all_cores"), "gpu_over_cpu": cb.get("gpu_over_cpu")}
+    line["multi_gpu"] = _short(full.get("multi_gpu", ""), 120)
+    line["detail"] = "bench_detail.json / the '# bench_detail:' stdout line"
+    # the budget is enforced, not hoped for: optional keys go, least important first, until the line fits
+    size = lambda: len(json.dumps(line, separators=(",", ":")))
+    also = line.get("also", {})
+    trims = ([lambda a=a: a.pop("placement_ms_per_call", None) for a in also.values()] +
+             [lambda a=a: a.pop("bytes_per_launch", None) for a in also.values()] +
+             [lambda a=a: a.__setitem__("per_gpu", [int(round(x)) for x in a["per_gpu"]]) if "per_gpu" in a else None for a in also.values()] +
+             [lambda: line.__setitem__("data", _short(line["data"], 60)),
+              lambda: line["config"].__setitem__("workload", _short(line["config"]["workload"], 160)),
+              lambda: line.__setitem__("multi_gpu", _short(line["multi_gpu"], 60))] +
+             [lambda a=a: a.pop("traffic", None) for a in also.values()] +
+             [lambda a=a: a.pop("per_gpu", None) for a in also.values()])
+    for t in trims:
+        if size() <= 3900:
+            break
+        t()
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -773,10 +940,16 @@ def main():
                     help="channels per input stream (rtl.c's own shape: one dongle feeds up to 16 channels); >1 = shared-stream "
                          "mode, VALU-bound, reported separately and never as the roofline figure (SURVEY 8d)")
     ap.add_argument("--bitlog", type=int, default=1, help="1: the demodulator also writes its per-bit soft symbols (vo, level: 8 B per bit) to HBM")
-    ap.add_argument("--placements", type=int, default=4,
-                    help="contexts tried with acg_placement_trial before the run (set-up, untimed), the fastest kept; the trial times of all "
-                         "of them are on the line (config.placement: the first entry is the context a host without the trial would have). "
-                         "1 = take the first.  Round 3 found no layout rule behind the differences (DESIGN 4.1)")
+    ap.add_argument("--placements", type=int, default=1,
+                    help="diagnostic: N contexts alive at once, acg_placement_trial on each before the run (untimed); their times go to "
+                         "config.placement.  The context that is timed is the FIRST one (what a host gets from acg_create) unless "
+                         "--placement-keep best")
+    ap.add_argument("--placement-keep", choices=["first", "best"], default="first")
+    ap.add_argument("--raw-blocks", action="store_true",
+                    help="time the pre-repair blocks (acg_collect_frames without ACG_F_REPAIR) as rounds 1-3 did, instead of the "
+                         "delivered acg_msg records")
+    ap.add_argument("--detail-file", default=None, help="where the full per-case detail goes (default: bench_detail.json next to bench.py, "
+                                                        "and gpurun_out/ when that exists)")
     ap.add_argument("--decoders", type=int, default=1, help="measurement aid: time this many decoders (separate allocations) in the same process")
     ap.add_argument("--ab", default=None, help="measurement aid: comma-separated ACG_FIR_VARIANT values (or NAME=v1,v2 for another per-launch "
                                                "switch, e.g. ACG_MSK_LPC_LIVE=2,4) timed after the run in the same process, same decoder")
@@ -859,7 +1032,7 @@ def main():
     elif overridden or args.format != "u8" or args.share > 1:
         also = []
     else:
-        also = ["wide", "stress", "cs16", "f32"] if world == 1 else ["shard2048"]
+        also = ["wide", "stress", "shard2048", "cs16", "f32"] if world == 1 else ["shard2048"]
         also = [a for a in also if a != args.config]
     cases = [(args.config, case)] + [(a, dict(CASES[a])) for a in also]
     # with several ranks sharing one GPU (gloo rehearsal) keep the footprint small
@@ -907,7 +1080,7 @@ def main():
                                                  "serial recurrence, latency-bound), see whole_job_frac_of_hbm" % out["time_dominant_kernel"])
         if len(res) > 1:
             out["also"] = {name: {k: r[k] for k in ("value", "ms_per_step", "timed_region_s", "sustain", "burst", "whole_job_frac_of_hbm", "whole_job_GBs_per_gpu",
-                                                    "time_dominant_kernel", "roofline", "kernels", "parity", "config", "data") if k in r}
+                                                    "time_dominant_kernel", "roofline", "kernels", "parity", "config", "data", "hostfed") if k in r}
                            for (name, _), r in zip(cases[1:], res[1:])}
             for name, r in zip([n for n, _ in cases[1:]], res[1:]):
                 if "per_gpu" in r:
@@ -915,7 +1088,22 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = run_cpu_baseline(case["decim"])
             out["cpu_baseline"]["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
-        print(json.dumps(out))
+        out["multi_gpu"] = MULTI_GPU_NOTE
+        # 1. the full detail: an EARLIER stdout line (not JSON-looking: it does not start with "{") and a file
+        detail = json.dumps(out)
+        print("# bench_detail: " + detail, flush=True)
+        paths = [args.detail_file] if args.detail_file else [os.path.join(ROOT, "bench_detail.json")] + (
+            [os.path.join(ROOT, "gpurun_out", "bench_detail.json")] if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else [])
+        for pth in paths:
+            try:
+                with open(pth, "w") as f:
+                    f.write(detail + "\n")
+            except OSError:
+                pass
+        # 2. the result: ONE compact line, last on stdout
+        line = json.dumps(compact_line(out), separators=(",", ":"))
+        assert len(line) < 4096, len(line)
+        print(line, flush=True)
     if J.coll is not None:
         dist.barrier(device_ids=[local]) if J.backend == "nccl" else dist.barrier()
         dist.destroy_process_group()

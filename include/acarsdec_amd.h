@@ -32,8 +32,11 @@ extern "C" {
 #define ACG_ENOMEM     -2   /* host or device allocation failed */
 #define ACG_EHIP       -3   /* HIP runtime error (acg_last_error has the text) */
 #define ACG_ENODEV     -4   /* no usable GPU: the library has NO CPU fallback */
-#define ACG_EOVERFLOW  -5   /* an output queue was too small; results truncated */
+#define ACG_EOVERFLOW  -5   /* results were LOST: the device lapped the block queue (the host collected too rarely), or a per-bit
+                               log was longer than its buffer; what could be handed out has been */
 #define ACG_ESTATE     -6   /* call sequence error */
+#define ACG_EAGAIN     -7   /* drain/collect: the caller's buffer is full and more results are queued -- nothing is lost,
+                               call again */
 
 #define ACG_INTRATE     12500     /* acarsdec.h:31 */
 #define ACG_BLOCK       1024      /* rtl.c:49 RTLOUTBUFSZ: outputs per reference callback */
@@ -66,6 +69,9 @@ typedef struct {
 	int ntaps;          /* complex taps per channel, 1..decim.  Reference: ntaps == decim */
 	int max_blocks;     /* capacity: 1024-output blocks per acg_process_* call */
 	uint32_t flags;
+	int max_lag;        /* most process calls acg_collect_* may stay behind (sizes the block queue: the worst case of
+	                       max_lag + 1 calls).  0 = as many as fit into 512 MiB, at most 6; a host that collects with
+	                       lag <= 1 after every call asks for 1 and gets the smallest queue */
 } acg_config;
 
 /* MSK + framing fields of channel_t (acarsdec.h:76-89) */
@@ -197,22 +203,24 @@ int  acg_feed_samples_host(acg_ctx *ctx, int fmt, const void *p0, const void *p1
 			   size_t nsamples);
 
 /* ---- results ------------------------------------------------------------------------------ */
-/* Blocks completed since the last drain/collect, ordered by (chn, end_bit).  Waits for ALL
- * enqueued work of the context. */
+/* Blocks completed since the last drain/collect, ordered by (chn, end_bit) within the call.  Waits for ALL
+ * enqueued work of the context.  If more blocks are queued than max_frames, the oldest max_frames are handed out, the
+ * rest STAY queued and the call returns ACG_EAGAIN (call again: across calls the order is completion order). */
 int  acg_drain_frames(acg_ctx *ctx, acg_frame *out, int max_frames, int *nframes);
 /* Streaming variant: hands over the blocks of every process call except the `lag` most recent
  * ones and waits only for those older calls, so that the newest call(s) keep the GPU busy
  * (lag = 1: classic double buffering; lag = 0: wait for the last call only).  0 <= lag <= acg_max_lag(). */
 int  acg_collect_frames(acg_ctx *ctx, int lag, acg_frame *out, int max_frames, int *nframes);
 /* Largest lag this context accepts: its block queue is sized for the worst case (a 56-bit block every 291 samples on
- * every channel) of acg_max_lag() + 1 calls, so a host that collects after every call cannot be lapped.  6 unless that
- * would take more than 512 MiB (then fewer, at least 1). */
+ * every channel) of acg_max_lag() + 1 calls, so a host that collects after every call cannot be lapped.
+ * acg_config.max_lag if that was given, else 6 unless that would take more than 512 MiB (then fewer, at least 1). */
 int  acg_max_lag(const acg_ctx *ctx);
 /* SURVEY 8f.4, the batch sink: like acg_drain_frames / acg_collect_frames, but every block is taken through
  * outputmsg()'s field split on the device and handed over as a fixed binary record.  Needs ACG_F_REPAIR (outputmsg()
- * receives repaired, parity-stripped blocks); blocks the repair drops are omitted.  Ordered by (chn, end_bit).  If more
- * messages are queued than max_msgs, the oldest max_msgs are handed out, the rest STAY queued and the call returns
- * ACG_EOVERFLOW ("call again"); every byte of a record is defined (unused text bytes are 0). */
+ * receives repaired, parity-stripped blocks); blocks the repair drops are omitted.  Ordered by (chn, end_bit) within the
+ * call.  A call looks at the oldest max_msgs queued blocks only (splits, copies and consumes exactly those); if more are
+ * queued they STAY queued and the call returns ACG_EAGAIN ("call again"; across calls the order is completion order).
+ * Every byte of a record is defined (unused text bytes are 0). */
 int  acg_drain_msgs(acg_ctx *ctx, acg_msg *out, int max_msgs, int *nmsgs);
 int  acg_collect_msgs(acg_ctx *ctx, int lag, acg_msg *out, int max_msgs, int *nmsgs);
 /* Per-bit records of the LAST process call for one channel (needs ACG_F_BITLOG):

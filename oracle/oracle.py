@@ -467,56 +467,62 @@ def wav_to_float(pcm16):
 
 
 # --------------------------------------------------------------------------- reference builds against each other
-def ref_blocks_forked(variant, rows, M, taps, timeout_s=600):
+def _ref_blocks_child(variant, path_in, path_out):
+    """child side of ref_blocks: a FRESH interpreter (the reference is all global state, an -march=native build may hit an
+    illegal instruction on this host, and forking a process that holds a GPU runtime can deadlock on a lock whose owner
+    thread does not exist in the child -- ADVICE r03)."""
+    import pickle
+    z = np.load(path_in)
+    rows, taps, M = z["rows"], z["taps"], int(z["M"])
+    os.dup2(os.open(os.devnull, os.O_WRONLY), 2)          # initRtl narrates on stderr
+    blk = 1024 * M * 2
+    ref = Ref(variant)
+    grab = lambda fr: [(int(f.len), int(f.err), bytes(f.crc), bytes(f.txt[: max(0, f.len)])) for f in fr]
+    raw, out = [], []
+    for c in range(rows.shape[0]):
+        ref.init_rtl(["131.725"], M)                      # one channel; its state is re-initialised by every init
+        ref.set_wf(0, taps[c])
+        r = np.ascontiguousarray(rows[c]).reshape(-1)
+        for b in range(r.size // blk):
+            ref.in_callback(r[b * blk:(b + 1) * blk])
+        ref.drain()                                       # blk_thread's pass over what decodeAcars queued (acars.c:93-215)
+        raw.append(grab(ref.raw_frames()))
+        out.append(grab(ref.out_frames()))
+    with open(path_out, "wb") as w:
+        pickle.dump(dict(raw=raw, out=out), w)
+
+
+def ref_blocks(variant, rows, M, taps, timeout_s=600):
     """The UNMODIFIED reference build `variant` ("" = -O2 IEEE, "_fast" = the reference's own -Ofast -march=native,
     "_v3") run over rows[c] (u8 I/Q of whole callbacks) with channel c's tap table taps[c], one channel per pass, through
-    its own in_callback -> demodMSK -> decodeAcars.  Returns [blocks of channel c as (len, err, crc, txt)] or None when
-    the build is missing or cannot run on this host (an -march=native build may hit an illegal instruction elsewhere).
-    Runs in a forked child: the reference is all global state, and a crash must not take the caller down.  The child
-    touches only numpy and the reference library (no GPU runtime calls after the fork)."""
+    its own in_callback -> demodMSK -> decodeAcars -> blk_thread.  Returns {"raw": [...], "out": [...]}: per channel the
+    blocks as decodeAcars queued them and as outputmsg() received them, each (len, err, crc, txt) -- or None when the build
+    is missing or cannot run on this host.  Runs in a child interpreter; rows and taps travel through a temporary file."""
     import pickle
-    import select
-    import signal
-    import time
+    import sys
+    import tempfile
     if not ref_available(variant):
         return None
-    blk = 1024 * M * 2
-    rfd, wfd = os.pipe()
-    pid = os.fork()
-    if pid == 0:
-        rc = 1
+    with tempfile.TemporaryDirectory() as td:
+        pin, pout = os.path.join(td, "in.npz"), os.path.join(td, "out.pkl")
+        tp = np.zeros((len(taps), M, 2), dtype=np.float32)     # (a shorter table is zero-filled, as ref_set_wf does anyway)
+        for c, t in enumerate(taps):
+            t = np.ascontiguousarray(t, dtype=np.float32).reshape(-1, 2)
+            tp[c, : t.shape[0]] = t
+        np.savez(pin, rows=np.stack([np.ascontiguousarray(r).reshape(-1) for r in rows]), taps=tp, M=M)
+        code = "import sys; sys.path.insert(0, %r); from oracle import oracle as O; O._ref_blocks_child(%r, %r, %r)" % (
+            os.path.dirname(HERE), variant, pin, pout)
         try:
-            os.close(rfd)
-            os.dup2(os.open(os.devnull, os.O_WRONLY), 2)      # initRtl narrates on stderr
-            ref = Ref(variant)
-            out = []
-            for c in range(len(rows)):
-                ref.init_rtl(["131.725"], M)               # one channel; its state is re-initialised by every init
-                ref.set_wf(0, taps[c])
-                r = np.ascontiguousarray(rows[c]).reshape(-1)
-                for b in range(r.size // blk):
-                    ref.in_callback(r[b * blk:(b + 1) * blk])
-                out.append([(int(f.len), int(f.err), bytes(f.crc), bytes(f.txt[: max(0, f.len)])) for f in ref.raw_frames()])
-            with os.fdopen(wfd, "wb") as w:
-                pickle.dump(out, w)
-            rc = 0
-        finally:
-            os._exit(rc)
-    os.close(wfd)
-    data = b""
-    t0 = time.time()
-    with os.fdopen(rfd, "rb") as r:
-        while True:
-            left = timeout_s - (time.time() - t0)
-            if left <= 0:
-                os.kill(pid, signal.SIGKILL)
-                break
-            if select.select([r], [], [], min(left, 1.0))[0]:
-                chunk = os.read(r.fileno(), 1 << 20)
-                if not chunk:
-                    break
-                data += chunk
-    _, status = os.waitpid(pid, 0)
-    if status != 0 or not data:
-        return None
-    return pickle.loads(data)
+            r = subprocess.run([sys.executable, "-c", code], capture_output=True, timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            return None
+        if r.returncode != 0 or not os.path.exists(pout):
+            return None
+        with open(pout, "rb") as f:
+            return pickle.load(f)
+
+
+def ref_blocks_forked(variant, rows, M, taps, timeout_s=600):
+    """raw blocks only (the name is historical: the child is a fresh interpreter now, see ref_blocks)"""
+    d = ref_blocks(variant, rows, M, taps, timeout_s)
+    return None if d is None else d["raw"]

@@ -13,10 +13,27 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def last_json(text):
-    lines = [l for l in text.splitlines() if l.startswith("{")]
-    assert lines, text[-2000:]
+def compact_json(text):
+    """the driver-facing result: the LAST stdout line, compact (< 4 KB)"""
+    lines = [l for l in text.splitlines() if l.strip()]
+    assert lines and lines[-1].startswith("{"), text[-2000:]
+    assert len(lines[-1]) < 4096, len(lines[-1])
+    assert len([l for l in lines if l.startswith("{")]) == 1          # one JSON-looking line per run
     return json.loads(lines[-1])
+
+
+def last_json(text):
+    """the full detail: the earlier '# bench_detail: {...}' line (also written to bench_detail.json)"""
+    lines = [l for l in text.splitlines() if l.startswith("# bench_detail: ")]
+    assert len(lines) == 1, text[-2000:]
+    compact_json(text)
+    return json.loads(lines[0][len("# bench_detail: "):])
+
+
+def par_msgs(d):
+    m = d["parity"]["msgs"]
+    assert m["exact"] is True and m["delivered"] >= m["records"]
+    return m["records"]
 
 
 def test_bench_line_contract():
@@ -24,9 +41,18 @@ def test_bench_line_contract():
                         "--no-cpu-baseline", "--sustain", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     d = last_json(r.stdout)
+    c = compact_json(r.stdout)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline"):
-        assert k in d, k
+        assert k in d and k in c, k
+    assert c["value"] == d["value"] and c["ms_per_step"] == d["ms_per_step"] and c["roofline"]["frac"] == d["roofline"]["frac"]
+    assert c["parity"]["exact_given_gpu_dm"] is True and c["parity"]["msgs_exact"] is True and c["parity"]["exact_order_identical"] is True
+    assert c["config"]["channels_per_gpu"] == 256 and "workload" in c["config"] and "acg_msg" in c["config"]["delivered"]
+    assert c["roofline"]["launches_per_step"] == d["roofline"]["launches_per_pass"] * d["sustain"]["passes_per_step"]
+    # the delivered path is what is timed: repaired blocks -> acg_msg records, and the gate compared every field of them
+    assert par_msgs(d) > 0 and "ACG_F_REPAIR" in d["config"]["delivered"]
+    with open(os.path.join(ROOT, "bench_detail.json")) as f:
+        assert json.load(f)["value"] == d["value"]
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1 and d["roofline"]["peak"] == 8000.0
     par = d["parity"]
@@ -50,11 +76,15 @@ def test_bench_also_cases_in_one_line():
     code = ("import sys, bench; bench.CASES['throughput'].update(channels=128, blocks=12); "
             "bench.CASES['wide'].update(channels=512, blocks=2); bench.CASES['stress'].update(channels=256, blocks=2); "
             "bench.CASES['cs16'].update(channels=256, blocks=2); bench.CASES['f32'].update(channels=256, blocks=2); "
+            "bench.CASES['shard2048'].update(channels=192, blocks=4); "
             "sys.argv = ['bench.py', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--sustain', '0.5']; bench.main()")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     d = last_json(r.stdout)
-    assert set(d["also"]) == {"wide", "stress", "cs16", "f32"}
+    assert set(d["also"]) == {"wide", "stress", "shard2048", "cs16", "f32"}
+    c = compact_json(r.stdout)
+    assert set(c["also"]) == set(d["also"]) and all(a["parity_ok"] is True for a in c["also"].values())
+    assert c["also"]["shard2048"]["channels"] == 192 and "u8" not in d["also"]["cs16"]["config"]["arithmetic"]
     for name, a in d["also"].items():
         assert a["parity"]["dm_within_1e5_rel"] is True and a["parity"]["blocks_exact_given_gpu_dm"] is True and a["parity"]["channels_checked"] == 64
         if name not in ("cs16", "f32"):                   # (the exact-order mode restates rtl.c's u8 loop)
@@ -84,8 +114,8 @@ def test_bench_gpus_flag_self_launch():
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     d = last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["channels_total"] == 512 and len(d["per_gpu"]) == 2
-    assert len([l for l in r.stdout.splitlines() if l.startswith("{")]) == 1
     assert d["parity"]["blocks_exact_given_gpu_dm"] is True and d["parity"]["channels_checked"] == 64
+    assert len(compact_json(r.stdout)["per_gpu"]) == 2
     # without the rehearsal backend a 1-GPU box must refuse 2 ranks instead of running one
     import torch
     if torch.cuda.device_count() < 2:
@@ -105,7 +135,7 @@ def test_bench_two_ranks_rehearsal():
     d = last_json(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["channels_per_gpu"] == 256 and d["config"]["channels_total"] == 512
     assert d["parity"]["blocks_exact_given_gpu_dm"] is True
-    assert len([l for l in r.stdout.splitlines() if l.startswith("{")]) == 1          # rank 0 alone reports
+    compact_json(r.stdout)                                                             # rank 0 alone reports: one result line
     # whole-job aggregate: both ranks' samples over the slowest rank's time
     assert abs(d["value"] - 2 * 256 * 8 * 1024 * 200 * 4 / (d["ms_per_step"] * 4e-3) / 1e6) < 1e-3 * d["value"]
 

@@ -566,9 +566,10 @@ def test_device_message_split_matches_reference_json_and_oracle(D, O, msgsplit_g
 
 
 def test_message_drain_keeps_what_does_not_fit_and_records_are_fully_defined(D, msgsplit_golden):
-    """a drain into a buffer that is too small hands out the OLDEST messages that fit, reports ACG_EOVERFLOW
-    ("call again") and keeps the rest queued -- nothing is lost; and every byte of a record is defined (the device staging
-    buffer comes from hipMalloc: the split clears the record before it fills it)."""
+    """A drain into a buffer that is too small hands out the OLDEST messages that fit, reports ACG_EAGAIN ("call again")
+    and keeps the rest queued -- nothing is lost; every byte of a record is defined (the device staging buffer comes from
+    hipMalloc: the split clears the record before it fills it); the Python wrappers loop on ACG_EAGAIN instead of raising
+    (ADVICE r03), and the block drain has the same keep-the-rest contract."""
     from acarsdec_amd import _capi as K
     pcm, want = msgsplit_golden
     x = pcm.astype(np.float32) / 32768.0
@@ -583,13 +584,13 @@ def test_message_drain_keeps_what_does_not_fit_and_records_are_fully_defined(D, 
         buf = (K.Msg * 7)()
         n = C.c_int(0)
         rc = dec.L.acg_drain_msgs(dec.ctx, buf, 7, C.byref(n))
-        assert rc in (K.OK, K.EOVERFLOW), rc
+        assert rc in (K.OK, K.EAGAIN), rc
         got += [K.Msg.from_buffer_copy(buf[i]) for i in range(n.value)]
         rounds += 1
         if rc == K.OK:
             break
-        assert n.value == 7                                     # a full buffer every time there is more
-    assert len(got) == total and rounds == (total + 6) // 7
+        assert 0 < n.value <= 7 and b"call again" in dec.L.acg_last_error(dec.ctx)
+    assert len(got) == total and rounds >= (total + 6) // 7
     ref = dec2 = None
     dec2 = D.Decoder(2, decim=8, ntaps=8, max_blocks=chunk // 1024, repair=True, bitlog=False)
     for s in range(0, x.size, chunk):
@@ -597,6 +598,32 @@ def test_message_drain_keeps_what_does_not_fit_and_records_are_fully_defined(D, 
     ref = dec2.drain_msgs(4096)
     key = lambda m: (int(m.chn), int(m.end_bit))
     assert sorted(bytes(m) for m in got) == sorted(bytes(m) for m in ref) and len({key(m) for m in got}) == total
+    # the wrappers: a small buffer is looped over, never raised on; collect (lag 0) likewise
+    for take in ("drain", "collect"):
+        d3 = D.Decoder(2, decim=8, ntaps=8, max_blocks=chunk // 1024, repair=True, bitlog=False, max_lag=1)
+        assert d3.max_lag == 1
+        some = []
+        for s0 in range(0, x.size, chunk):
+            d3.demod_msk(np.tile(x[s0:s0 + chunk], (2, 1)))
+            some += d3.collect_msgs(lag=0, max_msgs=5) if take == "collect" else []
+        some += d3.drain_msgs(5)
+        assert sorted(bytes(m) for m in some) == sorted(bytes(m) for m in ref), take
+        d3.close()
+    # blocks: the same keep-the-rest contract
+    d4 = D.Decoder(2, decim=8, ntaps=8, max_blocks=chunk // 1024, repair=True, bitlog=False)
+    for s0 in range(0, x.size, chunk):
+        d4.demod_msk(np.tile(x[s0:s0 + chunk], (2, 1)))
+    fb = (K.Frame * 3)()
+    nfr, codes = 0, set()
+    while True:
+        rc = d4.L.acg_drain_frames(d4.ctx, fb, 3, C.byref(n))
+        codes.add(rc)
+        nfr += n.value
+        if rc != K.EAGAIN:
+            break
+    assert rc == K.OK and nfr == total and K.EAGAIN in codes
+    assert len(d4.drain_frames(5)) == 0
+    d4.close()
     for m in got:                                               # text beyond txt_len and the reserved fields are zero
         assert bytes(m.txt[m.txt_len:]) == bytes(242 - m.txt_len) and m.reserved0 == 0.0 and m.reserved1 == 0
     dec.close()

@@ -314,3 +314,38 @@ def test_host_side_under_address_and_undefined_behaviour_sanitizers(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "sanitized host driver: ok" in r.stdout, (r.stdout[-500:], r.stderr[-3000:])
     assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+
+
+def test_bench_compact_line_stays_under_4k_at_the_full_case_shape():
+    """the driver keeps a bounded tail of stdout and could not recover round 3's 26 KB line.  bench.py's last
+    stdout line is compact_line(detail): fed the real round-3 detail (five cases) widened to the round-4 shape (seven "also"
+    cases, placement diagnostics and per-GPU lists of an 8-GPU run on every one) it must stay under 4 KB and carry every key
+    of the contract plus roofline and cpu_baseline."""
+    import json
+    import bench
+    with open(os.path.join(ROOT, "profiles", "r03_bench_line.json")) as f:
+        d = json.load(f)
+    for extra in ("shard2048", "hostfed"):
+        d["also"][extra] = json.loads(json.dumps(d["also"]["wide"]))
+    d["also"]["hostfed"]["hostfed"] = {"h2d_GBs": 55.12, "frac_of_h2d": 0.931, "realtime_10000ch": True, "value_needed_for_realtime": 25000}
+    d["multi_gpu"] = bench.MULTI_GPU_NOTE
+    d["per_gpu"] = [1364179.5] * 8
+    d["config"].update(delivered="acg_msg records: " + "x" * 300, contexts="one context from acg_create " + "y" * 100)
+    for a in list(d["also"].values()) + [d]:
+        a["config"]["placement"] = {"ms_per_call": [5.255, 4.527, 4.521, 5.313]}
+        a["parity"]["msgs"] = {"records": 762, "exact": True, "delivered": 12000}
+    for a in d["also"].values():
+        a["per_gpu"] = [3047963.0] * 8
+    line = json.dumps(bench.compact_line(d), separators=(",", ":"))
+    assert len(line) < 4096, len(line)
+    c = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "parity", "also"):
+        assert k in c, k
+    assert c["config"]["workload"] and c["config"]["channels_per_gpu"] == 1024 and c["config"]["callbacks_per_call"] == 8
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_launch", "avg_launch_ms", "launches_per_step"):
+        assert k in c["roofline"], k
+    assert c["cpu_baseline"]["kind"] == "reference" and c["cpu_baseline"]["cores"] == 1 and c["cpu_baseline"]["all_cores"]["processes"] == 64
+    assert c["parity"]["exact_given_gpu_dm"] is True and c["parity"]["msgs_exact"] is True and c["parity"]["ref_builds_differing"] == 1
+    assert set(c["also"]) == {"wide", "stress", "cs16", "f32", "shard2048", "hostfed"}
+    assert all(a["parity_ok"] is True and 0 < a["roofline_frac"] < 1 for a in c["also"].values())
