@@ -40,51 +40,54 @@ def hipcc():
 
 
 LIB_POLY = os.path.join(LIBDIR, "libacarsdec_amd_poly.so")
+LIB_LAB = os.path.join(LIBDIR, "libacarsdec_amd_lab.so")
+
+# -ffp-contract=off keeps the reference's separate mul/add roundings.  The -mllvm switches only move
+# instructions and shape control flow: the demodulator is one long dependent chain per wave, and
+# ILP-first scheduling without machine sinking / branch folding / tail duplication, uniform regions
+# left unstructured and small diamonds folded into selects measured 13 % faster per bit
+# (1.160 -> 1.005 us; profiles/probe/msk_only.py) than the default heuristics.
+MSK_FLAGS = ["-O3", "-ffp-contract=off", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-disable-machine-sink",
+             "-mllvm", "-disable-branch-fold", "-mllvm", "-disable-tail-duplicate",
+             "-mllvm", "-structurizecfg-skip-uniform-regions", "-mllvm", "-phi-node-folding-threshold=4"]
+# unit -> (flags, in the product library?).  msk2.hip (the two-wave demodulator: bit-identical and slower) is lab only.
+UNITS = [("fir.hip", ["-O3"], True), ("msk.hip", MSK_FLAGS, True), ("msk2.hip", MSK_FLAGS, False), ("synth.hip", ["-O3"], True),
+         ("blk.hip", ["-O3"], True), ("acg_api.cpp", ["-O2"], True)]
+# which units see which define (the others are compiled once and shared between the libraries)
+SEES = {"-DACG_LAB": ("fir.hip", "msk2.hip", "acg_api.cpp"), "-DACG_MSK_STAMP": ("msk.hip", "msk2.hip", "acg_api.cpp"),
+        "-DACG_MSK_SINCOS_POLY": ("msk.hip", "msk2.hip")}
 
 
-def build_lib(force=False, stamp=False, poly=False):
-    """stamp=True: the measurement build (lib/libacarsdec_amd_stamp.so, -DACG_MSK_STAMP: s_memtime stamps in the
-    demodulator's per-bit loop, read by profiles/probe/msk_phase_stamps.py); never loaded by the product.
-    poly=True: the checking build (lib/libacarsdec_amd_poly.so, -DACG_MSK_SINCOS_POLY: the mixer's sin/cos as the < 1 ulp
-    Cody-Waite + fdlibm-kernel evaluation instead of table + rotation); a GPU test runs it beside the product build and
-    wants identical bits and state (tests/test_gpu_parity.py); never loaded by the product either."""
+def build_lib(force=False, stamp=False, poly=False, lab=False):
+    """The library in one of four shapes:
+      (default)  lib/libacarsdec_amd.so        THE PRODUCT: the default down-converter kernels (wave-private direct, workgroup-
+                                               granular fallback, shared-stream, exact-order, the other sample formats), the
+                                               one-wave demodulator, block repair / message split, generators;
+      lab=True   lib/libacarsdec_amd_lab.so    + -DACG_LAB: every measurement variant (ACG_FIR_VARIANT 0-4, 6-8, 50-56, 70-73),
+                                               the two-wave demodulator (msk2.hip), debug shapes -- loaded by tests and probes only;
+      stamp=True lib/libacarsdec_amd_stamp.so  the lab build + -DACG_MSK_STAMP (s_memtime stamps in the demodulator's per-bit loop,
+                                               read by profiles/probe/msk_phase_stamps.py);
+      poly=True  lib/libacarsdec_amd_poly.so   the lab build with -DACG_MSK_SINCOS_POLY (the mixer's sin/cos as the < 1 ulp Cody-Waite +
+                                               fdlibm-kernel evaluation instead of table + rotation); a GPU test runs it beside the
+                                               lab build (whose one-wave demodulator is the product's object file) and wants
+                                               identical bits and state from both demodulator kernels.
+    Only the first is ever loaded by the product path (acarsdec_amd/_capi.py load())."""
     os.makedirs(OBJDIR, exist_ok=True)
-    tag = "_stamp" if stamp else "_poly" if poly else ""
-    extra = ["-DACG_MSK_STAMP"] if stamp else ["-DACG_MSK_SINCOS_POLY"] if poly else []
-    out_lib = LIB_STAMP if stamp else LIB_POLY if poly else LIB
+    defs = (["-DACG_LAB"] if (lab or stamp or poly) else []) + (["-DACG_MSK_STAMP"] if stamp else []) + (["-DACG_MSK_SINCOS_POLY"] if poly else [])
+    out_lib = LIB_STAMP if stamp else LIB_POLY if poly else LIB_LAB if lab else LIB
     hdrs = [os.path.join(CSRC, "acg_internal.h"), os.path.join(CSRC, "msk_common.h"), os.path.join(INC, "acarsdec_amd.h"),
             os.path.abspath(__file__)]   # flags live here
-    units = [
-        ("fir.hip", ["-O3"]),
-        # -ffp-contract=off keeps the reference's separate mul/add roundings.  The -mllvm switches only move
-        # instructions and shape control flow: the demodulator is one long dependent chain per wave, and
-        # ILP-first scheduling without machine sinking / branch folding / tail duplication, uniform regions
-        # left unstructured and small diamonds folded into selects measured 13 % faster per bit
-        # (1.160 -> 1.005 us; profiles/probe/msk_only.py) than the default heuristics.
-        ("msk.hip", ["-O3", "-ffp-contract=off", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-disable-machine-sink",
-                     "-mllvm", "-disable-branch-fold", "-mllvm", "-disable-tail-duplicate",
-                     "-mllvm", "-structurizecfg-skip-uniform-regions", "-mllvm", "-phi-node-folding-threshold=4"]),
-        ("msk2.hip", ["-O3", "-ffp-contract=off", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-disable-machine-sink",
-                      "-mllvm", "-disable-branch-fold", "-mllvm", "-disable-tail-duplicate",
-                      "-mllvm", "-structurizecfg-skip-uniform-regions", "-mllvm", "-phi-node-folding-threshold=4"]),
-        ("synth.hip", ["-O3"]),
-        ("blk.hip", ["-O3"]),
-        ("acg_api.cpp", ["-O2"]),
-    ]
     objs = []
     hc = hipcc()
-    for name, flags in units:
+    for name, flags, in_product in UNITS:
+        if not in_product and "-DACG_LAB" not in defs:
+            continue
+        mine = [d for d in defs if name in SEES[d]]
+        tag = "".join("_" + d[6:].lower() for d in mine)          # e.g. fir.hip_lab.o, msk.hip_msk_stamp.o
         src = os.path.join(CSRC, name)
-        if poly and name not in ("msk.hip", "msk2.hip"):
-            objs.append(os.path.join(OBJDIR, name + ".o"))
-            continue
-        if stamp and name not in ("msk.hip", "msk2.hip", "acg_api.cpp"):
-            objs.append(os.path.join(OBJDIR, name + ".o"))          # unchanged units are shared with the product build
-            continue
         obj = os.path.join(OBJDIR, name + tag + ".o")
         if force or _newer([src] + hdrs, obj):
-            _run([hc, "--offload-arch=" + ARCH, "-std=c++17", "-fPIC", "-I" + INC, "-I" + CSRC] + flags + extra +
-                 ["-c", src, "-o", obj])
+            _run([hc, "--offload-arch=" + ARCH, "-std=c++17", "-fPIC", "-I" + INC, "-I" + CSRC] + flags + mine + ["-c", src, "-o", obj])
         objs.append(obj)
     src = os.path.join(CSRC, "host_setup.c")
     obj = os.path.join(OBJDIR, "host_setup.o")
@@ -129,11 +132,29 @@ def build_demo_rtl(force=False):
     return DEMO_RTL
 
 
+MULTIDEV = os.path.join(LIBDIR, "host_multidev")
+
+
+def build_multidev(force=False):
+    """tests/multidev/host_multidev.c: a plain-C host (gcc, no hipcc) that drives one context per GPU through the C ABI;
+    it allocates its device input with the HIP runtime's C API, hence -lamdhip64."""
+    build_lib()
+    src = os.path.join(os.path.dirname(HERE), "tests", "multidev", "host_multidev.c")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    if force or _newer([src, LIB, os.path.join(INC, "acarsdec_amd.h")], MULTIDEV):
+        _run(["gcc", "-O2", "-Wall", "-Wextra", "-I" + INC, "-I" + os.path.join(rocm, "include"), src, "-o", MULTIDEV,
+              "-L" + LIBDIR, "-lacarsdec_amd", "-L" + os.path.join(rocm, "lib"), "-lamdhip64",
+              "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(rocm, "lib"), "-lm"])
+    return MULTIDEV
+
+
 def build_all(force=False):
     lib = build_lib(force)
+    build_lib(force, lab=True)
     build_lib(force, poly=True)
     demo = build_demo(force)
     build_demo_rtl(force)
+    build_multidev(force)
     return lib, demo
 
 

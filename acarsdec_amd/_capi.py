@@ -6,6 +6,8 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # ACARSDEC_AMD_LIB: measurement aid (A/B timing of two builds on one box, the stamp build); the product is the in-tree path
 LIB_PATH = os.environ.get("ACARSDEC_AMD_LIB") or os.path.join(HERE, "lib", "libacarsdec_amd.so")
+# the lab build: every measurement kernel variant and debug shape; tests and probes only (Decoder(lab=True), tune(..., lab=True))
+LAB_PATH = os.path.join(HERE, "lib", "libacarsdec_amd_lab.so")
 
 OK, EINVAL, ENOMEM, EHIP, ENODEV, EOVERFLOW, ESTATE, EAGAIN = 0, -1, -2, -3, -4, -5, -6, -7
 F_BITLOG, F_TIMING, F_REPAIR, F_EXACT_FIR = 1, 2, 4, 8
@@ -71,6 +73,10 @@ SYMBOLS = {
     "acg_airspy_taps": (C.c_int, [C.c_int, C.c_int, C.c_uint, C.c_void_p]),
     "acg_process_samples_dev": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]),
     "acg_feed_samples_host": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
+    "acg_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "acg_host_free": (None, [C.c_void_p]),
+    "acg_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "acg_host_unregister": (C.c_int, [C.c_void_p]),
     "acg_drain_frames": (C.c_int, [C.c_void_p, C.POINTER(Frame), C.c_int, C.POINTER(C.c_int)]),
     "acg_collect_frames": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Frame), C.c_int, C.POINTER(C.c_int)]),
     "acg_drain_msgs": (C.c_int, [C.c_void_p, C.POINTER(Msg), C.c_int, C.POINTER(C.c_int)]),
@@ -80,6 +86,7 @@ SYMBOLS = {
     "acg_bit_capacity": (C.c_int, [C.c_void_p]),
     "acg_max_lag": (C.c_int, [C.c_void_p]),
     "acg_tune": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "acg_is_lab_build": (C.c_int, []),
     "acg_read_dm": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "acg_get_state": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(ChanState)]),
     "acg_set_state": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(ChanState)]),
@@ -90,41 +97,53 @@ SYMBOLS = {
     "acg_fill_random_u8_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_uint64, C.c_void_p]),
     "acg_synth_iq_u8_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_uint64, C.c_void_p]),
+    "acg_probe_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "acg_probe_read_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "acg_selftest_div2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "acg_selftest_sincos": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
 }
 
 _lib = None
+_lab = None
 
 
-def load():
-    """Load the native library.  Raises (never falls back) if it is missing."""
-    global _lib
+def _open(path):
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % path)
+    try:
+        # PyTorch bundles its own libamdhip64.so.7; importing it first makes this library bind
+        # to the SAME HIP runtime instance so torch device pointers / streams are usable here.
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is plumbing, not required by the library
+        pass
+    L = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    return L
+
+
+def load(lab=False):
+    """Load the native library.  Raises (never falls back) if it is missing.  lab=True: the lab build (a second, independent
+    library with its own tuning table), for tests and probes that need a measurement variant."""
+    global _lib, _lab
+    if lab:
+        if _lab is None:
+            _lab = _open(LAB_PATH)
+            assert _lab.acg_is_lab_build() == 1
+        return _lab
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(
-                "%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
-        try:
-            # PyTorch bundles its own libamdhip64.so.7; importing it first makes this library bind
-            # to the SAME HIP runtime instance so torch device pointers / streams are usable here.
-            import torch  # noqa: F401
-        except Exception:  # pragma: no cover - torch is plumbing, not required by the library
-            pass
-        L = C.CDLL(LIB_PATH)
-        for name, (res, args) in SYMBOLS.items():
-            fn = getattr(L, name)
-            fn.restype = res
-            fn.argtypes = args
-        _lib = L
+        _lib = _open(LIB_PATH)
     return _lib
 
 
-def tune(name, value):
+def tune(name, value, lab=False):
     """Measurement switch NAME (ACG_...) := value for the following launches; None removes the override.  The library
     reads the environment only once, at its first look-up, so changing os.environ later has no effect: use this."""
-    rc = load().acg_tune(name.encode(), None if value is None else str(value).encode())
+    rc = load(lab).acg_tune(name.encode(), None if value is None else str(value).encode())
     if rc != OK:
         raise AcgError(rc, "acg_tune(%s)" % name)
 

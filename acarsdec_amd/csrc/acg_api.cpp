@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -30,30 +31,43 @@ namespace {
 struct EvPair { hipEvent_t a, b; };
 
 // ---- tuning overrides --------------------------------------------------------------------------------------------
-// Every measurement / layout switch of the library (ACG_FIR_VARIANT, ACG_MSK_LPC, ACG_FIR_DEBUG_*, ...) lives in ONE
-// table.  The environment is read ONCE, at the first look-up of the process, and whatever was picked up is reported on
-// stderr: a stray variable in a host process can no longer change results or speed silently, and no launch calls
-// getenv().  After that the table only changes through acg_tune() (bench.py --ab, the probes under profiles/probe).
+// Every measurement / layout switch of the library (ACG_FIR_VARIANT, ACG_MSK_LPC, ACG_PIPE_BLOCKS, ...) lives in ONE table.
+// A production process has an EMPTY table: a look-up is then one relaxed atomic load and returns the default -- no mutex,
+// no string, no allocation on any launch path.  The table gets entries in two ways only:
+//   * acg_tune(name, value) (bench.py --ab, the tests' `tune` fixture, the probes);
+//   * the environment, read ONCE at the first look-up of the process and reported on stderr -- in the product library only
+//     when ACG_ALLOW_TUNING=1 is set as well (a stray ACG_* variable of a host process is then named on stderr and ignored);
+//     the lab build (libacarsdec_amd_lab.so, -DACG_LAB: tests and probes) always takes it.
+// The measurement-only kernels and debug shapes (FIR variants other than 5 / 3, ACG_FIR_DEBUG_*, the two-wave demodulator)
+// are not compiled into the product library at all.
 std::mutex g_tune_mx;
 std::map<std::string, std::string> g_tune;
-bool g_tune_ready = false;
+std::atomic<int> g_tune_state{0};            // 0 = environment not looked at yet, 1 = table empty, 2 = table has entries
 
 void tune_init_locked()
 {
-    if (g_tune_ready) return;
-    g_tune_ready = true;
+    if (g_tune_state.load(std::memory_order_relaxed) != 0) return;
     std::string seen;
+    bool allow = false;
+#ifdef ACG_LAB
+    allow = true;
+#endif
+    for (char** e = environ; e && *e; ++e)
+        if (std::strcmp(*e, "ACG_ALLOW_TUNING=1") == 0) allow = true;
     for (char** e = environ; e && *e; ++e) {
         const char* kv = *e;
-        if (std::strncmp(kv, "ACG_", 4) != 0 || std::strncmp(kv, "ACG_BENCH_", 10) == 0) continue;
+        if (std::strncmp(kv, "ACG_", 4) != 0 || std::strncmp(kv, "ACG_BENCH_", 10) == 0 || std::strncmp(kv, "ACG_ALLOW_TUNING", 16) == 0) continue;
         const char* eq = std::strchr(kv, '=');
         if (!eq) continue;
-        g_tune[std::string(kv, (size_t)(eq - kv))] = std::string(eq + 1);
+        if (allow) g_tune[std::string(kv, (size_t)(eq - kv))] = std::string(eq + 1);
         seen += std::string(" ") + kv;
     }
     if (!seen.empty())
-        std::fprintf(stderr, "acarsdec_amd: tuning overrides taken from the environment (measurement switches, not product "
-                             "configuration):%s\n", seen.c_str());
+        std::fprintf(stderr, allow ? "acarsdec_amd: tuning overrides taken from the environment (measurement switches, not product "
+                                     "configuration):%s\n"
+                                   : "acarsdec_amd: ACG_* variables in the environment IGNORED (they are measurement switches; set "
+                                     "ACG_ALLOW_TUNING=1 to apply them):%s\n", seen.c_str());
+    g_tune_state.store(g_tune.empty() ? 1 : 2, std::memory_order_release);
 }
 
 // ---- roctx ranges (rocprofv3 --marker-trace): bound at run time, so the library carries no profiler dependency ----
@@ -87,13 +101,16 @@ struct RoctxRange {
 // look-up used by the launchers (fir.hip, msk.hip) and this file: the override's integer value, or dflt
 extern "C" int acg_tune_get(const char* name, int dflt)
 {
+    if (g_tune_state.load(std::memory_order_acquire) == 1) return dflt;          // the production case: nothing to look up
     std::lock_guard<std::mutex> lk(g_tune_mx);
     tune_init_locked();
+    if (g_tune.empty()) return dflt;
     auto it = g_tune.find(name);
     return it == g_tune.end() ? dflt : std::atoi(it->second.c_str());
 }
 extern "C" int acg_tune_has(const char* name)
 {
+    if (g_tune_state.load(std::memory_order_acquire) == 1) return 0;
     std::lock_guard<std::mutex> lk(g_tune_mx);
     tune_init_locked();
     return g_tune.count(name) ? 1 : 0;
@@ -105,7 +122,17 @@ extern "C" int acg_tune(const char* name, const char* value)
     tune_init_locked();
     if (value) g_tune[name] = value;
     else g_tune.erase(name);
+    g_tune_state.store(g_tune.empty() ? 1 : 2, std::memory_order_release);
     return ACG_OK;
+}
+// 1 in the lab build (libacarsdec_amd_lab.so: every kernel variant and debug shape), 0 in the product library
+extern "C" int acg_is_lab_build(void)
+{
+#ifdef ACG_LAB
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 struct acg_ctx {
@@ -177,10 +204,19 @@ struct acg_ctx {
     float2* d_bits = nullptr;
     int* d_nbits = nullptr;
     unsigned long long* d_stamp = nullptr;   // measurement build (ACG_MSK_STAMP): per-wave phase cycle sums of the last demodulator launch
-    void* d_stage = nullptr;        // staging for *_host entry points
+    // *_host entry points: TWO device staging buffers and a copy stream of their own, so that the host-to-device copy of
+    // call i+1 runs while the kernels of call i read the other buffer (the caller's memory is free again when the call
+    // returns: rtl.c:314-330 / soapy.c:220-254 hand over a buffer that is only valid during the callback)
+    void* d_stage[2] = {nullptr, nullptr};
+    size_t stage_bytes = 0;         // bytes of EACH buffer
+    hipStream_t h2d_stream = nullptr;
+    hipEvent_t h2d_done = nullptr;
+    hipEvent_t stage_free[2] = {nullptr, nullptr};   // the down-converter launches that read the buffer have been enqueued before it
+    bool stage_free_valid[2] = {false, false};
+    unsigned int stage_seq = 0;     // acg_process_iq_u8_host: calls so far (slot = seq & 1)
+    int feed_cur = 0;               // acg_feed_samples_host: the buffer whose head holds the carried samples
     int feed_fmt = 0;               // acg_feed_samples_host: format and samples of the incomplete window carried
     size_t feed_fill = 0;
-    size_t stage_bytes = 0;
 
     std::vector<EvPair> fir_ev, msk_ev;
     std::vector<hipEvent_t> ev_pool;
@@ -242,7 +278,7 @@ static void free_all(acg_ctx* c)
     hipFree(c->d_h); hipFree(c->d_sctab); hipFree(c->d_txt); hipFree(c->d_frames); hipFree(c->d_frame_count);
     hipFree(c->d_stamp);
     hipFree(c->d_msgs); std::free(c->h_msgs);
-    hipFree(c->d_bits); hipFree(c->d_nbits); hipFree(c->d_stage); hipFree(c->d_work); hipFree(c->d_msk_done); std::free(c->h_stage); hipFree(c->d_crctab); hipFree(c->d_rep_upto);
+    hipFree(c->d_bits); hipFree(c->d_nbits); hipFree(c->d_stage[0]); hipFree(c->d_stage[1]); hipFree(c->d_work); hipFree(c->d_msk_done); std::free(c->h_stage); hipFree(c->d_crctab); hipFree(c->d_rep_upto);
     for (auto& p : c->fir_ev) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto& p : c->msk_ev) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     for (auto e : c->ev_pool) hipEventDestroy(e);
@@ -257,6 +293,9 @@ static void free_all(acg_ctx* c)
     if (c->fir_stream) hipStreamDestroy(c->fir_stream);
     if (c->msk_stream) hipStreamDestroy(c->msk_stream);
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
+    if (c->h2d_stream) hipStreamDestroy(c->h2d_stream);
+    if (c->h2d_done) hipEventDestroy(c->h2d_done);
+    for (auto e : c->stage_free) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
 }
 
@@ -367,7 +406,15 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
     int rc = ACG_OK;
     auto body = [&]() -> int {
         HIPCHK(c, hipSetDevice(cfg->device));
-        HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        // (probe switch, profiles/probe/context_probe.py: streams with a CU mask get an HSA queue of their OWN instead of
+        //  one out of the runtime's pool of shared hardware queues; 1 = the demodulator stream, 2 = the context's stream too)
+        const int dedicated = acg_tune_get("ACG_STREAMS_DEDICATED", 0);
+        int total_cus = 256;
+        (void)hipDeviceGetAttribute(&total_cus, hipDeviceAttributeMultiprocessorCount, cfg->device);
+        uint32_t full_mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int cu = 0; cu < total_cus && cu < 256; ++cu) full_mask[cu >> 5] |= 1u << (cu & 31);
+        if (dedicated >= 2) HIPCHK(c, hipExtStreamCreateWithCUMask(&c->stream, 8, full_mask));
+        else HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         {
             // CU partition (ACG_MSK_CUS=n): the demodulator's few long-lived waves get n CUs of their own
             // (mask bits [0, n)) and the down-converter runs on the other 256 - n through an internal
@@ -388,7 +435,8 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
                 // a stream of its own priority class gets a hardware queue of its own
                 int lo = 0, hi = 0;
                 HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
-                HIPCHK(c, hipStreamCreateWithPriority(&c->msk_stream, hipStreamNonBlocking, hi));
+                if (dedicated >= 1) HIPCHK(c, hipExtStreamCreateWithCUMask(&c->msk_stream, 8, full_mask));
+                else HIPCHK(c, hipStreamCreateWithPriority(&c->msk_stream, hipStreamNonBlocking, hi));
             }
         }
         HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
@@ -447,10 +495,12 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
         HIPCHK(c, hipMalloc(&c->d_groups, nch * sizeof(int4)));
         HIPCHK(c, hipMalloc(&c->d_group_ch, nch * sizeof(int)));
         HIPCHK(c, hipMalloc(&c->d_gtaps, nch * (size_t)c->ntaps_pad * 2 * sizeof(float)));
+#ifdef ACG_LAB
         if (acg_tune_has("ACG_DEBUG_ADDR"))                    // placement probes (profiles/probe/placement_probe.py)
             fprintf(stderr, "acg_create: taps %p (%zu B)  dm %p (%zu B)  st %p  work %p  stream_of %p  txt %p\n", (void*)c->d_taps,
                     nch * c->ntaps_pad * 2 * sizeof(float), (void*)c->d_dm_all, 2 * nch * c->dm_pitch * sizeof(float), (void*)c->d_st,
                     (void*)c->d_work, (void*)c->d_stream_of, (void*)c->d_txt);
+#endif
         std::vector<int> so(nch);
         for (size_t i = 0; i < nch; ++i) so[i] = (int)(i % (size_t)cfg->nstreams);
         return upload_stream_map(c, so.data());
@@ -477,6 +527,9 @@ extern "C" int acg_reset(acg_ctx* ctx)
     ctx->consumed = 0;
     ctx->call_seq = 0;
     ctx->feed_fill = 0;
+    ctx->feed_cur = 0;
+    ctx->stage_seq = 0;
+    ctx->stage_free_valid[0] = ctx->stage_free_valid[1] = false;
     std::fill(ctx->msk_done_owner.begin(), ctx->msk_done_owner.end(), -1);
     // initMsk (msk.c:34-41): MskPhi = MskClk = MskS = MskDf = idx = 0, inb zeroed;
     // static storage: MskLvlSum = MskBitCount = 0; initAcars (acars.c:230-234): outbits 0, nbits 8, WSYN
@@ -677,10 +730,13 @@ static int launch_msk(acg_ctx* c, const float* dm_dev, size_t pitch_floats, int 
     int e;
     {
         RoctxRange range("acg:demodulator");
-        // few channels: the two-wave kernel (msk2.hip: the per-bit instruction stream split over a wave pair on two SIMDs);
-        // bit-identical to the one-wave kernel, so the switch may change from launch to launch
+        // lab build: the two-wave kernel (msk2.hip: the per-bit instruction stream split over a wave pair on two SIMDs);
+        // bit-identical to the one-wave kernel, so the switch may change from launch to launch -- and slower
+#ifdef ACG_LAB
         if (lpc == 8 && acg_tune_get("ACG_MSK_SPLIT", c->msk_split)) e = acg_launch_msk2(&a, c->fir_stream ? 2 : 1, s);
-        else e = acg_launch_msk(&a, lpc, s);
+        else
+#endif
+            e = acg_launch_msk(&a, lpc, s);
     }
     if (e != 0) {
         c->err = std::string("MSK launch: ") + hipGetErrorString((hipError_t)e);
@@ -797,16 +853,31 @@ extern "C" int acg_process_iq_u8_dev(acg_ctx* ctx, const uint8_t* iq_dev, size_t
 
 static int ensure_stage(acg_ctx* c, size_t bytes)
 {
+    if (!c->h2d_stream) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->h2d_stream, hipStreamNonBlocking));
+        HIPCHK(c, hipEventCreateWithFlags(&c->h2d_done, hipEventDisableTiming));
+        for (auto& e : c->stage_free) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     if (c->stage_bytes >= bytes) return ACG_OK;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->d_stage) hipFree(c->d_stage);
-    c->d_stage = nullptr;
+    if (c->feed_fill) return fail(c, ACG_ESTATE, "staging buffers cannot grow while a partial window is carried");
+    HIPCHK(c, hipDeviceSynchronize());                    // nothing may still read the buffers that go away
+    for (auto& p : c->d_stage) {
+        if (p) hipFree(p);
+        p = nullptr;
+    }
     c->stage_bytes = 0;
-    HIPCHK(c, hipMalloc(&c->d_stage, bytes));
+    c->stage_free_valid[0] = c->stage_free_valid[1] = false;
+    c->feed_cur = 0;
+    for (auto& p : c->d_stage) HIPCHK(c, hipMalloc(&p, bytes));
     c->stage_bytes = bytes;
     return ACG_OK;
 }
 
+// Host input: the copy of THIS call goes to the staging buffer the call before the previous one used, on the copy stream,
+// as soon as the down-converter launches that read that buffer are done -- i.e. it runs beside the kernels of the previous
+// call.  The call returns when the copy has left the caller's memory (rtl.c:314-330: the buffer belongs to the driver
+// again after the callback); its kernels run after the return, beside the host's next call.  From pinned memory
+// (acg_host_alloc / acg_host_register) the copy is one DMA at the link's rate; from pageable memory the runtime stages it.
 extern "C" int acg_process_iq_u8_host(acg_ctx* ctx, const uint8_t* iq_host, size_t pitch_bytes, int nblocks)
 {
     int r = check_iq_args(ctx, iq_host, pitch_bytes, nblocks);
@@ -814,10 +885,21 @@ extern "C" int acg_process_iq_u8_host(acg_ctx* ctx, const uint8_t* iq_host, size
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
     const size_t row = (size_t)nblocks * ACG_BLOCK * ctx->cfg.decim * 2;
     const size_t dpitch = (row + 15) & ~(size_t)15;
-    if ((r = ensure_stage(ctx, dpitch * ctx->cfg.nstreams)) != ACG_OK) return r;
-    HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_stage, dpitch, iq_host, ctx->cfg.nstreams > 1 ? pitch_bytes : row,
-                                 row, (size_t)ctx->cfg.nstreams, hipMemcpyHostToDevice, ctx->stream));
-    return acg_process_iq_u8_dev(ctx, (const uint8_t*)ctx->d_stage, dpitch, nblocks, nullptr);
+    const size_t max_row = (((size_t)ctx->cfg.max_blocks * ACG_BLOCK * ctx->cfg.decim * 2) + 15) & ~(size_t)15;
+    if ((r = ensure_stage(ctx, max_row * ctx->cfg.nstreams)) != ACG_OK) return r;
+    const int slot = (int)(ctx->stage_seq++ & 1u);
+    if (ctx->stage_free_valid[slot]) HIPCHK(ctx, hipStreamWaitEvent(ctx->h2d_stream, ctx->stage_free[slot], 0));
+    HIPCHK(ctx, hipMemcpy2DAsync(ctx->d_stage[slot], dpitch, iq_host, ctx->cfg.nstreams > 1 ? pitch_bytes : row,
+                                 row, (size_t)ctx->cfg.nstreams, hipMemcpyHostToDevice, ctx->h2d_stream));
+    HIPCHK(ctx, hipEventRecord(ctx->h2d_done, ctx->h2d_stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->h2d_done, 0));
+    r = acg_process_iq_u8_dev(ctx, (const uint8_t*)ctx->d_stage[slot], dpitch, nblocks, nullptr);
+    if (r != ACG_OK) return r;
+    // (the context's stream is ordered behind the call's last down-converter launch, whichever stream that ran on)
+    HIPCHK(ctx, hipEventRecord(ctx->stage_free[slot], ctx->stream));
+    ctx->stage_free_valid[slot] = true;
+    HIPCHK(ctx, hipEventSynchronize(ctx->h2d_done));       // the caller's buffer is free again
+    return ACG_OK;
 }
 
 extern "C" int acg_process_dm_dev(acg_ctx* ctx, const float* dm_dev, size_t pitch_floats, int len,
@@ -1357,43 +1439,77 @@ extern "C" int acg_feed_samples_host(acg_ctx* ctx, int fmt, const void* p0, cons
     const size_t plane = ((cap * bps) + 15) & ~(size_t)15;
     const size_t rowb = fmt == ACG_FMT_S16_SPLIT ? 2 * plane : plane;
     if ((r = ensure_stage(ctx, rowb * (size_t)g.nstreams)) != ACG_OK) return r;
-    hipStream_t s = ctx->stream;
+    hipStream_t s = ctx->stream, hs = ctx->h2d_stream;
     size_t done = 0;
     while (done < nsamples) {
         const size_t take = std::min(nsamples - done, cap - ctx->feed_fill);
-        unsigned char* base = (unsigned char*)ctx->d_stage;
-        // new samples behind the carried ones
+        const int cur = ctx->feed_cur;
+        unsigned char* base = (unsigned char*)ctx->d_stage[cur];
+        // new samples behind the carried ones, on the copy stream (which already waits for the last reader of this buffer
+        // and carries the copy of the carried samples: both were enqueued when the buffer became the current one)
         HIPCHK(ctx, hipMemcpy2DAsync(base + ctx->feed_fill * bps, rowb, (const unsigned char*)p0 + done * bps,
                                      (g.nstreams > 1 ? pitch_samples : nsamples) * bps, take * bps, (size_t)g.nstreams,
-                                     hipMemcpyHostToDevice, s));
+                                     hipMemcpyHostToDevice, hs));
         if (fmt == ACG_FMT_S16_SPLIT)
             HIPCHK(ctx, hipMemcpy2DAsync(base + plane + ctx->feed_fill * bps, rowb, (const unsigned char*)p1 + done * bps,
                                          (g.nstreams > 1 ? pitch_samples : nsamples) * bps, take * bps, (size_t)g.nstreams,
-                                         hipMemcpyHostToDevice, s));
-        HIPCHK(ctx, hipStreamSynchronize(s));          // the caller's buffers may be reused after return
+                                         hipMemcpyHostToDevice, hs));
+        HIPCHK(ctx, hipEventRecord(ctx->h2d_done, hs));
         done += take;
         const size_t have = ctx->feed_fill + take;
         const size_t nwin = have / M;
         if (nwin > 0) {
+            HIPCHK(ctx, hipStreamWaitEvent(s, ctx->h2d_done, 0));
             a.nwin = (int)nwin;
             a.iq = base;
             a.pitch = rowb;
             a.plane = plane;
             if ((r = run_fmt(ctx, fmt, &a, s)) != ACG_OK) return r;
+            HIPCHK(ctx, hipEventRecord(ctx->stage_free[cur], s));      // behind the last down-converter launch that reads `cur`
+            ctx->stage_free_valid[cur] = true;
+            // the other buffer becomes the current one: once its last reader (the launches of the feed before this one) is
+            // done, the < M samples of the incomplete window move to its head -- on the copy stream, beside the kernels
+            const int nxt = cur ^ 1;
             const size_t left = have - nwin * M;
-            if (left) {                                // < M <= nwin*M samples: source and destination never overlap
-                HIPCHK(ctx, hipMemcpy2DAsync(base, rowb, base + nwin * M * bps, rowb, left * bps, (size_t)g.nstreams,
-                                             hipMemcpyDeviceToDevice, s));
+            if (ctx->stage_free_valid[nxt]) HIPCHK(ctx, hipStreamWaitEvent(hs, ctx->stage_free[nxt], 0));
+            if (left) {
+                unsigned char* nb = (unsigned char*)ctx->d_stage[nxt];
+                HIPCHK(ctx, hipMemcpy2DAsync(nb, rowb, base + nwin * M * bps, rowb, left * bps, (size_t)g.nstreams,
+                                             hipMemcpyDeviceToDevice, hs));
                 if (fmt == ACG_FMT_S16_SPLIT)
-                    HIPCHK(ctx, hipMemcpy2DAsync(base + plane, rowb, base + plane + nwin * M * bps, rowb, left * bps,
-                                                 (size_t)g.nstreams, hipMemcpyDeviceToDevice, s));
+                    HIPCHK(ctx, hipMemcpy2DAsync(nb + plane, rowb, base + plane + nwin * M * bps, rowb, left * bps,
+                                                 (size_t)g.nstreams, hipMemcpyDeviceToDevice, hs));
             }
             ctx->feed_fill = left;
+            ctx->feed_cur = nxt;
         } else {
             ctx->feed_fill = have;
         }
+        HIPCHK(ctx, hipEventSynchronize(ctx->h2d_done));   // the caller's buffers may be reused after return
     }
     return ACG_OK;
+}
+
+// pinned host memory for the *_host entry points, so that a C host needs no HIP headers: hipHostMalloc / hipHostRegister
+extern "C" void* acg_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+extern "C" void acg_host_free(void* p)
+{
+    if (p) (void)hipHostFree(p);
+}
+extern "C" int acg_host_register(void* p, size_t bytes)
+{
+    if (!p || bytes == 0) return ACG_EINVAL;
+    return hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess ? ACG_OK : ACG_EHIP;
+}
+extern "C" int acg_host_unregister(void* p)
+{
+    if (!p) return ACG_EINVAL;
+    return hipHostUnregister(p) == hipSuccess ? ACG_OK : ACG_EHIP;
 }
 
 extern "C" int acg_selftest_sincos(const double* x_host, double* sin_host, double* cos_host, int n)
@@ -1480,6 +1596,20 @@ extern "C" int acg_probe_read_dev(const void* dev, size_t bytes, int repeats, do
     if (e1) hipEventDestroy(e1);
     hipFree(sink);
     return rc;
+}
+
+// measurement aid: what one host-to-device copy of `bytes` reaches on this box (the ceiling of the *_host entry points)
+extern "C" int acg_probe_h2d(void* dev, const void* host, size_t bytes, int repeats, double* gb_per_s)
+{
+    if (!dev || !host || bytes == 0 || repeats < 1 || !gb_per_s) return ACG_EINVAL;
+    if (hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice) != hipSuccess) return ACG_EHIP;      // warm-up
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < repeats; ++i)
+        if (hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice) != hipSuccess) return ACG_EHIP;
+    if (hipDeviceSynchronize() != hipSuccess) return ACG_EHIP;
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    *gb_per_s = (double)bytes * repeats / sec / 1e9;
+    return ACG_OK;
 }
 
 extern "C" int acg_synth_iq_u8_dev(uint8_t* iq_dev, size_t pitch_bytes, int nrows, int nout, int decim,

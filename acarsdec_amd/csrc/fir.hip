@@ -67,6 +67,7 @@ __device__ __forceinline__ float cabs_like_glibc(float re, float im)
     return (float)__dsqrt_rn(d);
 }
 
+#ifdef ACG_LAB   // round 1's first kernel (ACG_FIR_VARIANT=0): lab build only (libacarsdec_amd_lab.so)
 __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_tile_kernel(const FirArgs a,
                                                                   const uint8_t* __restrict__ iq_base,
                                                                   const float* __restrict__ taps_base,
@@ -181,6 +182,8 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_tile_kernel(const FirArgs a
         // before anyone rewrites it.
     }
 }
+
+#endif  // ACG_LAB
 
 // Persistent variant: the grid is exactly the number of workgroups the chip holds at once and the
 // (channel, tile) space is cut into equal contiguous runs, one per workgroup, so that all workgroups
@@ -527,6 +530,7 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_shared_kernel(const FirArgs
     if (tid == 0) dispenser_sign_off(a.work_counter, pending_next);
 }
 
+#ifdef ACG_LAB   // LDS-DMA variant (ACG_FIR_VARIANT=4): lab build only
 // LDS-DMA variant (rows that are an odd number of 16-byte slots, e.g. M = 200: no padding needed, so the
 // LDS image of a tile is the linear image of its bytes in HBM).  `global_load_lds_dwordx4 ... nt` moves
 // 1 KiB per wave-instruction straight into LDS: no staging VGPRs, no ds_write pass, one barrier per
@@ -645,6 +649,8 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_dma_kernel(const FirArgs a,
     }
     if (tid == 0) dispenser_sign_off(a.work_counter, pending_next);
 }
+
+#endif  // ACG_LAB
 
 // ---------------------------------------------------------------------------------------------------
 // Wave-private streaming variant -- the default for whole callbacks at the documented rates
@@ -975,6 +981,7 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_direct_kernel(const FirArgs
     fird_body<CPR, UU, BB, FOLD, WT, NOMAC>(a, iq_base, taps_base, stream_of, dm_base);
 }
 
+#ifdef ACG_LAB   // register-tap and matrix-pipe variants (ACG_FIR_VARIANT=7 / 8 / 6, 70..73): lab build only
 // ---------------------------------------------------------------------------------------------------
 // fir_u8_coltap_kernel (ACG_FIR_VARIANT=7, 2.5 Msps only): the wave-private streaming kernel above with the taps in
 // REGISTERS.  What the kernel above pays per 16 input bytes besides its arithmetic is 64 bytes of tap reads from LDS
@@ -1468,6 +1475,8 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_mfma_kernel(const FirArgs a
         }
     }
 }
+
+#endif  // ACG_LAB
 
 // ---------------------------------------------------------------------------------------------------
 // The other front ends' sample formats: same tile scheme, 4 bytes per input sample.
@@ -2136,15 +2145,18 @@ static int launch_direct(const FirArgs* a, int num_cu, hipStream_t stream)
     if (grid > need) grid = need;
     FirArgs b = *a;
     b.run_pairs = pairs;
+#ifdef ACG_LAB
     if (acg_tune_get("ACG_FIR_DEBUG_DMPITCH0", 0)) b.dm_pitch = 0;          // measurement aid: every channel's dm lands in the first row (no write stream to HBM)
     if (acg_tune_has("ACG_FIR_DEBUG_SHAPE"))
         fprintf(stderr, "fir_u8_direct<%d>: nch %d nwin %d  wpg %d per_cu %d grid %lld  bodies/ch %lld pairs %d runs %lld  shares_cus %d prio %d\n",
                 CPR, a->nch, a->nwin, wpg, per_cu, grid, bodies_per_ch, pairs, nrun, a->shares_cus, a->high_prio);
+#endif
     FIR_LAUNCH((fir_u8_direct_kernel<CPR, UU, BB, FOLD, WT, NOMAC>), dim3((unsigned int)grid), dim3(64 * wpg), lds, stream, b, a->iq, a->taps,
                        a->stream_of, a->dm);
     return (int)hipGetLastError();
 }
 
+#ifdef ACG_LAB   // launchers of the lab variants
 // register-resident taps (ACG_FIR_VARIANT=7 / 8, 2.5 Msps): 13 / 17 KiB of LDS per wave
 template <bool FOLD = true, int UU = 13, int BB = 1, bool STAGED = false>
 static int launch_coltap(const FirArgs* a, int num_cu, hipStream_t stream)
@@ -2206,17 +2218,25 @@ static int launch_mfma(const FirArgs* a, int num_cu, hipStream_t stream)
     return (int)hipGetLastError();
 }
 
+#endif  // ACG_LAB
+
 extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
 {
     const size_t lds = acg_fir_lds_bytes(a);
     FirDev* fd = nullptr;
     if (int e = fir_device(&fd)) return e;
     const int num_cu = fd->num_cu;
-    // ACG_FIR_VARIANT: 5 (default) wave-private streaming kernel where it applies (dm stored write-through), else 3;
-    // 0 one workgroup per segment; 1 / 2 static persistent partition without / with non-temporal loads; 3 workgroup-
-    // granular dynamic dispenser; 4 LDS-DMA double buffering; 6 matrix pipe; 7 taps in registers; 8 = 7 with the results
-    // parked in LDS and written in chip-wide bursts; 50..56, 70..73 measurement knobs of 5 and 7 (55: write-back stores; 56: no arithmetic, dm is garbage)
-    const int variant = env_int("ACG_FIR_VARIANT", 5);
+    // ACG_FIR_VARIANT.  The PRODUCT library has two kernels behind this entry point: 5 (default) the wave-private streaming
+    // kernel where it applies (whole two-tile bodies, rtlMult 160 / 192 / 200; dm stored write-through), and 3, the
+    // workgroup-granular kernel with the dynamic run dispenser, for everything else (ragged launches, other window lengths).
+    // The LAB build (libacarsdec_amd_lab.so, -DACG_LAB; tests and probes only) adds: 0 one workgroup per segment; 1 / 2 static
+    // persistent partition without / with non-temporal loads; 4 LDS-DMA double buffering; 6 matrix pipe; 7 taps in registers;
+    // 8 = 7 with the results parked in LDS and written in chip-wide bursts; 50..56, 70..73 measurement knobs of 5 and 7
+    // (55: write-back stores; 56: no arithmetic, dm is garbage).
+    int variant = env_int("ACG_FIR_VARIANT", 5);
+#ifndef ACG_LAB
+    if (variant != 3) variant = 5;
+#else
     if ((variant == 7 || variant == 8 || (variant >= 70 && variant <= 73)) && a->cpr == 25 && a->nwin > 0 && a->nwin % ACG_TILE_WIN == 0 && (a->nwin / ACG_TILE_WIN) % FIRD_R == 0 &&
         (long long)a->nch * (a->nwin / ACG_TILE_WIN) < (1ll << 31) && a->ntaps_pad <= a->decim)
     {            // 70..73: measurement knobs (staging slots, burst length)
@@ -2230,13 +2250,15 @@ extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
     if (variant == 6 && a->cpr == 25 && a->nwin > 0 && a->nwin % ACG_TILE_WIN == 0 && (a->nwin / ACG_TILE_WIN) % FIRD_R == 0 &&
         (long long)a->nch * (a->nwin / ACG_TILE_WIN) < (1ll << 31) && a->ntaps_pad <= a->decim)
         return launch_mfma<25>(a, num_cu, (hipStream_t)stream);
+#endif
     if ((variant == 5 || (variant >= 50 && variant <= 56)) && a->nwin > 0 && a->nwin % ACG_TILE_WIN == 0 && (a->nwin / ACG_TILE_WIN) % FIRD_R == 0 &&
         (long long)a->nch * (a->nwin / ACG_TILE_WIN) < (1ll << 31) && a->ntaps_pad <= a->decim) {
         switch (a->cpr) {
         // (dm is stored write-through: beside the streaming reads a write-back line costs more, see firc_flush)
         case 20: return launch_direct<20, 0, 0, true, true>(a, num_cu, (hipStream_t)stream);
         case 24: return launch_direct<24, 0, 0, true, true>(a, num_cu, (hipStream_t)stream);
-        case 25:          // 50..54: measurement knobs (staging slots, burst length, 127.37 per sample)
+        case 25:
+#ifdef ACG_LAB    // 50..54: measurement knobs (staging slots, burst length, 127.37 per sample)
             if (variant == 50) return launch_direct<25, 10, 1>(a, num_cu, (hipStream_t)stream);
             if (variant == 51) return launch_direct<25, 25, 5>(a, num_cu, (hipStream_t)stream);
             if (variant == 52) return launch_direct<25, 25, 10>(a, num_cu, (hipStream_t)stream);
@@ -2244,10 +2266,12 @@ extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
             if (variant == 54) return launch_direct<25, 0, 0, false>(a, num_cu, (hipStream_t)stream);      // 127.37 subtracted per sample
             if (variant == 56) return launch_direct<25, 0, 0, true, true, true>(a, num_cu, (hipStream_t)stream);   // measurement: no arithmetic (dm is garbage)
             if (variant == 55) return launch_direct<25>(a, num_cu, (hipStream_t)stream);                    // dm stored write-back (round 2a)
+#endif
             return launch_direct<25, 0, 0, true, true>(a, num_cu, (hipStream_t)stream);
         default: break;
         }
     }
+#ifdef ACG_LAB
     if (variant == 0) {
         const unsigned int grid = (unsigned int)a->nch * (unsigned int)a->nseg;
         FIR_LAUNCH(fir_u8_tile_kernel, dim3(grid), dim3(ACG_WG_FIR), lds, (hipStream_t)stream, *a,
@@ -2271,6 +2295,7 @@ extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
             return (int)hipGetLastError();
         }
     }
+#endif
     // resident workgroups: LDS-limited (160 KiB per CU), at most 5 (VGPR budget of 4-wave workgroups)
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 5) per_cu = 5;
@@ -2282,25 +2307,29 @@ extern "C" int acg_launch_fir(const FirArgs* a, void* stream)
     long long grid = (long long)(a->ncu > 0 ? a->ncu : num_cu) * per_cu;
     if (grid > G) grid = G;
     FirArgs b = *a;
+#ifdef ACG_LAB
     const bool nocompute = acg_tune_has("ACG_FIR_DEBUG_NOCOMPUTE") != 0;   // measurement aid: loads + LDS staging only
     if (nocompute) b.ntaps_pad = 0;
     if (variant == 1) {
         FIR_LAUNCH((fir_u8_persist_kernel<false, false, false>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds,
                            (hipStream_t)stream, b, a->iq, a->taps, a->stream_of, a->dm);
-    } else if (variant == 2) {
+        return (int)hipGetLastError();
+    }
+    if (variant == 2) {
         FIR_LAUNCH((fir_u8_persist_kernel<true, false, false>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds,
                            (hipStream_t)stream, b, a->iq, a->taps, a->stream_of, a->dm);
-    } else {
-        const long long nrun = (G + FIR_RUN - 1) / FIR_RUN;
-        if (grid > nrun) grid = nrun;
-        if (G >= (1ll << 31)) return (int)hipErrorInvalidValue;
-        if (a->nwin % ACG_TILE_WIN == 0)      // whole callbacks: every tile is complete
-            FIR_LAUNCH((fir_u8_persist_kernel<true, true, true>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds,
-                               (hipStream_t)stream, b, a->iq, a->taps, a->stream_of, a->dm);
-        else
-            FIR_LAUNCH((fir_u8_persist_kernel<true, true, false>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds,
-                               (hipStream_t)stream, b, a->iq, a->taps, a->stream_of, a->dm);
+        return (int)hipGetLastError();
     }
+#endif
+    const long long nrun = (G + FIR_RUN - 1) / FIR_RUN;
+    if (grid > nrun) grid = nrun;
+    if (G >= (1ll << 31)) return (int)hipErrorInvalidValue;
+    if (a->nwin % ACG_TILE_WIN == 0)      // whole callbacks: every tile is complete
+        FIR_LAUNCH((fir_u8_persist_kernel<true, true, true>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds,
+                           (hipStream_t)stream, b, a->iq, a->taps, a->stream_of, a->dm);
+    else
+        FIR_LAUNCH((fir_u8_persist_kernel<true, true, false>), dim3((unsigned int)grid), dim3(ACG_WG_FIR), lds,
+                           (hipStream_t)stream, b, a->iq, a->taps, a->stream_of, a->dm);
     return (int)hipGetLastError();
 }
 

@@ -64,8 +64,8 @@ def parse_freq_mhz(s):
 
 class Decoder:
     def __init__(self, nch, decim=160, ntaps=None, nstreams=None, max_blocks=1, device=0,
-                 bitlog=True, timing=False, repair=False, exact_fir=False, max_lag=0):
-        self.L = K.load()
+                 bitlog=True, timing=False, repair=False, exact_fir=False, max_lag=0, lab=False):
+        self.L = K.load(lab)          # lab=True: the lab build of the library (measurement variants; tests and probes only)
         self.nch, self.decim = int(nch), int(decim)
         self.ntaps = int(ntaps if ntaps is not None else decim)
         self.nstreams = int(nstreams if nstreams is not None else nch)

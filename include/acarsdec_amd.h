@@ -150,7 +150,11 @@ int  acg_reset(acg_ctx *ctx);
  * asynchronous: the down-converter (the only reader of iq) is enqueued on hip_stream (NULL = the
  * context's own stream) so later work on that stream may overwrite iq; the demodulator follows on
  * an internal stream.  Results are complete after acg_sync / acg_drain_frames / acg_collect_frames.
- * *_host copies first. */
+ * *_host: the librtlsdr contract (rtl.c:314-330: the buffer is the driver's again when the callback returns) -- the call
+ * returns as soon as the input has LEFT iq_host; it went to one of two device staging buffers on a copy stream of its own,
+ * beside the kernels of the previous call, and this call's kernels run after the return.  From pinned memory
+ * (acg_host_alloc, or the caller's own buffers through acg_host_register) that copy is one DMA at the link's rate; pageable
+ * memory works and is staged by the runtime. */
 int  acg_process_iq_u8_dev(acg_ctx *ctx, const uint8_t *iq_dev, size_t pitch_bytes, int nblocks,
 			   void *hip_stream);
 int  acg_process_iq_u8_host(acg_ctx *ctx, const uint8_t *iq_host, size_t pitch_bytes, int nblocks);
@@ -198,9 +202,17 @@ int  acg_process_samples_dev(acg_ctx *ctx, int fmt, const void *dev, size_t pitc
 			     int nblocks, void *hip_stream);
 /* Host input of ANY length per call, as the SDR drivers deliver it: windows may straddle calls (the
  * reference carries D / its index across buffers: soapy.c:232-254, sdrplay.c:215-236, air.c:299-338).
- * p0 = samples (I plane for ACG_FMT_S16_SPLIT), p1 = Q plane or NULL; rows pitch_samples apart. */
+ * p0 = samples (I plane for ACG_FMT_S16_SPLIT), p1 = Q plane or NULL; rows pitch_samples apart.  Same return contract
+ * and the same two staging buffers as acg_process_iq_u8_host: the copy of feed i+1 runs beside the kernels of feed i. */
 int  acg_feed_samples_host(acg_ctx *ctx, int fmt, const void *p0, const void *p1, size_t pitch_samples,
 			   size_t nsamples);
+
+/* pinned host memory for the *_host entry points (hipHostMalloc / hipHostRegister behind a C face, so that a C host needs
+ * no HIP headers): acg_host_alloc returns NULL on failure */
+void *acg_host_alloc(size_t bytes);
+void acg_host_free(void *p);
+int  acg_host_register(void *p, size_t bytes);
+int  acg_host_unregister(void *p);
 
 /* ---- results ------------------------------------------------------------------------------ */
 /* Blocks completed since the last drain/collect, ordered by (chn, end_bit) within the call.  Waits for ALL
@@ -241,10 +253,14 @@ typedef void (*acg_bit_sink)(void *user, int ch, float vo, float lvl);
 int  acg_replay_bits(acg_ctx *ctx, acg_bit_sink sink, void *user);
 
 /* ---- measurement -------------------------------------------------------------------------- */
-/* Measurement / layout switches (ACG_FIR_VARIANT, ACG_MSK_LPC, ACG_FIR_WAVES_PER_WG, ...: see DESIGN.md).  The
- * environment is read ONCE per process, at the library's first look-up, and what was picked up is reported on stderr;
- * afterwards only this call changes a switch (value NULL removes the override).  Not product configuration. */
+/* Measurement / layout switches (ACG_PIPE_BLOCKS, ACG_MSK_LPC, ACG_FIR_WAVES_PER_WG, ...: profiles/LEDGER.md).  A production
+ * process has none and pays one atomic load per look-up.  This call sets one (value NULL removes it).  The environment is
+ * read ONCE per process, at the library's first look-up, and only if ACG_ALLOW_TUNING=1 is set too (otherwise stray ACG_*
+ * variables are named on stderr and ignored).  The measurement-only kernel variants and debug shapes exist only in the lab
+ * build of the library (libacarsdec_amd_lab.so, which tests and probes load; it always takes the environment).
+ * Not product configuration. */
 int  acg_tune(const char *name, const char *value);
+int  acg_is_lab_build(void);
 /* Sums of HIP-event-bracketed kernel time since the last call (ACG_F_TIMING), in ms, and the
  * number of launches they cover.  Synchronises. */
 int  acg_get_timing(acg_ctx *ctx, double *fir_ms, int *fir_launches, double *msk_ms, int *msk_launches);
@@ -260,6 +276,10 @@ int  acg_fill_random_u8_dev(uint8_t *dev, size_t pitch_bytes, int nrows, size_t 
  * device memory, `repeats` back-to-back launches timed with HIP events on the default stream: the read
  * bandwidth this GPU delivers to a kernel that only reads.  Synchronises. */
 int  acg_probe_read_dev(const void *dev, size_t bytes, int repeats, double *gb_per_s);
+
+/* measurement aid: `repeats` synchronous host-to-device copies of `bytes` (after one for nothing), host clock: the rate
+ * the *_host entry points can at best be fed at from that host memory (pinned or pageable) */
+int  acg_probe_h2d(void *dev, const void *host, size_t bytes, int repeats, double *gb_per_s);
 
 /* device-side AM up-converter: row r = scale*env[env_index[r]][n/decim] *
  * exp(j(2*pi*off_hz[r]*n/(12500*decim) + phase[r])) + N(0, noise_sigma^2), quantised like an RTL

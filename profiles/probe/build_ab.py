@@ -7,9 +7,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), 
 sys.path.insert(0, ROOT)
 from acarsdec_amd import _build as B
 
-MSK_FLAGS = ["-O3", "-ffp-contract=off", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-disable-machine-sink",
-             "-mllvm", "-disable-branch-fold", "-mllvm", "-disable-tail-duplicate", "-mllvm", "-structurizecfg-skip-uniform-regions",
-             "-mllvm", "-phi-node-folding-threshold=4"]
+MSK_FLAGS = B.MSK_FLAGS                 # the product's recipe (acarsdec_amd/_build.py)
 B.build_lib()
 out = os.path.join(B.LIBDIR, "ab")
 os.makedirs(out, exist_ok=True)
@@ -34,7 +32,7 @@ for spec in sys.argv[1:]:
         open(src, "w").write(subprocess.run(["git", "show", "%s:acarsdec_amd/csrc/msk.hip" % rev], cwd=ROOT, capture_output=True, text=True, check=True).stdout)
     obj = os.path.join(out, "msk_%s.o" % name)
     B._run([B.hipcc(), "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-I" + B.INC, "-I" + B.CSRC] + base + flags + ["-c", src, "-o", obj])
-    objs = [os.path.join(B.OBJDIR, n) for n in ("fir.hip.o", "msk2.hip.o", "synth.hip.o", "blk.hip.o", "acg_api.cpp.o", "host_setup.o")] + [obj]
+    objs = [os.path.join(B.OBJDIR, n) for n in ("fir.hip.o", "synth.hip.o", "blk.hip.o", "acg_api.cpp.o", "host_setup.o")] + [obj]
     lib = os.path.join(out, "lib%s.so" % name)
     B._run([B.hipcc(), "--offload-arch=gfx950", "-shared", "-o", lib] + objs + ["-ldl", "-lm"])
     print(lib)

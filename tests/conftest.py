@@ -30,12 +30,13 @@ def tune():
     from acarsdec_amd import _capi as K
     touched = []
 
-    def set_(name, value):
-        K.tune(name, value)
-        touched.append(name)
+    def set_(name, value, lab=False):
+        """lab=True: the switch of the LAB build of the library (Decoder(..., lab=True)), which has its own table"""
+        K.tune(name, value, lab=lab)
+        touched.append((name, lab))
     yield set_
-    for n in touched:
-        K.tune(n, os.environ.get(n))
+    for n, lab in touched:
+        K.tune(n, None, lab=lab)
 
 
 @pytest.fixture(scope="session")

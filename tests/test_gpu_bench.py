@@ -77,13 +77,20 @@ def test_bench_also_cases_in_one_line():
             "bench.CASES['wide'].update(channels=512, blocks=2); bench.CASES['stress'].update(channels=256, blocks=2); "
             "bench.CASES['cs16'].update(channels=256, blocks=2); bench.CASES['f32'].update(channels=256, blocks=2); "
             "bench.CASES['shard2048'].update(channels=192, blocks=4); "
-            "sys.argv = ['bench.py', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--sustain', '0.5']; bench.main()")
+            "sys.argv = ['bench.py', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--sustain', '0.5', '--hostfed-channels', '320']; bench.main()")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     d = last_json(r.stdout)
-    assert set(d["also"]) == {"wide", "stress", "shard2048", "cs16", "f32"}
+    assert set(d["also"]) == {"wide", "stress", "shard2048", "cs16", "f32", "hostfed"}
+    hf = d["also"].pop("hostfed")
+    # the host-fed case: the same records as the _dev entry point on the same bytes, the oracle on the gate channels, and a
+    # rate that is a fraction (<= 1, within timer noise) of what a bare host-to-device copy reaches on this box
+    assert hf["parity"]["same_records_as_dev_entry_point"] is True and hf["parity"]["blocks_exact_given_gpu_dm"] is True and hf["parity"]["blocks"] > 0
+    assert hf["hostfed"]["h2d_GBs_measured"] > 1 and 0 < hf["hostfed"]["frac_of_h2d"] < 1.1 and hf["value"] > 0
+    assert hf["config"]["channels_per_gpu"] == 320 and hf["hostfed"]["realtime_needs"] == 320 * 2.5
     c = compact_json(r.stdout)
-    assert set(c["also"]) == set(d["also"]) and all(a["parity_ok"] is True for a in c["also"].values())
+    assert set(c["also"]) == set(d["also"]) | {"hostfed"} and all(a["parity_ok"] is True for a in c["also"].values())
+    assert c["also"]["hostfed"]["hostfed"]["realtime"] in (True, False)
     assert c["also"]["shard2048"]["channels"] == 192 and "u8" not in d["also"]["cs16"]["config"]["arithmetic"]
     for name, a in d["also"].items():
         assert a["parity"]["dm_within_1e5_rel"] is True and a["parity"]["blocks_exact_given_gpu_dm"] is True and a["parity"]["channels_checked"] == 64

@@ -90,6 +90,58 @@ def test_replicated_channels_agree_and_match_oracle(env, nch, M, ntaps, nblk):
     dec.close()
 
 
+@pytest.mark.parametrize("nch,ntaps,exact", [(1024, 200, False), (2048, 200, False), (4096, 192, False), (16384, 200, False), (1024, 200, True)])
+def test_default_kernels_one_stream_per_channel_at_baseline_widths(env, nch, ntaps, exact):
+    """the DEFAULT pipeline -- nstreams == nch, so fir_u8_direct_kernel (wave-private, dispensed runs) with
+    the CU partition up to 2048 channels, the two-stage stream pipeline above -- at BASELINE's widths: configs[2] (1024),
+    configs[3]'s per-GPU share (2048), configs[4] (4096 channels, 192 taps) and the north-star regime (16 384).  The 64
+    distinct streams are replicated ON THE DEVICE into nch distinct rows (distinct memory, so every row really is read), so the
+    oracle still covers 64 and the replicas must equal their originals: dm bit for bit, every soft bit, every block.  Originals:
+    dm within 1e-5 of the oracle's down-converter, blocks bit-exact against the oracle's demodulator fed with the GPU's dm, end
+    to end at most one razor-edge block apart; with ACG_F_EXACT_FIR (the exact-order kernel at full width) dm is bit-identical
+    to the oracle's and the blocks are identical end to end."""
+    torch, D, S, K, O = env
+    M, nblk, nsrc = 200, 2, 64
+    iq, offs = make_streams(S, nsrc, nblk, M, 777 + nch + ntaps)
+    win = np.ones(ntaps) if ntaps == M else np.hamming(ntaps) / np.hamming(ntaps).mean() * (M / ntaps)
+    base = [(D.rtl_taps(131000000 + int(o), 131000000, M)[:ntaps] * win[:, None]).astype(np.float32) for o in offs]
+    src = torch.from_numpy(iq).cuda()
+    dev = src.repeat(nch // nsrc, 1).contiguous()                 # row c = stream c % 64, its own memory
+    assert dev.shape == (nch, iq.shape[1]) and dev.data_ptr() != src.data_ptr()
+    dec = D.Decoder(nch, decim=M, ntaps=ntaps, nstreams=nch, max_blocks=nblk, exact_fir=exact)
+    dec.set_taps(np.stack([base[c % nsrc] for c in range(nch)]))
+    dec.in_callback(dev, nblocks=nblk, pitch=dev.stride(0))
+    frames = dec.drain_frames(max_frames=16 * nch)
+    by = {}
+    for f in frames:
+        by.setdefault(int(f.chn), []).append(D.frame_tuple(f)[1:])
+    nout = nblk * 1024
+    counts, vo, lvl = dec.bits_all()
+    ref_dm = [dec.dm(c, nout) for c in range(nsrc)]
+    for c in range(nsrc, nch):                                    # replicas: bits and blocks exhaustively
+        s_ = c % nsrc
+        assert counts[c] == counts[s_] and np.array_equal(vo[c, :counts[c]], vo[s_, :counts[s_]]) and np.array_equal(lvl[c, :counts[c]], lvl[s_, :counts[s_]]), c
+        assert by.get(c, []) == by.get(s_, []), c
+    for c in list(range(nsrc, nch, 61)) + [nch - 1]:              # ... dm sampled (a D2H copy per channel)
+        assert np.array_equal(dec.dm(c, nout), ref_dm[c % nsrc]), c
+    total, e2e_off = 0, 0
+    for s_ in range(nsrc):
+        want_dm = O.fir_u8(iq[s_], M, base[s_], ntaps=ntaps)
+        if exact:
+            assert np.array_equal(ref_dm[s_].view(np.uint32), want_dm.view(np.uint32)), s_
+        else:
+            assert np.all(np.abs(ref_dm[s_] - want_dm) <= 1e-5 * np.abs(want_dm) + 1e-6), s_
+        ch = O.Channel(s_)
+        ch.demod(ref_dm[s_])
+        assert by.get(s_, []) == [O.frame_tuple(f)[1:] for f in ch.frames], s_          # exact given the GPU's dm
+        ch2 = O.Channel(s_)
+        ch2.demod(want_dm)
+        e2e_off += len(set(by.get(s_, [])) ^ {O.frame_tuple(f)[1:] for f in ch2.frames})
+        total += len(ch.frames)
+    assert total >= nsrc // 2 and e2e_off <= (0 if exact else 1), (total, e2e_off)
+    dec.close()
+
+
 def test_chunking_and_pipeline_invariance_1024(env, tune):
     """1024 channels x 2.5 Msps: 1 call x 4 callbacks == 4 calls x 1 callback == pipeline chunk 1/2/off."""
     torch, D, S, K, O = env

@@ -272,8 +272,15 @@ def test_fir_kernel_variants_all_match_oracle(variant, M):
     segment, 1/2 static persistent partition without/with non-temporal loads, 3 the workgroup-granular dynamic
     dispenser, 4 LDS-DMA double buffering, 5 the default wave-private streaming kernel, 54 the same with 127.37
     subtracted per sample, 6 the matrix-pipe experiment, 7 the wave-private kernel with register-resident taps, 8 the same
-    with the results parked in LDS and written in chip-wide bursts): each one against the oracle, in a fresh process."""
-    env = dict(os.environ, ACG_FIR_VARIANT=variant)
+    with the results parked in LDS and written in chip-wide bursts): each one against the oracle, in a fresh process.  Only 5
+    and 3 exist in the product library; the others live in the lab build (libacarsdec_amd_lab.so), which the child loads
+    instead (ACARSDEC_AMD_LIB) -- and in the product library a lab variant's number must fall back to the default kernel."""
+    from acarsdec_amd import _capi as K
+    env = dict(os.environ, ACG_FIR_VARIANT=variant, ACG_ALLOW_TUNING="1")
+    if variant not in ("3", "5"):
+        r = subprocess.run([sys.executable, "-c", FIR_VARIANT_CHILD % dict(root=ROOT), str(M)], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("OK"), (r.stdout[-500:], r.stderr[-1500:])     # product: default kernel
+        env["ACARSDEC_AMD_LIB"] = K.LAB_PATH
     r = subprocess.run([sys.executable, "-c", FIR_VARIANT_CHILD % dict(root=ROOT), str(M)], capture_output=True, text=True,
                        timeout=600, env=env)
     assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("OK"), (r.stdout[-500:], r.stderr[-1500:])
@@ -287,7 +294,7 @@ def test_fir_direct_kernel_many_runs_scrambled_streams(D, O, M, ntaps, variant, 
     is a permutation (row lookup instead of the identity shortcut), fewer taps than the window (zero columns), and
     three launches in a row on the same dispenser (it re-arms itself).  Every channel against the oracle."""
     if variant:
-        tune("ACG_FIR_VARIANT", variant)      # (looked up at every launch) 7: register-resident taps, 26 loads per tile
+        tune("ACG_FIR_VARIANT", variant, lab=True)      # (looked up at every launch) 7: register-resident taps, 26 loads per tile; lab build
     rng = np.random.default_rng(4242 + M + ntaps)
     nch, nblk = 300, 8
     nout = nblk * 1024
@@ -297,7 +304,7 @@ def test_fir_direct_kernel_many_runs_scrambled_streams(D, O, M, ntaps, variant, 
     taps = np.stack([(O.rtl_taps(131000000 + 25000 * int(rng.integers(-40, 41)), 131000000, M)[:ntaps] * win[:, None]).astype(np.float32)
                      for c in range(nch)])
     perm = rng.permutation(nch)
-    dec = D.Decoder(nch, decim=M, ntaps=ntaps, max_blocks=nblk, bitlog=False)
+    dec = D.Decoder(nch, decim=M, ntaps=ntaps, max_blocks=nblk, bitlog=False, lab=bool(variant))
     dec.set_taps(taps)
     want = [None] * nch
     for rnd, smap in enumerate((np.arange(nch), perm, perm)):
@@ -880,8 +887,8 @@ def test_msk_two_wave_kernel_is_bit_identical_to_the_one_wave_kernel(D, O, S, tu
     cuts = [0, 2999, 2999, 3000, 3005, 3006, 3013, 3077, 7173, 7173 + 4096, n]        # calls of 2999, 0, 1, 5, 1, 7, 64, 4096, 4096, rest
 
     def run_dm(split):
-        tune("ACG_MSK_SPLIT", split)
-        dec = D.Decoder(nch, decim=8, ntaps=8, max_blocks=8)
+        tune("ACG_MSK_SPLIT", split, lab=True)             # (the two-wave kernel exists in the lab build only)
+        dec = D.Decoder(nch, decim=8, ntaps=8, max_blocks=8, lab=True)
         fr, bits = [], [[] for _ in range(nch)]
         for a0, a1 in zip(cuts[:-1], cuts[1:]):
             if a1 > a0:
@@ -921,8 +928,8 @@ def test_msk_two_wave_kernel_is_bit_identical_to_the_one_wave_kernel(D, O, S, tu
     row1 = 1024 * M * 2
 
     def run_iq(split):
-        tune("ACG_MSK_SPLIT", split)
-        dec = D.Decoder(20, decim=M, nstreams=3, max_blocks=3)
+        tune("ACG_MSK_SPLIT", split, lab=True)
+        dec = D.Decoder(20, decim=M, nstreams=3, max_blocks=3, lab=True)
         dec.set_taps(taps)
         dec.set_channel_streams(smap)
         fr, b0 = [], 0
@@ -984,7 +991,9 @@ def test_table_sincos_build_and_polynomial_sincos_build_agree_bit_for_bit(tmp_pa
     if not os.path.exists(_build.LIB_POLY):
         pytest.skip("checking build not present (build() makes it)")
     res = {}
-    for name, lib in (("table", _build.LIB), ("poly", _build.LIB_POLY)):
+    # (both are lab builds, which carry the two-wave kernel; msk.hip does not see ACG_LAB: the one-wave kernel of the lab build IS
+    #  the product's object file)
+    for name, lib in (("table", _build.LIB_LAB), ("poly", _build.LIB_POLY)):
         out = str(tmp_path / (name + ".npz"))
         r = subprocess.run([sys.executable, "-c", SINCOS_AB_CHILD % dict(root=ROOT, wav=os.path.join(ROOT, "tests", "golden", "testwav_pcm16.npz")), out],
                            capture_output=True, text=True, timeout=600, env=dict(os.environ, ACARSDEC_AMD_LIB=lib))
@@ -1037,6 +1046,79 @@ def test_streaming_collect_equals_blocking_drain(D, O, S):
         ch.demod(O.fir_u8(iq[c], M, taps[c]))
         assert results[0].get(c, []) == [O.frame_tuple(f) for f in ch.frames]
     assert sum(len(v) for v in results[0].values()) >= nch
+
+
+@pytest.mark.parametrize("nch,M", [(6, 160), (1200, 200)])
+def test_host_fed_calls_reuse_their_buffer_and_equal_device_fed_calls(D, O, S, nch, M):
+    """acg_process_iq_u8_host: two device staging buffers and a copy stream, the copy of call i+1 beside the
+    kernels of call i.  The contract is librtlsdr's (rtl.c:314-330): the buffer is the caller's again when the call returns --
+    so this host OVERWRITES its one buffer with garbage right after every call, from pageable memory, from acg_host_alloc memory
+    and from its own registered memory, with calls of varying size (1, 2, 2, 1, 2 callbacks: the staging slots alternate and a
+    short call follows a long one).  Blocks, every soft bit and the channel state equal the device-fed run; at 1200 channels the
+    down-converter runs on its CU-masked stream (two more events in the ordering)."""
+    import torch
+    from acarsdec_amd import _capi as K
+    rng = np.random.default_rng(31337 + nch)
+    sizes = [1, 2, 2, 1, 2]
+    nsrc = min(nch, 6)
+    total = sum(sizes) * 1024
+    env = np.zeros((nsrc, total))
+    for c in range(nsrc):
+        a, _ = S.channel_audio(rng, total, gap=(600, 1500), text_len=(3, 20))
+        env[c] = 0.5 * (1 + 0.5 * a)
+    off = [-325000, -300000, 75000, 150000, -50000, 25000]
+    src = np.stack([S.iq_u8_from_envelopes(env[c:c + 1], M, [off[c]], phases=[0.4 * c], noise=0.01, rng=rng).reshape(-1) for c in range(nsrc)])
+    iq = src[np.arange(nch) % nsrc]                                  # [nch, total * M * 2]
+    taps = np.stack([D.rtl_taps(131850000 + off[c % nsrc], 131850000, M) for c in range(nch)])
+    L = K.load()
+
+    def run(mode):
+        dec = D.Decoder(nch, decim=M, max_blocks=2, max_lag=1)
+        dec.set_taps(taps)
+        cap = 2 * 1024 * M * 2
+        if mode == "alloc":
+            p = L.acg_host_alloc(nch * cap)
+            assert p
+            buf = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_ubyte)), shape=(nch, cap))
+        else:
+            buf = np.empty((nch, cap), dtype=np.uint8)
+            p = buf.ctypes.data
+            if mode == "registered":
+                assert L.acg_host_register(p, buf.nbytes) == K.OK
+        blocks, bits, pos = [], [[] for _ in range(nsrc)], 0
+        dev_in = torch.from_numpy(iq).cuda() if mode == "dev" else None
+        for nb in sizes:
+            rowb = nb * 1024 * M * 2
+            if mode == "dev":
+                dec.in_callback(dev_in[:, pos:pos + rowb], nblocks=nb, pitch=dev_in.stride(0))
+            else:
+                buf[:, :rowb] = iq[:, pos:pos + rowb]
+                assert L.acg_process_iq_u8_host(dec.ctx, p, cap, nb) == K.OK
+                buf[:] = 0xA5                                   # the buffer is ours again: scribble over it at once
+            pos += rowb
+            n, fb = dec.collect_frames_raw(lag=1, max_frames=8 * nch + 64)
+            blocks += [D.frame_tuple(fb[i]) for i in range(n)]
+            if nch <= 64:                                       # (reading the bit log waits for the call: only where it is cheap)
+                for c in range(nsrc):
+                    bits[c].append(np.concatenate(dec.bits(c)))
+        blocks += [D.frame_tuple(f) for f in dec.drain_frames(8 * nch + 64)]
+        st = [dec.state(c) for c in range(0, nch, max(1, nch // 7))]
+        key = [(s_["MskPhi"], s_["MskDf"], s_["MskClk"], s_["MskS"], s_["idx"], s_["nbits"], s_["Acarsstate"], s_["inb"].tobytes()) for s_ in st]
+        dec.close()
+        if mode == "alloc":
+            L.acg_host_free(p)
+        elif mode == "registered":
+            assert L.acg_host_unregister(p) == K.OK
+        return sorted(blocks), [np.concatenate(b).tobytes() if b else b"" for b in bits], key
+    want = run("dev")
+    assert len(want[0]) >= nch
+    for mode in ("pageable", "alloc", "registered"):
+        got = run(mode)
+        assert got[0] == want[0] and got[1] == want[1] and got[2] == want[2], mode
+    for c in range(nsrc):                                            # and the oracle, end to end, on the originals
+        ch = O.Channel(c)
+        ch.demod(O.fir_u8(iq[c], M, taps[c]))
+        assert [b for b in want[0] if b[0] == c] == sorted(O.frame_tuple(f) for f in ch.frames), c
 
 
 @pytest.mark.parametrize("pipe", ["", "1", "3"])

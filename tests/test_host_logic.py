@@ -33,17 +33,34 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_tuning_switches_go_through_one_table_not_the_environment():
-    """ACG_* measurement switches: the library reads the environment once (and says so on stderr); afterwards only acg_tune
-    changes them.  Names outside the ACG_ prefix are refused."""
+    """ACG_* measurement switches live in one table that is EMPTY in a production process (a look-up is then one atomic load).
+    acg_tune fills it; the environment does only with ACG_ALLOW_TUNING=1 in the product library (a stray variable is named on
+    stderr and ignored -- ADVICE r03) and always in the lab build; names outside the ACG_ prefix are refused; no launch path
+    reads the environment; and the measurement-only kernels are not in the product library at all."""
     L = K.load()
-    assert L.acg_tune(b"ACG_FIR_VARIANT", b"55") == K.OK and L.acg_tune(b"ACG_FIR_VARIANT", None) == K.OK
+    assert L.acg_is_lab_build() == 0 and K.load(lab=True).acg_is_lab_build() == 1
+    assert L.acg_tune(b"ACG_FIR_VARIANT", b"3") == K.OK and L.acg_tune(b"ACG_FIR_VARIANT", None) == K.OK
     assert L.acg_tune(b"LD_PRELOAD", b"x") == K.EINVAL and L.acg_tune(None, b"1") == K.EINVAL
     src = open(os.path.join(ROOT, "acarsdec_amd", "csrc", "fir.hip")).read() + open(os.path.join(ROOT, "acarsdec_amd", "csrc", "msk.hip")).read()
     assert "getenv(" not in src                                   # no launch path reads the environment
     code = ("import os, sys; sys.path.insert(0, %r); os.environ['ACG_FIR_DEBUG_SHAPE'] = '1'\n"
-            "from acarsdec_amd import _capi as K; K.tune('ACG_MSK_LPC', 4)" % ROOT)
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+            "from acarsdec_amd import _capi as K; K.tune('ACG_MSK_LPC', 4, lab=%%s)" % ROOT)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("ACG_")}
+    r = subprocess.run([sys.executable, "-c", code % "False"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "IGNORED" in r.stderr and "ACG_FIR_DEBUG_SHAPE=1" in r.stderr and "taken from" not in r.stderr
+    r = subprocess.run([sys.executable, "-c", code % "False"], capture_output=True, text=True, timeout=300, env=dict(env, ACG_ALLOW_TUNING="1"))
     assert r.returncode == 0 and "tuning overrides taken from the environment" in r.stderr and "ACG_FIR_DEBUG_SHAPE=1" in r.stderr
+    r = subprocess.run([sys.executable, "-c", code % "True"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "tuning overrides taken from the environment" in r.stderr           # the lab build always takes it
+    # the product library carries the product's kernels only
+    sym = subprocess.run(["nm", "-D", "--defined-only", K.LIB_PATH], capture_output=True, text=True).stdout
+    lab = subprocess.run(["nm", "-D", "--defined-only", K.LAB_PATH], capture_output=True, text=True).stdout
+    for name in ("fir_u8_coltap_kernel", "fir_u8_mfma_kernel", "fir_u8_dma_kernel", "fir_u8_tile_kernel", "msk_demod2_kernel", "acg_launch_msk2"):
+        assert name not in sym and name in lab, name
+    for name in ("fir_u8_direct_kernel", "fir_u8_persist_kernel", "fir_u8_shared_kernel", "fir_u8_generic_kernel", "fir_fmt_direct_kernel",
+                 "msk_demod_kernel", "blk_repair_kernel", "msg_split_kernel"):
+        assert name in sym, name
+    assert os.path.getsize(K.LIB_PATH) < 0.75 * os.path.getsize(K.LAB_PATH)
 
 
 def test_device_sincos_model_keeps_the_mixer_products_of_glibc_cexp(tmp_path):
@@ -220,8 +237,8 @@ def test_build_recipe_keeps_the_exactness_critical_flags():
     """msk.hip must be built without multiply-add contraction (the reference's IEEE build keeps mul and add
     separate, msk.c:86-113) and host_setup.c likewise; the -mllvm switches may only be layout switches."""
     src = open(os.path.join(ROOT, "acarsdec_amd", "_build.py")).read()
-    unit = src[src.index('("msk.hip"'):src.index('("synth.hip"')]
-    assert '"-ffp-contract=off"' in unit
+    unit = src[src.index('MSK_FLAGS = ['):src.index('UNITS = [')]
+    assert '"-ffp-contract=off"' in unit and '("msk.hip", MSK_FLAGS, True)' in src and '("msk2.hip", MSK_FLAGS, False)' in src
     assert "fast-math" not in src and "-Ofast" not in src and "-ffast" not in src
     assert re.search(r'"gcc", "-O2", "-ffp-contract=off"', src)
     allowed = {"-amdgpu-sched-strategy=max-ilp", "-disable-machine-sink", "-disable-branch-fold", "-disable-tail-duplicate",
@@ -250,7 +267,7 @@ def test_async_ticket_register_is_left_alone_until_its_wait():
     if not hipcc:
         pytest.skip("hipcc not available")
     csrc = os.path.join(ROOT, "acarsdec_amd", "csrc")
-    r = subprocess.run([hipcc, "--offload-arch=gfx950", "--cuda-device-only", "-std=c++17", "-O3", "-I" + csrc,
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "--cuda-device-only", "-std=c++17", "-O3", "-DACG_LAB", "-I" + csrc,      # (the lab build: every kernel)
                         "-I" + os.path.join(ROOT, "include"), "-S", "-o", "-", os.path.join(csrc, "fir.hip")],
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
