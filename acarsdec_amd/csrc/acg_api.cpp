@@ -141,6 +141,8 @@ struct acg_ctx {
     hipStream_t stream = nullptr;
     hipStream_t msk_stream = nullptr;   // demodulator launches (they carry the channel state) run here, in order
     hipStream_t copy_stream = nullptr;  // result copies that must not queue behind running kernels
+    hipStream_t post_stream = nullptr;  // ACG_F_REPAIR: the block thread's pass over a call's blocks, OFF the demodulator's serial chain
+    hipEvent_t msk_end[8] = {};         // per call slot: the call's last demodulator launch has finished
     hipEvent_t in_ev = nullptr;
     hipStream_t fir_stream = nullptr;   // CU partition: down-converter on the CUs the demodulator does not own
     hipEvent_t fir_in = nullptr, fir_out = nullptr;
@@ -293,6 +295,8 @@ static void free_all(acg_ctx* c)
     if (c->fir_stream) hipStreamDestroy(c->fir_stream);
     if (c->msk_stream) hipStreamDestroy(c->msk_stream);
     if (c->copy_stream) hipStreamDestroy(c->copy_stream);
+    if (c->post_stream) hipStreamDestroy(c->post_stream);
+    for (auto e : c->msk_end) if (e) hipEventDestroy(e);
     if (c->h2d_stream) hipStreamDestroy(c->h2d_stream);
     if (c->h2d_done) hipEventDestroy(c->h2d_done);
     for (auto e : c->stage_free) if (e) hipEventDestroy(e);
@@ -406,15 +410,11 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
     int rc = ACG_OK;
     auto body = [&]() -> int {
         HIPCHK(c, hipSetDevice(cfg->device));
-        // (probe switch, profiles/probe/context_probe.py: streams with a CU mask get an HSA queue of their OWN instead of
-        //  one out of the runtime's pool of shared hardware queues; 1 = the demodulator stream, 2 = the context's stream too)
-        const int dedicated = acg_tune_get("ACG_STREAMS_DEDICATED", 0);
         int total_cus = 256;
         (void)hipDeviceGetAttribute(&total_cus, hipDeviceAttributeMultiprocessorCount, cfg->device);
         uint32_t full_mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int cu = 0; cu < total_cus && cu < 256; ++cu) full_mask[cu >> 5] |= 1u << (cu & 31);
-        if (dedicated >= 2) HIPCHK(c, hipExtStreamCreateWithCUMask(&c->stream, 8, full_mask));
-        else HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         {
             // CU partition (ACG_MSK_CUS=n): the demodulator's few long-lived waves get n CUs of their own
             // (mask bits [0, n)) and the down-converter runs on the other 256 - n through an internal
@@ -435,7 +435,11 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
                 // a stream of its own priority class gets a hardware queue of its own
                 int lo = 0, hi = 0;
                 HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
-                if (dedicated >= 1) HIPCHK(c, hipExtStreamCreateWithCUMask(&c->msk_stream, 8, full_mask));
+                // >= 16 384 channels the down-converter is the longer stage and the demodulator fills its gaps: there a queue of
+                // the demodulator's own at NORMAL priority (a stream with a CU mask -- all CUs -- gets an HSA queue of its own
+                // instead of one out of the runtime's shared pool) measured 2.7 % faster per call than the high-priority stream
+                // (profiles/r04_context_probe.txt: 9.38 -> 9.13 ms; at 4096 channels the high-priority stream wins by 11 %)
+                if (cfg->nch >= 16384) HIPCHK(c, hipExtStreamCreateWithCUMask(&c->msk_stream, 8, full_mask));
                 else HIPCHK(c, hipStreamCreateWithPriority(&c->msk_stream, hipStreamNonBlocking, hi));
             }
         }
@@ -482,8 +486,10 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
             acg_host_crc_tables_n(tabs.data(), tabs.data() + 256, 243);
             HIPCHK(c, hipMalloc(&c->d_crctab, tabs.size() * sizeof(unsigned short)));
             HIPCHK(c, hipMemcpy(c->d_crctab, tabs.data(), tabs.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
-            HIPCHK(c, hipMalloc(&c->d_rep_upto, sizeof(unsigned int)));
-            HIPCHK(c, hipMemset(c->d_rep_upto, 0, sizeof(unsigned int)));
+            HIPCHK(c, hipMalloc(&c->d_rep_upto, 2 * sizeof(unsigned int)));       // {blocks through the pass, workgroups finished}
+            HIPCHK(c, hipMemset(c->d_rep_upto, 0, 2 * sizeof(unsigned int)));
+            HIPCHK(c, hipStreamCreateWithFlags(&c->post_stream, hipStreamNonBlocking));
+            for (auto& e : c->msk_end) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
         float h[136] = {0};
         acg_host_msk_h(h);                               // msk.c:44-48
@@ -538,7 +544,8 @@ extern "C" int acg_reset(acg_ctx* ctx)
     for (auto& s : st) s.nbits = 8;
     HIPCHK(ctx, hipMemcpy(ctx->d_st, st.data(), st.size() * sizeof(AcgChan), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemset(ctx->d_frame_count, 0, sizeof(unsigned int)));
-    if (ctx->d_rep_upto) HIPCHK(ctx, hipMemset(ctx->d_rep_upto, 0, sizeof(unsigned int)));
+    if (ctx->d_rep_upto) HIPCHK(ctx, hipMemset(ctx->d_rep_upto, 0, 2 * sizeof(unsigned int)));
+    std::memset(ctx->h_call_count, 0, sizeof(unsigned int) * acg_ctx::NCALL);
     int zr = zero_sync(ctx, ctx->d_nbits, (size_t)ctx->cfg.nch * sizeof(int));
     if (zr != ACG_OK) return zr;
     ctx->last_len = 0;
@@ -782,13 +789,21 @@ extern "C" int acg_fir_only_dev(acg_ctx* ctx, const uint8_t* iq_dev, size_t pitc
 static int end_of_call(acg_ctx* ctx)
 {
     const int slot = (int)(ctx->call_seq % acg_ctx::NCALL);
-    if (ctx->d_crctab) {          // ACG_F_REPAIR: the block thread's work on whatever this call queued
-        const int e = acg_launch_blk_repair(ctx->d_frames, ctx->frame_cap, ctx->d_frame_count, ctx->d_rep_upto,
-                                            ctx->d_crctab + 256, ctx->d_crctab, ctx->msk_stream);
-        if (e != 0) return fail(ctx, ACG_EHIP, "block repair launch failed");
-    }
     // the queue length of this call was published by its last demodulator launch (MskArgs::snap)
-    HIPCHK(ctx, hipEventRecord(ctx->call_done[slot], ctx->msk_stream));
+    if (ctx->d_crctab) {
+        // ACG_F_REPAIR: the block thread's work (acars.c:93-215) on what this call queued -- on a stream of its OWN, behind the
+        // call's last demodulator launch: the demodulator of the next call does not wait for it (on its stream the pass sat on
+        // the serial chain that sets the step at <= 2048 channels and cost 30 % of the headline: profiles/LEDGER.md round 4).
+        // The pass ends at the call's published queue length, not at the live counter the next call is already moving.
+        HIPCHK(ctx, hipEventRecord(ctx->msk_end[slot], ctx->msk_stream));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->post_stream, ctx->msk_end[slot], 0));
+        const int e = acg_launch_blk_repair(ctx->d_frames, ctx->frame_cap, ctx->d_call_count + slot, ctx->d_rep_upto, ctx->d_rep_upto + 1,
+                                            ctx->d_crctab + 256, ctx->d_crctab, ctx->post_stream);
+        if (e != 0) return fail(ctx, ACG_EHIP, "block repair launch failed");
+        HIPCHK(ctx, hipEventRecord(ctx->call_done[slot], ctx->post_stream));
+    } else {
+        HIPCHK(ctx, hipEventRecord(ctx->call_done[slot], ctx->msk_stream));
+    }
     ctx->call_seq++;
     return ACG_OK;
 }
@@ -944,6 +959,7 @@ extern "C" int acg_sync(acg_ctx* ctx)
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->msk_stream));
+    if (ctx->post_stream) HIPCHK(ctx, hipStreamSynchronize(ctx->post_stream));
     return ACG_OK;
 }
 

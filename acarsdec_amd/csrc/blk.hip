@@ -25,14 +25,20 @@ __device__ __forceinline__ bool crc_acceptable(const unsigned short* synd, unsig
     return false;
 }
 
-__global__ void blk_repair_kernel(AcgFrameRec* frames, unsigned int cap, const unsigned int* count,
-                                  const unsigned int* done_upto, const unsigned short* synd,
-                                  const unsigned short* crctab)
+__global__ void blk_repair_kernel(AcgFrameRec* frames, unsigned int cap, const unsigned int* upto,
+                                  unsigned int* done_upto, unsigned int* done_ctr, const unsigned short* synd,
+                                  const unsigned short* crctab_g)
 {
-    // at most one lap of the ring: if the demodulator queued more than `cap` blocks since the last repair pass
-    // (the host reports that as ACG_EOVERFLOW), the surviving newest `cap` are each processed exactly once
-    const unsigned int hi = *count;
-    const unsigned int lo = (hi - *done_upto > cap) ? hi - cap : *done_upto;
+    // The pass covers blocks [*done_upto, *upto): `upto` is the queue length the call's last demodulator launch published
+    // (a host-mapped word), NOT the live counter -- the pass runs on a stream of its own beside the demodulator of the NEXT
+    // call, which is appending records behind that mark.  At most one lap of the ring: if more than `cap` blocks were queued
+    // since the last pass (the host reports that as ACG_EOVERFLOW), the surviving newest `cap` are each processed once.
+    __shared__ unsigned short crctab[256];
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) crctab[i] = crctab_g[i];
+    __syncthreads();
+    const unsigned int hi = __hip_atomic_load(upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned int from = *done_upto;
+    const unsigned int lo = (hi - from > cap) ? hi - cap : from;
     for (unsigned int q = lo + blockIdx.x * blockDim.x + threadIdx.x; q - lo < hi - lo; q += gridDim.x * blockDim.x) {
         AcgFrameRec* f = frames + (q % cap);
         const int len = f->len;
@@ -93,6 +99,16 @@ __global__ void blk_repair_kernel(AcgFrameRec* frames, unsigned int cap, const u
             txt[i] &= 0x7f;
         }
         f->status = pn2 ? 2 : 1;
+    }
+    // the last workgroup out moves the mark (every workgroup has read it by then) and re-arms the counter
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned int d = atomicAdd(done_ctr, 1u);
+        if (d == gridDim.x - 1) {
+            __hip_atomic_store(done_upto, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(done_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -163,13 +179,10 @@ extern "C" int acg_launch_msg_split(const AcgFrameRec* frames, unsigned int cap,
     return (int)hipGetLastError();
 }
 
-__global__ void blk_advance_kernel(unsigned int* done_upto, const unsigned int* count) { *done_upto = *count; }
-
-extern "C" int acg_launch_blk_repair(AcgFrameRec* frames, unsigned int cap, const unsigned int* count,
-                                     unsigned int* done_upto, const unsigned short* synd,
+extern "C" int acg_launch_blk_repair(AcgFrameRec* frames, unsigned int cap, const unsigned int* upto,
+                                     unsigned int* done_upto, unsigned int* done_ctr, const unsigned short* synd,
                                      const unsigned short* crctab, void* stream)
 {
-    hipLaunchKernelGGL(blk_repair_kernel, dim3(64), dim3(64), 0, (hipStream_t)stream, frames, cap, count, done_upto, synd, crctab);
-    hipLaunchKernelGGL(blk_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, done_upto, count);
+    hipLaunchKernelGGL(blk_repair_kernel, dim3(64), dim3(64), 0, (hipStream_t)stream, frames, cap, upto, done_upto, done_ctr, synd, crctab);
     return (int)hipGetLastError();
 }

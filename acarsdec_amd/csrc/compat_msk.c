@@ -1,98079 +1,194 @@
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-//* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-'/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-w/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-B/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-I/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-N/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-S/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-I/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-D/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-E/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-'/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-w/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-W/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-I/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-T/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-H/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-'/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-y/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-:/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-6/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-2/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-7/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-4/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-I/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-N/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-S/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-T/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-E/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-D/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-y/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-y/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-y/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-I/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-x/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-:/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-9/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-:/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-3/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-5/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-S/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-K/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-:/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-9/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-:/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-6/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-7/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-3/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-7/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-3/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-2/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-x/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-:/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-3/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-4/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-3/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-6/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-y/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-:/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-3/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-6/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-4/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-D/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-:/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-G/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-P/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-U/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-w/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-S/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-K/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-w/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-F/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-S/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-w/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-D/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-//* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-S/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-:/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-2/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-4/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-2/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-2/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-5/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-9/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-2/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-7/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-4/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-y/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-{/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-y/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-}/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-y/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-'/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-:/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-5/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-3/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-6/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-3/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-2/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-3/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-U/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-N/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-H/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-N/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-G/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-E/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-D/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-y/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-x/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-y/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-:/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-S/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-K/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-w/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-y/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-T/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-P/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-U/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-:/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-G/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-P/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-U/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-y/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-x/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-U/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-:/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-4/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-5/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-6/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-4/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-5/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-9/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-//* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-#/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-</* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-#/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-</* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-#/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-</* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-#/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-</* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-#/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-#/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-#/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-F/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-L/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-E/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-N/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-I/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-N/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-T/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-R/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-T/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-E/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-//* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-2/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-+/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-x/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-//* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-x/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-S/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-K/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-//* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-x/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-//* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-x/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-//* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-w/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-x/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-{/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-:/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-%/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-:/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-%/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-%/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-\/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-w/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-?/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-:/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-x/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-}/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-{/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-//* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-:/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-3/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-4/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-4/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-2/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-:/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-//* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-P/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-S/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-D/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-x/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-F/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-L/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-E/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-N/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-z/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-x/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-N/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-U/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-L/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-L/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-}/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-x/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-{/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-&/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-z/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-P/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-P/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-D/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-D/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-L/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-S/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-L/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-S/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-B/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-B/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-S/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-S/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-x/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-x/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-</* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-F/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-L/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-E/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-N/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-+/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-+/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-{/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-[/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-2/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-]/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-[/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-]/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-[/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-2/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-+/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-]/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-[/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-]/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-}/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-?/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-:/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-?/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-:/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-&/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-!/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-G/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-O/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-K/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-}/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-w/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-x/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-{/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-&/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-!/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-G/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-O/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-K/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-//* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-w/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-y/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-y/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-w/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-y/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-//* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-P/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-P/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-D/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-D/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-S/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-S/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-x/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-x/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-</* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-F/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-L/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-E/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-N/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-+/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-+/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-[/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-]/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-[/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-2/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-]/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-+/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-[/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-2/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-+/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-]/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-I/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-}/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-//* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-:/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-2/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-3/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-+/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-:/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-5/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-3/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-6/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-3/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-'/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-//* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-{/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-[/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-]/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-L/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-S/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-+/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-//* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-4/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-B/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-+/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-+/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-|/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-x/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-8/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-</* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-}/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-//* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-T/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-w/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-w/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-y/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-'/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-w/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-'/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-q/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-y/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-G/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-E/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-O/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-V/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-E/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-R/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-F/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-L/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-O/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-W/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-y/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-y/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-w/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-w/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-y/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-y/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-//* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-x/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-{/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-[/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-8/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-]/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-8/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-&/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-!/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-G/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-O/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-K/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-&/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-&/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-!/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-G/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-E/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-O/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-V/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-E/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-R/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-F/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-L/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-O/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-W/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-}/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-S/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-K/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-{/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-[/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-]/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-</* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-N/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-U/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-L/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-L/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-|/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-|/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-+/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-G/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-B/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-L/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-O/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-K/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-//* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-G/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-B/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-L/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-O/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-K/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-{/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-y/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-&/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-z/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-+/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-G/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-B/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-L/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-O/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-K/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-//* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-G/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-B/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-L/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-O/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-K/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-</* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-4/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-4/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-//* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-:/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-2/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-7/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-X/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-N/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-B/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-F/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-R/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-E/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-S/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-4/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-9/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-6/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-//* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-8/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-8/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-x/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-G/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-F/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-B/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-I/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-T/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-L/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-O/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-G/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-&/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-&/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-!/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-G/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-O/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-K/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-N/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-U/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-L/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-L/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-}/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-[/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-]/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
->/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-z/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-!/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-G/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-O/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-K/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-y/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-!/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-G/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-O/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-K/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-y/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-w/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-}/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-#/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-W/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-I/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-T/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-H/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-R/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-T/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-L/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-3/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-2/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-x/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-{/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-[/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-X/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-N/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-B/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-H/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-N/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-N/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-E/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-L/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-S/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-]/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-x/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-!/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-3/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-2/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-G/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-B/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-L/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-O/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-K/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-2/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-{/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-//* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-:/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-3/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-2/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-2/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-3/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-2/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-6/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-//* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-w/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-:/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-\/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-}/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-N/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-U/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-L/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-L/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-{/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-z/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-2/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-z/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-&/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-z/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-x/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-G/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-F/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-B/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-I/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-T/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-L/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-O/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-G/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-&/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-&/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-!/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-G/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-O/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-K/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-N/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-U/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-L/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-L/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-</* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-+/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-+/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-//* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-w/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-R/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-:/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-2/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-8/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-3/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-2/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-8/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-6/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-//* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-</* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-+/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-+/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-{/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-[/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-2/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-z/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-+/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-]/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-[/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-]/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-w/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-[/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-]/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-[/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-2/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-z/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-M/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-+/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-+/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-]/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-[/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-]/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-w/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-[/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-]/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-}/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-!/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-G/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-O/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-K/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-}/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-</* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-+/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-+/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-{/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-[/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-]/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-&/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-[/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-]/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-&/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-[/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-]/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-}/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-q/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-8/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-z/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-1/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-!/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-G/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-O/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-K/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-q/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-</* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-+/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-+/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-//* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-:/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-3/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-5/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-3/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-:/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-y/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-//* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-[/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-]/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-m/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-u/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-G/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-B/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-L/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-O/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-K/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-y/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-!/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-A/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-C/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-G/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-O/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-K/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-//* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-./* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-:/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-3/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-5/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-7/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
--/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-3/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-6/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-*/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-//* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-p/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-y/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-"/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-=/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-0/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-</* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-+/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-+/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-w/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-,/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
- /* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-&/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-h/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-[/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-]/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-	/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-a/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-v/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-b/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-o/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-c/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-k/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-s/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-(/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-g/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-_/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-r/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-t/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-l/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-)/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-;/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-}/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-#/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-e/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
+/*
+ * compat_msk.c -- the reference's own call surface on top of libacarsdec_amd.so.
+ *
+ * Build this file INSIDE the reference tree (it includes the reference's acarsdec.h and must be
+ * compiled with the same WITH_* macros as the rest of acarsdec, because channel_t's layout
+ * depends on them, acarsdec.h:62-74) and link it INSTEAD of msk.c.  acars.c, output.c,
+ * acarsdec.c, soundfile.c ... stay byte-for-byte unchanged.  It exports
+ *
+ *     int  initMsk(channel_t *ch);            acarsdec.h:190, replaces msk.c:30-51
+ *     void demodMSK(channel_t *ch, int len);  acarsdec.h:191, replaces msk.c:67-137
+ *     void acarsdec_amd_in_callback(unsigned char *buf, uint32_t nread, void *ctx);
+ *                                             replaces the static in_callback, rtl.c:314-361
+ *                                             (pass it to rtlsdr_read_async at rtl.c:364)
+ *
+ * Division of labour: the GPU runs the down-converter and the MSK loop (with a device mirror of
+ * the framing FSM, needed because decodeAcars() writes MskDf/MskS back into the loop,
+ * acars.c:242,259,274); every decided bit comes back as {soft symbol, level} and is replayed here
+ * through the reference's putbit() arithmetic (msk.c:53-63,112-113) into the UNCHANGED
+ * decodeAcars().  channel_t stays the state carrier exactly as in the reference: its MSK fields
+ * are uploaded before and downloaded after every call.
+ *
+ * There is no CPU fallback: if the GPU library fails the process exits like the reference does
+ * on "Unable to init internal decoders" (acarsdec.c:456-459).
+ */
+#include <stdlib.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdint.h>
+#include "acarsdec.h"
+#include "acarsdec_amd.h"
 
-n/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-d/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-i/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
-f/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
-
+#define FLEN ((INTRATE / 1200) + 1)
 
-/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
- * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
- * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
-static void discard_device_blocks(acg_ctx *g)
-{
-	acg_frame f[8];
-	int n = 0, rc;
-	do {
-		rc = acg_drain_frames(g, f, 8, &n);
-	} while (rc == ACG_EAGAIN);
-	if (rc != ACG_OK)
-		die("drain_frames", g, rc);
-}
+static acg_ctx *g_msk;          /* 1-channel context behind demodMSK() */
+static int g_msk_blocks;
+static acg_ctx *g_rtl;          /* nbch-channel context behind acarsdec_amd_in_callback() */
 
+static void die(const char *what, acg_ctx *c, int rc)
+{
+	fprintf(stderr, "acarsdec_amd: %s: %s (%s)\n", what, acg_strerror(rc), c ? acg_last_error(c) : "");
+	exit(1);
+}
+
+int initMsk(channel_t *ch)
+{
+	/* msk.c:34-42: same observable effect on channel_t */
+	ch->MskPhi = ch->MskClk = 0;
+	ch->MskS = 0;
+	ch->MskDf = 0;
+	ch->idx = 0;
+	ch->inb = calloc(FLEN, sizeof(float complex));
+	if (ch->inb == NULL)
+		return -1;
+	return 0;
+}
+
+static void upload(acg_ctx *c, int slot, const channel_t *ch)
+{
+	acg_chan_state st;
+	int i, rc;
+	memset(&st, 0, sizeof(st));
+	st.MskPhi = ch->MskPhi; st.MskDf = ch->MskDf; st.MskLvlSum = ch->MskLvlSum;
+	st.MskClk = ch->MskClk; st.MskBitCount = ch->MskBitCount;
+	st.MskS = ch->MskS; st.idx = ch->idx;
+	for (i = 0; i < FLEN; i++) {
+		st.inb[2 * i] = crealf(ch->inb[i]);
+		st.inb[2 * i + 1] = cimagf(ch->inb[i]);
+	}
+	st.outbits = ch->outbits; st.nbits = ch->nbits; st.Acarsstate = ch->Acarsstate;
+	st.blk_len = ch->blk ? ch->blk->len : 0;
+	st.blk_err = ch->blk ? ch->blk->err : 0;
+	if ((rc = acg_set_state(c, slot, &st)) != ACG_OK)
+		die("set_state", c, rc);
+}
+
+static void download(acg_ctx *c, int slot, channel_t *ch)
+{
+	acg_chan_state st;
+	int i, rc;
+	if ((rc = acg_get_state(c, slot, &st)) != ACG_OK)
+		die("get_state", c, rc);
+	/* the loop state lives on the device; the framing state was advanced by the replay below
+	 * through the real decodeAcars() and is already in *ch */
+	ch->MskPhi = st.MskPhi; ch->MskDf = st.MskDf; ch->MskClk = st.MskClk;
+	ch->MskS = st.MskS; ch->idx = st.idx;
+	for (i = 0; i < FLEN; i++)
+		ch->inb[i] = st.inb[2 * i] + st.inb[2 * i + 1] * I;
+}
+
+/* msk.c:112-113 + putbit() msk.c:53-63, on the caller's channel_t */
+static void bit_sink(void *user, int slot, float vo, float lvl)
+{
+	channel_t *ch = ((channel_t **)user)[slot];
+	ch->MskLvlSum += lvl * lvl / 4;
+	ch->MskBitCount++;
+	ch->outbits >>= 1;
+	if (vo > 0)
+		ch->outbits |= 0x80;
+	ch->nbits--;
+	if (ch->nbits <= 0)
+		decodeAcars(ch);
+}
+
+/* The device assembles blocks as well; this view replays the bits through the caller's own decodeAcars()
+ * instead, so the device's copies are dropped to keep its queue empty (ACG_EAGAIN: more are waiting than the
+ * scratch holds, come again; ACG_EOVERFLOW cannot happen to a host that drains after every call). */
+static void discard_device_blocks(acg_ctx *g)
+{
+	acg_frame f[8];
+	int n = 0, rc;
+	do {
+		rc = acg_drain_frames(g, f, 8, &n);
+	} while (rc == ACG_EAGAIN);
+	if (rc != ACG_OK)
+		die("drain_frames", g, rc);
+}
+
+void demodMSK(channel_t *ch, int len)
+{
+	int rc;
+	channel_t *one[1];
+
+	if (len <= 0)
+		return;
+	if (g_msk == NULL || (len + ACG_BLOCK - 1) / ACG_BLOCK > g_msk_blocks) {
+		acg_config cfg;
+		if (g_msk)
+			acg_destroy(g_msk);
+		memset(&cfg, 0, sizeof(cfg));
+		g_msk_blocks = (len + ACG_BLOCK - 1) / ACG_BLOCK;
+		if (g_msk_blocks < 4)
+			g_msk_blocks = 4;                     /* soundfile.c:27 MAXNBFRAMES 4096 */
+		cfg.nch = 1; cfg.nstreams = 1; cfg.decim = 8; cfg.ntaps = 8;
+		cfg.max_blocks = g_msk_blocks;
+		cfg.flags = ACG_F_BITLOG;
+		cfg.max_lag = 1;                              /* drained after every call */
+		if ((rc = acg_create(&g_msk, &cfg)) != ACG_OK)
+			die("acg_create", NULL, rc);
+	}
+	one[0] = ch;
+	upload(g_msk, 0, ch);
+	if ((rc = acg_process_dm_host(g_msk, ch->dm_buffer, (size_t)len, len)) != ACG_OK)
+		die("process_dm", g_msk, rc);
+	if ((rc = acg_replay_bits(g_msk, bit_sink, one)) != ACG_OK)
+		die("replay", g_msk, rc);
+	download(g_msk, 0, ch);
+	discard_device_blocks(g_msk);
+}
+
+#ifdef WITH_RTL
+void acarsdec_amd_in_callback(unsigned char *rtlinbuff, uint32_t nread, void *ctx)
+{
+	unsigned int n;
+	int rc;
+	channel_t *chs[MAXNBCHANNELS];
+	(void)ctx;
+
+	if (nread != (uint32_t)(ACG_BLOCK * rtlMult * 2)) {          /* rtl.c:322-326 */
+		fprintf(stderr, "warning: partial read\n");
+		return;
+	}
+	if (g_rtl == NULL) {
+		acg_config cfg;
+		float *taps = malloc(sizeof(float) * 2 * (size_t)rtlMult * nbch);
+		int k;
+		memset(&cfg, 0, sizeof(cfg));
+		cfg.nch = (int)nbch; cfg.nstreams = 1; cfg.decim = rtlMult; cfg.ntaps = rtlMult;
+		cfg.max_blocks = 1; cfg.flags = ACG_F_BITLOG; cfg.max_lag = 1;
+		if ((rc = acg_create(&g_rtl, &cfg)) != ACG_OK)
+			die("acg_create", NULL, rc);
+		for (n = 0; n < nbch; n++)                           /* wf from initRtl, rtl.c:283-286 */
+			for (k = 0; k < rtlMult; k++) {
+				taps[2 * ((size_t)n * rtlMult + k)] = crealf(channel[n].wf[k]);
+				taps[2 * ((size_t)n * rtlMult + k) + 1] = cimagf(channel[n].wf[k]);
+			}
+		if ((rc = acg_set_taps(g_rtl, 0, (int)nbch, taps)) != ACG_OK)
+			die("set_taps", g_rtl, rc);
+		free(taps);
+	}
+	for (n = 0; n < nbch; n++) {
+		chs[n] = &channel[n];
+		upload(g_rtl, (int)n, &channel[n]);
+	}
+	if ((rc = acg_process_iq_u8_host(g_rtl, rtlinbuff, (size_t)nread, 1)) != ACG_OK)
+		die("process_iq", g_rtl, rc);
+	for (n = 0; n < nbch; n++)                                   /* rtl.c:353: dm_buffer stays observable */
+		acg_read_dm(g_rtl, (int)n, channel[n].dm_buffer, ACG_BLOCK);
+	if ((rc = acg_replay_bits(g_rtl, bit_sink, chs)) != ACG_OK)       /* rtl.c:357-360 order */
+		die("replay", g_rtl, rc);
+	for (n = 0; n < nbch; n++)
+		download(g_rtl, (int)n, &channel[n]);
+	discard_device_blocks(g_rtl);
+}
+#endif

@@ -166,6 +166,11 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
     // few channels: this serial chain is the critical path of the whole job -> win issue arbitration;
     // many channels: the down-converter is, and these waves have slack -> stay at normal priority
     if (a.high_prio) __builtin_amdgcn_s_setprio(3);
+#ifdef ACG_MSK_AB_PICK_EXEC
+    unsigned long long pick_mask[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pick_mask[u] = __builtin_amdgcn_ballot_w64(g == u);
+#endif
     STAMP_DECL
 #ifdef ACG_MSK_STAMP
     unsigned long long stamp_iters = 0, stamp_bits = 0;
@@ -221,6 +226,18 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
         //  fifth step below needs no end-of-buffer predicate on the serial phase / clock chains: 3.5 % per bit)
         const bool quick = (s > 0) && !((double)c4 >= thr) && (n + 6 <= len);
         if (n < len && quick) {
+#ifdef ACG_MSK_AB_PICK_EXEC
+                // A/B build only: the per-lane phase pick as an EXEC-masked 64-bit move (1 VALU + 2 SALU) instead of the two
+                // v_cndmask_b32 the compiler makes of the select
+                if constexpr (LPC == 8) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        unsigned long long sv_;
+                        asm volatile("s_and_saveexec_b64 %1, %2\n\tv_mov_b64 %0, %3\n\ts_mov_b64 exec, %1"
+                                     : "+v"(myp[0]), "=&s"(sv_) : "s"(pick_mask[u]), "v"(pq[u]));
+                    }
+                } else
+#endif
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
                     if ((u % LPC) == g) myp[u / LPC] = pq[u];
@@ -274,7 +291,19 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
         unsigned int idx_n = idx + (unsigned int)cnt;
         if (idx_n >= FLEN) idx_n -= FLEN;
         const float clk_f = fired ? (float)((double)L.clk - K_3PI2) : L.clk;   // msk.c:100
+#ifdef ACG_MSK_AB_TAPPHASE_FAST
+        // A/B build only (profiles/probe/build_ab.py; never in the product): the quotient from rcp + ONE Newton step, no
+        // remainder step -- 4 instructions fewer, and no longer the correctly rounded quotient: o can differ from the
+        // reference's where 12 (q + 0.5) lies within an ulp or two of an integer.  What it would buy is in profiles/LEDGER.md.
+        int o;
+        {
+            double r_ = __builtin_amdgcn_rcp(s);
+            r_ = __builtin_fma(r_, __builtin_fma(-s, r_, 1.0), r_);
+            o = (int)(MFLTOVER * ((double)clk_f * r_ + 0.5));
+        }
+#else
         int o = (int)(MFLTOVER * (div1_rcp((double)clk_f, s) + 0.5));           // msk.c:103
+#endif
         if (o > MFLTOVER) o = MFLTOVER;
         if (o < 0) o = 0;          // memory safety only: the reference indexes h[] out of bounds here
         typedef float f2v __attribute__((ext_vector_type(2)));
