@@ -748,16 +748,19 @@ def run_case(J, name, case, args, steps, warmup, headline):
     if fmt == 0:
         kname = "fir_u8_shared_kernel" if share > 1 else J.fir_kernel_name(M, nout)
     else:
-        # (mirrors acg_launch_fir_fmt: the wave-private kernel where it is instantiated for the window length)
-        direct = int(os.environ.get("ACG_FIR_VARIANT", "5")) >= 5 and M in {"cs16": (160, 192, 200), "f32": (200, 240, 480, 800), "split16": (160,)}[fmt_name]
-        kname = ("fir_fmt_direct_kernel<%s>" if direct else "fir_fmt_kernel<%s>") % fmt_name
+        # (mirrors acg_launch_fir_fmt: the wave-private kernel <FMT, 16-byte chunks per window (per plane), windows per tile> where it is
+        #  instantiated for the window length, else round 1's workgroup-granular kernel)
+        fid = {"cs16": 1, "split16": 2, "f32": 3}[fmt_name]
+        shape = {("cs16", 160): (40, 32), ("cs16", 192): (48, 32), ("cs16", 200): (50, 32), ("f32", 200): (50, 32), ("f32", 240): (60, 16),
+                 ("f32", 480): (120, 8), ("f32", 800): (200, 8), ("split16", 160): (20, 64)}.get((fmt_name, M))
+        kname = ("fir_fmt_direct_kernel<%d, %d, %d>" % ((fid,) + shape)) if shape else "fir_fmt_kernel<%d>" % fid
     # HBM traffic of this launch shape from the committed PMC passes (rocprofv3 cannot run inside the timed
-    # process): looked up, not measured in this run -- the source is named next to the number
+    # process): looked up by the full kernel signature and launch shape, not measured in this run -- the source is named next to the number
     traffic, traffic_src = None, None
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             for e in json.load(f)["entries"]:
-                if fmt == 0 and share == 1 and (e["channels"], e["decim"], e["ntaps"]) == (nch, M, ntaps) \
+                if share == 1 and (e["channels"], e["decim"], e["ntaps"]) == (nch, M, ntaps) \
                         and abs(e["blocks_per_launch"] - nblk / lps) < 1e-9 and e["kernel"] == kname:
                     traffic, traffic_src = e["traffic_bytes"], e.get("source", "profiles/pmc_traffic.json")
     except Exception:
@@ -868,11 +871,15 @@ def run_hostfed(J, args, steps, warmup):
         a, _ = S.channel_audio(np.random.default_rng(0xACA25 + 5000 + c), nout, gap=(500, 1500), text_len=(5, 40))
         trk[c] = CARRIER * (1.0 + DEPTH * a)
     d_trk = torch.from_numpy(trk).to(dev)
-    assert L.acg_synth_iq_u8_dev(full.data_ptr(), nbuf * row, ncheck, nout, M, d_trk.data_ptr(), nout,
-                                 torch.arange(ncheck, dtype=torch.int32, device=dev).data_ptr(),
-                                 torch.from_numpy(offs[:ncheck].astype(np.float32)).to(dev).data_ptr(),
-                                 torch.from_numpy(phases[:ncheck].astype(np.float32)).to(dev).data_ptr(), SCALE, sigma, 0xACA25, None) == 0
+    # (named tensors: a temporary's memory goes back to the caching allocator the moment data_ptr() has been taken, and the next
+    #  temporary gets the same address -- round 4's first version of this function handed the kernel three aliases of one buffer)
+    d_idx = torch.arange(ncheck, dtype=torch.int32, device=dev)
+    d_off = torch.from_numpy(offs[:ncheck].astype(np.float32)).to(dev)
+    d_ph = torch.from_numpy(phases[:ncheck].astype(np.float32)).to(dev)
+    assert L.acg_synth_iq_u8_dev(full.data_ptr(), nbuf * row, ncheck, nout, M, d_trk.data_ptr(), nout, d_idx.data_ptr(),
+                                 d_off.data_ptr(), d_ph.data_ptr(), SCALE, sigma, 0xACA25, None) == 0
     torch.cuda.synchronize()
+    del d_trk, d_idx, d_off, d_ph
     # the host side: nbuf pinned buffers of one call each
     t_pin = time.perf_counter()
     hptr = [L.acg_host_alloc(nch * row) for _ in range(nbuf)]
@@ -1066,6 +1073,9 @@ def compact_line(full):
     if full.get("also"):
         line["also"] = {}
         for name, a in full["also"].items():
+            if "error" in a:
+                line["also"][name] = {"error": _short(a["error"], 120)}
+                continue
             ar = a.get("roofline", {})
             e = {"value": a.get("value"), "ms_per_step": a.get("ms_per_step"), "channels": a.get("config", {}).get("channels_per_gpu"),
                  "whole_job_frac": a.get("whole_job_frac_of_hbm"), "roofline_frac": ar.get("frac"), "traffic": ar.get("traffic"),
@@ -1132,6 +1142,10 @@ def main():
                     help="time the pre-repair blocks (acg_collect_frames without ACG_F_REPAIR) as rounds 1-3 did, instead of the "
                          "delivered acg_msg records")
     ap.add_argument("--hostfed-channels", type=int, default=None, help="channels of the hostfed case (default 10 000)")
+    ap.add_argument("--hostfed-child", action="store_true",
+                    help="(internal) run only the hostfed case and print its dict: the parent runs it in a child process with a "
+                         "timeout AFTER its own cases, so that whatever pinning tens of GB of host memory does on a box cannot take "
+                         "the result line with it")
     ap.add_argument("--detail-file", default=None, help="where the full per-case detail goes (default: bench_detail.json next to bench.py, "
                                                         "and gpurun_out/ when that exists)")
     ap.add_argument("--decoders", type=int, default=1, help="measurement aid: time this many decoders (separate allocations) in the same process")
@@ -1227,16 +1241,16 @@ def main():
         return 2 if f == "u8" else 4
     need = max(c["channels"] // (max(1, args.share) if i == 0 else 1) * c["blocks"] * 1024 * c["decim"] * case_bps(i, c)
                for i, (_, c) in enumerate(cases))
-    if with_hostfed:          # two calls' worth on the device (the _dev reference of its gate) + one call of scratch
-        need = max(need, (args.hostfed_channels or HOSTFED["channels"]) * HOSTFED["call_blocks"] * 1024 * HOSTFED["decim"] * 2 * 3)
+    hostfed_need = (args.hostfed_channels or HOSTFED["channels"]) * HOSTFED["call_blocks"] * 1024 * HOSTFED["decim"] * 2 * 3
+    if args.hostfed_child:    # two calls' worth on the device (the _dev reference of its gate) + one call of scratch
+        J.iq_all = torch.empty(hostfed_need, dtype=torch.uint8, device=dev)
+        print("HOSTFED_RESULT " + json.dumps(run_hostfed(J, args, args.steps, args.warmup)), flush=True)
+        return
     J.iq_all = torch.empty(need, dtype=torch.uint8, device=dev)
 
     res = []
     for i, (name, c) in enumerate(cases):
         res.append(run_case(J, name, c, args, args.steps, args.warmup, headline=(i == 0)))
-    if with_hostfed:
-        cases.append(("hostfed", HOSTFED))
-        res.append(run_hostfed(J, args, args.steps, args.warmup))
 
     if rank == 0:
         head = res[0]
@@ -1249,6 +1263,22 @@ def main():
             for r in res:
                 r["roofline"]["pure_reader_GBs_measured_this_run"] = round(gbs.value, 1)
                 r["roofline"]["frac_of_pure_reader"] = round(r["roofline"]["achieved"] / gbs.value, 4)
+        hostfed = None
+        if with_hostfed:
+            # the hostfed case in a child process with a timeout, after this process has let go of its input buffer
+            del J.iq_all
+            torch.cuda.empty_cache()
+            cmd = [sys.executable, os.path.abspath(__file__), "--hostfed-child", "--steps", str(args.steps), "--warmup", str(args.warmup),
+                   "--sustain", str(args.sustain), "--check-channels", str(args.check_channels)]
+            if args.hostfed_channels:
+                cmd += ["--hostfed-channels", str(args.hostfed_channels)]
+            try:
+                r_ = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+                got_ = [l for l in r_.stdout.splitlines() if l.startswith("HOSTFED_RESULT ")]
+                hostfed = json.loads(got_[-1][len("HOSTFED_RESULT "):]) if (r_.returncode == 0 and got_) else \
+                    {"error": "child exited with %d: %s" % (r_.returncode, (r_.stderr or r_.stdout)[-300:])}
+            except subprocess.TimeoutExpired:
+                hostfed = {"error": "hostfed child did not finish within 240 s"}
         out = {
             "metric": "acars_channels_x_input_msps",
             "value": head["value"],
@@ -1276,6 +1306,8 @@ def main():
             for name, r in zip([n for n, _ in cases[1:]], res[1:]):
                 if "per_gpu" in r:
                     out["also"][name]["per_gpu"] = r["per_gpu"]
+        if hostfed is not None:
+            out.setdefault("also", {})["hostfed"] = hostfed
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = run_cpu_baseline(case["decim"])
             out["cpu_baseline"]["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
@@ -1291,13 +1323,22 @@ def main():
                     f.write(detail + "\n")
             except OSError:
                 pass
-        # 2. the result: ONE compact line, last on stdout
-        line = json.dumps(compact_line(out), separators=(",", ":"))
-        assert len(line) < 4096, len(line)
-        print(line, flush=True)
+        # 2. the result: ONE compact line, LAST on stdout -- printed below, after the process group has been torn down and C
+        # stdio has been flushed (RCCL writes its version banner through C stdio, which is block-buffered on a pipe and would
+        # otherwise land behind this line at exit)
+        final_line = json.dumps(compact_line(out), separators=(",", ":"))
+        assert len(final_line) < 4096, len(final_line)
     if J.coll is not None:
         dist.barrier(device_ids=[local]) if J.backend == "nccl" else dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        import ctypes
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(final_line, flush=True)
 
 
 if __name__ == "__main__":

@@ -96,7 +96,10 @@ def test_equal_contexts_run_at_equal_rates(N):
     """8192 channels of device-generated input over N contexts on the box's GPU(s), timed by the C host: all together, then each
     alone in turn.  The contexts are identical in size and work; what they reach alone is written to gpurun_out/ and must agree
     (rounds 2-3 saw 7-16 % between the contexts of one process at 4096 channels)."""
-    r = subprocess.run([BIN, "random", "rtl", "8192", "200", "8", "8", str(N), "--msgs", "--time", "12"], capture_output=True, text=True, timeout=900)
+    # (--time 150: every context is timed alone over 150 calls = 0.2-0.4 s after a turn for nothing.  The first version timed 12 calls
+    #  = 30 ms per context and saw 6-7 % between them, contexts 0 and N-1 slower -- the pattern rounds 2-3 chased as a "placement
+    #  lottery": it is what a 30 ms measurement right after another context's burst looks like, not a property of the context)
+    r = subprocess.run([BIN, "random", "rtl", "8192", "200", "8", "8", str(N), "--msgs", "--time", "150"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-1500:]
     alone = [float(l.split(":")[1].split()[0]) for l in r.stderr.splitlines() if l.startswith("context ") and " alone:" in l]
     together = [float(l.split(":")[1].split()[0]) for l in r.stderr.splitlines() if l.startswith("all ")]
