@@ -1,9 +1,11 @@
 // blk.hip -- the block thread's work (acars.c:93-215) batched on the device: parity check, CRC
 // check, recursive parity-error repair (fixprerr, acars.c:39-64), two-bits-in-a-byte repair
-// (fixdberr, acars.c:66-90), parity strip.  One thread per queued block: blocks are rare (a few per
-// second per channel) and each costs at most a few thousand table look-ups, so this is not a
-// bandwidth or latency problem -- it only removes the last per-message host loop when tens of
-// thousands of channels deliver blocks.  Results are written back in place into the block queue.
+// (fixdberr, acars.c:66-90), parity strip.  One thread per queued block, results written back in place
+// into the block queue.  The arithmetic is nothing; what matters is LATENCY: the pass runs beside the
+// streaming down-converter, where a byte-wise walk over a block's text in global memory is a chain of
+// ~2 us HBM round trips (round 4 measured 0.5 ms per pass at 1024 channels, 4 ms at 16 384: a fifth of
+// the GPU time).  So a thread first pulls its block's text into its own LDS row with sixteen
+// independent 16-byte loads, works there (tables in LDS too), and writes the row back as vectors.
 #include <hip/hip_runtime.h>
 #include "acg_internal.h"
 
@@ -25,24 +27,43 @@ __device__ __forceinline__ bool crc_acceptable(const unsigned short* synd, unsig
     return false;
 }
 
-__global__ void blk_repair_kernel(AcgFrameRec* frames, unsigned int cap, const unsigned int* upto,
-                                  unsigned int* done_upto, unsigned int* done_ctr, const unsigned short* synd,
-                                  const unsigned short* crctab_g)
+#define BLK_ROW 272   // LDS row of one block's text: 256 bytes + 16 (68 dwords: at most 8 lanes of a wave share a bank)
+#define NSYND (8 * 243)
+
+// pulls block f's text (256 bytes, 16-byte aligned in the ring) into this thread's LDS row: sixteen independent loads
+__device__ __forceinline__ void stage_text(const AcgFrameRec* f, unsigned char* row)
+{
+    const uint4* src = (const uint4*)f->txt;
+    uint4 v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = src[j];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) ((uint4*)row)[j] = v[j];
+}
+
+__global__ __launch_bounds__(64) void blk_repair_kernel(AcgFrameRec* frames, unsigned int cap, const unsigned int* upto,
+                                                        unsigned int* done_upto, unsigned int* done_ctr,
+                                                        const unsigned short* synd_g, const unsigned short* crctab_g)
 {
     // The pass covers blocks [*done_upto, *upto): `upto` is the queue length the call's last demodulator launch published
     // (a host-mapped word), NOT the live counter -- the pass runs on a stream of its own beside the demodulator of the NEXT
     // call, which is appending records behind that mark.  At most one lap of the ring: if more than `cap` blocks were queued
     // since the last pass (the host reports that as ACG_EOVERFLOW), the surviving newest `cap` are each processed once.
     __shared__ unsigned short crctab[256];
-    for (int i = threadIdx.x; i < 256; i += blockDim.x) crctab[i] = crctab_g[i];
+    __shared__ unsigned short synd[NSYND];
+    __shared__ __attribute__((aligned(16))) unsigned char rows[64 * BLK_ROW];
+    for (int i = threadIdx.x; i < 256; i += 64) crctab[i] = crctab_g[i];
+    for (int i = threadIdx.x; i < NSYND; i += 64) synd[i] = synd_g[i];
     __syncthreads();
+    unsigned char* txt = rows + threadIdx.x * BLK_ROW;                       // this thread's row; nobody else touches it
     const unsigned int hi = __hip_atomic_load(upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned int from = *done_upto;
     const unsigned int lo = (hi - from > cap) ? hi - cap : from;
-    for (unsigned int q = lo + blockIdx.x * blockDim.x + threadIdx.x; q - lo < hi - lo; q += gridDim.x * blockDim.x) {
+    for (unsigned int q = lo + blockIdx.x * 64 + threadIdx.x; q - lo < hi - lo; q += gridDim.x * 64) {
         AcgFrameRec* f = frames + (q % cap);
         const int len = f->len;
-        unsigned char* txt = f->txt;
+        const unsigned int c0 = f->crc[0], c1 = f->crc[1];
+        stage_text(f, txt);
         if (len < 13) { f->status = 2; continue; }                         // acars.c:124
         txt[12] = (unsigned char)((txt[12] & (ETX | STX)) | (ETX & STX));   // acars.c:132-133
         int pn = 0, pr[MAXPERR];
@@ -56,9 +77,8 @@ __global__ void blk_repair_kernel(AcgFrameRec* frames, unsigned int cap, const u
             crc = crc_upd(crctab, crc, c);
         }
         if (pn > MAXPERR) { f->status = 2; continue; }                      // acars.c:145
-        f->err = pn;                                                        // acars.c:156
-        crc = crc_upd(crctab, crc, f->crc[0]);
-        crc = crc_upd(crctab, crc, f->crc[1]);
+        crc = crc_upd(crctab, crc, c0);
+        crc = crc_upd(crctab, crc, c1);
         bool ok = true;
         if (pn) {
             // fixprerr: depth-first over bit positions of the pn flagged bytes, first byte outermost,
@@ -95,9 +115,16 @@ __global__ void blk_repair_kernel(AcgFrameRec* frames, unsigned int cap, const u
         if (!ok) { f->status = 2; continue; }
         int pn2 = 0;                                                         // acars.c:195-207
         for (int i = 0; i < len; ++i) {
-            if ((__popc((unsigned int)txt[i]) & 1) == 0) ++pn2;
-            txt[i] &= 0x7f;
+            const unsigned int c = txt[i];
+            if ((__popc(c) & 1) == 0) ++pn2;
+            txt[i] = (unsigned char)(c & 0x7f);
         }
+        {   // back into the ring: the text as vectors (whole 16-byte groups up to len: the bytes behind len are the block's own)
+            uint4* dst = (uint4*)f->txt;
+            const int nv = (len + 15) >> 4;
+            for (int j = 0; j < nv; ++j) dst[j] = ((const uint4*)txt)[j];
+        }
+        f->err = pn;                                                        // acars.c:156
         f->status = pn2 ? 2 : 1;
     }
     // the last workgroup out moves the mark (every workgroup has read it by then) and re-arms the counter
@@ -116,9 +143,10 @@ __global__ void blk_repair_kernel(AcgFrameRec* frames, unsigned int cap, const u
 // device: processed blocks [first, first + n) of the queue -> fixed binary records (AcgMsgRec == acg_msg, see
 // include/acarsdec_amd.h), one thread per block.  valid = 0 marks blocks the repair dropped (acars.c:124-207) and
 // blocks the repair has not seen.  The level (a log10) is filled in on the host, like for acg_frame.
-__global__ void msg_split_kernel(const AcgFrameRec* frames, unsigned int cap, unsigned int first, unsigned int n, AcgMsgRec* out)
+__global__ __launch_bounds__(64) void msg_split_kernel(const AcgFrameRec* frames, unsigned int cap, unsigned int first, unsigned int n, AcgMsgRec* out)
 {
-    const unsigned int q = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ __attribute__((aligned(16))) unsigned char rows[64 * BLK_ROW];
+    const unsigned int q = blockIdx.x * 64 + threadIdx.x;
     if (q >= n) return;
     const AcgFrameRec* f = frames + ((first + q) % cap);
     AcgMsgRec* m = out + q;
@@ -127,7 +155,9 @@ __global__ void msg_split_kernel(const AcgFrameRec* frames, unsigned int cap, un
         unsigned long long* z = (unsigned long long*)m;
         for (unsigned int i = 0; i < sizeof(AcgMsgRec) / 8; ++i) z[i] = 0ull;
     }
-    const unsigned char* t = f->txt;
+    // the text through this thread's LDS row (one burst of loads instead of a byte-wise walk over global memory, see above)
+    unsigned char* t = rows + threadIdx.x * BLK_ROW;
+    stage_text(f, t);
     const int len = f->len;
     m->chn = f->chn;
     m->err = f->err;
