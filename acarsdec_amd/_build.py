@@ -132,6 +132,47 @@ def build_demo_rtl(force=False):
     return DEMO_RTL
 
 
+DEMO_SOAPY = os.path.join(LIBDIR, "acarsdec_gpu_soapy")
+SOAPY_OLD_TAIL = "\t\tcurrent_index = (current_index + res) % rateMult;\n"
+
+
+def patched_soapy_source():
+    """The reference's soapy.c with the ONE hunk of INTEGRATION.md applied, as text (never written to the repo): the
+    per-channel loop of the reader thread (soapy.c:228-254: `int n, i; ... current_index = (current_index + res) % rateMult;`)
+    becomes a call of acarsdec_amd_soapy_samples() (compat_msk.c).  Everything else -- initSoapy, chooseFc, the oscillator
+    tables, the watchdog, open / close -- is the reference's own text."""
+    src = open(os.path.join(REF, "soapy.c")).read()
+    a = src.index("\t\tint n, i;\n\t\tint\tlocal_ind;")
+    b = src.index(SOAPY_OLD_TAIL, a) + len(SOAPY_OLD_TAIL)
+    assert "demodMSK(ch, SOAPYOUTBUFSZ)" in src[a:b] and src.count("demodMSK(") == 1
+    return (src[:a] + "\t\t{ extern void acarsdec_amd_soapy_samples(const int16_t *iq, int nsamples);\n"
+            "\t\t  acarsdec_amd_soapy_samples(soapyInBuf, res); }          /* acarsdec_amd: replaces soapy.c:228-254 */\n" + src[b:])
+
+
+def build_demo_soapy(force=False):
+    """Reference acarsdec.c + acars.c + output.c ... UNCHANGED and soapy.c with the one-hunk binding, compat_msk.c instead of
+    msk.c, and a file-playing SoapySDR stand-in (csrc/demo/demo_soapy_file.c; headers: oracle/stub/SoapySDR).  The patched
+    soapy.c goes to the compiler through stdin: no reference text is written anywhere in the repo."""
+    if not os.path.exists(os.path.join(REF, "soapy.c")):
+        return DEMO_SOAPY if os.path.exists(DEMO_SOAPY) else None
+    build_lib()
+    demo_dir = os.path.join(CSRC, "demo")
+    stub = os.path.join(os.path.dirname(HERE), "oracle", "stub")
+    ref_units = ["acarsdec.c", "acars.c", "output.c", "label.c", "cJSON.c", "netout.c", "fileout.c"]
+    mine = [os.path.join(CSRC, "compat_msk.c"), os.path.join(demo_dir, "demo_soapy_file.c")]
+    srcs = [os.path.join(REF, u) for u in ref_units] + mine
+    if force or _newer(srcs + [LIB, os.path.join(REF, "soapy.c"), os.path.abspath(__file__)], DEMO_SOAPY):
+        obj = os.path.join(OBJDIR, "soapy_bound.o")
+        r = subprocess.run(["gcc", "-O2", "-w", "-DWITH_SOAPY", "-I" + REF, "-I" + INC, "-I" + stub, "-x", "c", "-c", "-", "-o", obj],
+                           input=patched_soapy_source(), capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("soapy.c (bound) failed to compile:\n" + r.stderr)
+        _run(["gcc", "-O2", "-w", "-DWITH_SOAPY", "-I" + REF, "-I" + INC, "-I" + stub] + srcs + [obj] +
+             ["-o", DEMO_SOAPY, "-L" + LIBDIR, "-lacarsdec_amd", "-Wl,-rpath,$ORIGIN", "-lm", "-lpthread"])
+        os.remove(obj)
+    return DEMO_SOAPY
+
+
 MULTIDEV = os.path.join(LIBDIR, "host_multidev")
 
 
@@ -154,6 +195,7 @@ def build_all(force=False):
     build_lib(force, poly=True)
     demo = build_demo(force)
     build_demo_rtl(force)
+    build_demo_soapy(force)
     build_multidev(force)
     return lib, demo
 

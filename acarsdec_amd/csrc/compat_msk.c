@@ -11,6 +11,8 @@
  *     void acarsdec_amd_in_callback(unsigned char *buf, uint32_t nread, void *ctx);
  *                                             replaces the static in_callback, rtl.c:314-361
  *                                             (pass it to rtlsdr_read_async at rtl.c:364)
+ *     void acarsdec_amd_soapy_samples(const int16_t *iq, int nsamples);       (-DWITH_SOAPY)
+ *                                             replaces the per-channel loop of soapy.c:228-254
  *
  * Division of labour: the GPU runs the down-converter and the MSK loop (with a device mirror of
  * the framing FSM, needed because decodeAcars() writes MskDf/MskS back into the loop,
@@ -192,3 +194,67 @@ void acarsdec_amd_in_callback(unsigned char *rtlinbuff, uint32_t nread, void *ct
 	discard_device_blocks(g_rtl);
 }
 #endif
+
+#ifdef WITH_SOAPY
+/*
+ * The per-channel loop of soapy.c:228-254 for all channels: `nsamples` CS16 samples of a read of any size.  The reference
+ * carries the partial window across reads in ch->D / current_index; here the incomplete window's samples wait on the device
+ * (acg_feed_samples_host), the sums are the same sequential windows.  Every complete window is demodulated at once (the
+ * reference waits until SOAPYOUTBUFSZ = 1024 of them have gathered, soapy.c:245-248: the same per-channel bit sequence,
+ * decodeAcars() called a little earlier), the bits are replayed into the caller's channel_t.  The binding a maintainer adds is
+ * one hunk in soapy.c's reader:
+ *     -		for (n = 0; n < nbch; n++) { ... }            soapy.c:231-253
+ *     -		current_index = (current_index + res) % rateMult;
+ *     +		acarsdec_amd_soapy_samples(soapyInBuf, res);
+ */
+static acg_ctx *g_soapy;
+static size_t g_soapy_carry;          /* samples of the incomplete window the device holds */
+
+void acarsdec_amd_soapy_samples(const int16_t *iq, int nsamples)
+{
+	unsigned int n;
+	int rc;
+	channel_t *chs[MAXNBCHANNELS];
+
+	if (nsamples <= 0)
+		return;
+	if (g_soapy == NULL) {
+		acg_config cfg;
+		float *taps = malloc(sizeof(float) * 2 * (size_t)rateMult * nbch);
+		int k;
+		memset(&cfg, 0, sizeof(cfg));
+		cfg.nch = (int)nbch; cfg.nstreams = 1; cfg.decim = rateMult; cfg.ntaps = rateMult;
+		cfg.max_blocks = 2;                                  /* a read is at most SOAPYOUTBUFSZ windows (soapy.c:59) + the carry */
+		cfg.flags = ACG_F_BITLOG; cfg.max_lag = 1;
+		if ((rc = acg_create(&g_soapy, &cfg)) != ACG_OK)
+			die("acg_create", NULL, rc);
+		for (n = 0; n < nbch; n++)                           /* oscillator[] from initSoapy, soapy.c:131-137 */
+			for (k = 0; k < rateMult; k++) {
+				taps[2 * ((size_t)n * rateMult + k)] = crealf(channel[n].oscillator[k]);
+				taps[2 * ((size_t)n * rateMult + k) + 1] = cimagf(channel[n].oscillator[k]);
+			}
+		if ((rc = acg_set_taps(g_soapy, 0, (int)nbch, taps)) != ACG_OK)
+			die("set_taps", g_soapy, rc);
+		free(taps);
+	}
+	if ((g_soapy_carry + (size_t)nsamples) / (size_t)rateMult == 0) {        /* no window completes: nothing to demodulate yet */
+		if ((rc = acg_feed_samples_host(g_soapy, ACG_FMT_CS16, iq, NULL, 0, (size_t)nsamples)) != ACG_OK)
+			die("feed_samples", g_soapy, rc);
+		g_soapy_carry += (size_t)nsamples;
+		return;
+	}
+	for (n = 0; n < nbch; n++) {
+		chs[n] = &channel[n];
+		upload(g_soapy, (int)n, &channel[n]);
+	}
+	if ((rc = acg_feed_samples_host(g_soapy, ACG_FMT_CS16, iq, NULL, 0, (size_t)nsamples)) != ACG_OK)
+		die("feed_samples", g_soapy, rc);
+	g_soapy_carry = (g_soapy_carry + (size_t)nsamples) % (size_t)rateMult;
+	if ((rc = acg_replay_bits(g_soapy, bit_sink, chs)) != ACG_OK)           /* channel order, as soapy.c:231 iterates */
+		die("replay", g_soapy, rc);
+	for (n = 0; n < nbch; n++)
+		download(g_soapy, (int)n, &channel[n]);
+	discard_device_blocks(g_soapy);
+}
+#endif
+

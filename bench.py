@@ -1208,7 +1208,7 @@ def main():
         if (v in (7, 8) or 70 <= v <= 73) and M == 200 and nout % 128 == 0:
             return "fir_u8_coltap_kernel"
         if (v in (5, 7, 8) or 50 <= v <= 55 or 70 <= v <= 73) and M in (160, 192, 200) and nout % 128 == 0:
-            return "fir_u8_direct_kernel<%d, 0, 0, true, %s>" % (M // 8, "false" if v == 55 else "true")     # (50..54: other staging shapes)
+            return "fir_u8_direct_kernel<%d, 0, 0, true, %s, false>" % (M // 8, "false" if v == 55 else "true")     # (as rocprofv3 prints it)
         return {0: "fir_u8_tile_kernel", 4: "fir_u8_dma_kernel"}.get(v, "fir_u8_persist_kernel")
     J.fir_kernel_name = fir_kernel_name
 

@@ -1441,6 +1441,39 @@ def test_compat_rtl_program_output_is_golden(golden, testwav, S, tmp_path):
     assert out.count("\n") == 7
 
 
+def test_compat_soapy_program_output_equals_the_cpu_program(testwav, S, O, tmp_path):
+    """The SoapySDR path end to end (VERDICT r03 "missing" 7): the reference's UNCHANGED acarsdec.c + acars.c + output.c ... and
+    soapy.c with the one hunk of INTEGRATION.md applied at build time (its per-channel loop, soapy.c:228-254, replaced by a call of
+    acarsdec_amd_soapy_samples() from compat_msk.c), fed by a file-playing SoapySDR stand-in that hands out reads of RAGGED size
+    (the window carry of soapy.c:232-254 is exercised at every read).  `acarsdec -o 1 -m 160 -d file f1 f2 f3 f4` must print what
+    the CPU twin (the same program with the reference's own soapy.c and msk.c, oracle/_ref/acarsdec_cpu_soapy) prints on the
+    same CS16 file: the same messages with the same levels and error counts, per channel in the same order."""
+    import re
+    gpu = os.path.join(ROOT, "acarsdec_amd", "lib", "acarsdec_gpu_soapy")
+    cpu = os.path.join(ROOT, "oracle", "_ref", "acarsdec_cpu_soapy")
+    if not (os.path.exists(gpu) and os.path.exists(cpu)):
+        pytest.skip("demo binaries not built (they need the reference tree at build time)")
+    freqs, M = ["131.525", "131.725", "131.825", "131.550"], 160
+    fr = [int(round(float(f) * 1e6)) for f in freqs]
+    fc = 131850000                                                   # soapy.c's chooseFc for these four (tests/test_oracle_vs_ref.py pins it against _ref)
+    env = S.pad_blocks(0.5 + 0.5 * testwav.T.astype(np.float64), 1024, 0.5)
+    env = np.concatenate([env, np.full((4, 1024 * 3), 0.5)], axis=1)    # (the CPU loop only demodulates whole 1024-output buffers, soapy.c:245)
+    iq = S.iq_s16_from_envelopes(env, M, [f - fc for f in fr], phases=[0.3, 1.1, 2.2, 0.7])
+    path = tmp_path / "t.cs16"
+    path.write_bytes(iq.tobytes())
+    outs = []
+    for exe in (cpu, gpu):
+        r = subprocess.run([exe, "-o", "1", "-m", str(M), "-d", "file"] + freqs, env=dict(os.environ, ACARSDEC_IQ_FILE=str(path)),
+                           capture_output=True, timeout=300)
+        assert r.returncode == 0, r.stderr.decode("latin-1")[-800:]
+        lines = re.sub(r"\d\d/\d\d/\d{4} \d\d:\d\d:\d\d\.\d{3} ", "", r.stdout.decode("latin-1")).splitlines()
+        per = {}
+        for l in lines:
+            per.setdefault(l.split()[0], []).append(l)
+        outs.append(per)
+    assert outs[0] == outs[1] and sum(len(v) for v in outs[0].values()) == 7 and set(outs[0]) == {"#1", "#2", "#3", "#4"}
+
+
 def test_replay_sink_matches_device_blocks(D, O, testwav):
     """acg_replay_bits hands every bit to a putbit()-shaped sink; feeding an oracle FSM from it
     yields the same blocks the device assembled."""

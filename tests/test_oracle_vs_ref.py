@@ -360,3 +360,35 @@ def test_reference_builds_against_each_other_and_the_oracle():
     assert fast is not None
     assert sum(len(set(x) ^ set(y)) for x, y in zip(o2, fast)) == 0
     assert O.ref_blocks_forked("_no_such_build", rows, M, taps) is None
+
+
+def test_reference_soapy_program_decodes_the_golden_recording(tmp_path):
+    """The CPU twin of the SoapySDR demo: the reference's UNCHANGED soapy.c + msk.c + acars.c + output.c behind a file-playing
+    SoapySDR stand-in with ragged reads (acarsdec_amd/csrc/demo/demo_soapy_file.c), fed the golden recording up-converted to CS16
+    at the offsets soapy.c's own chooseFc gives: it prints the seven messages of SURVEY App. B.  This is what the GPU test
+    test_compat_soapy_program_output_equals_the_cpu_program compares the bound program with; it also pins the centre frequency
+    that test uses."""
+    import re
+    import subprocess
+    from acarsdec_amd import synth as S
+    exe = os.path.join(os.path.dirname(O.ref_path()), "acarsdec_cpu_soapy")
+    if not (os.path.exists(exe) and O.ref_available("_soapy")):
+        pytest.skip("oracle/_ref not built")
+    freqs, M = ["131.525", "131.725", "131.825", "131.550"], 160
+    code = "import sys; sys.path.insert(0, %r); from oracle import oracle as O; print(O.Ref('_soapy').init_soapy(%r, %d))" % (
+        os.path.dirname(os.path.dirname(os.path.abspath(O.__file__))), freqs, M)
+    fc = int(subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120).stdout.strip().splitlines()[-1])
+    assert fc == 131850000
+    pcm = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "testwav_pcm16.npz"))["pcm"]
+    wav = pcm.astype(np.float32) / np.float32(32768.0)
+    fr = [int(round(float(f) * 1e6)) for f in freqs]
+    env = S.pad_blocks(0.5 + 0.5 * wav.T.astype(np.float64), 1024, 0.5)
+    env = np.concatenate([env, np.full((4, 1024 * 3), 0.5)], axis=1)
+    iq = S.iq_s16_from_envelopes(env, M, [f - fc for f in fr], phases=[0.3, 1.1, 2.2, 0.7])
+    path = tmp_path / "t.cs16"
+    path.write_bytes(iq.tobytes())
+    r = subprocess.run([exe, "-o", "1", "-m", str(M), "-d", "file"] + freqs, env=dict(os.environ, ACARSDEC_IQ_FILE=str(path)), capture_output=True, timeout=300)
+    out = re.sub(r"\d\d/\d\d/\d{4} \d\d:\d\d:\d\d\.\d{3} ", "", r.stdout.decode("latin-1"))
+    assert r.returncode == 0 and out.count("\n") == 7, out + r.stderr.decode("latin-1")[-500:]
+    for tail in ("PH-BXR KL1681 E 5V S53A", "LN-DYY DY083J 2 Q0 S46A", "F-GTAE AF7728 G H1 D65C", "G-DBCK BA031T E Q0 S63A"):
+        assert tail in out, tail
