@@ -1,11 +1,10 @@
 // blk.hip -- the block thread's work (acars.c:93-215) batched on the device: parity check, CRC
 // check, recursive parity-error repair (fixprerr, acars.c:39-64), two-bits-in-a-byte repair
-// (fixdberr, acars.c:66-90), parity strip.  One thread per queued block, results written back in place
-// into the block queue.  The arithmetic is nothing; what matters is LATENCY: the pass runs beside the
-// streaming down-converter, where a byte-wise walk over a block's text in global memory is a chain of
-// ~2 us HBM round trips (round 4 measured 0.5 ms per pass at 1024 channels, 4 ms at 16 384: a fifth of
-// the GPU time).  So a thread first pulls its block's text into its own LDS row with sixteen
-// independent 16-byte loads, works there (tables in LDS too), and writes the row back as vectors.
+// (fixdberr, acars.c:66-90), parity strip -- results written back in place into the block queue -- and
+// outputmsg()'s field split (output.c:486-560).  The arithmetic is nothing; what matters is LATENCY: both
+// run beside a down-converter that saturates HBM, where anything that walks a block's text byte by byte
+// is a chain of microsecond round trips.  The repair gives every block a wave (the CRC is linear: see
+// below), the split stages the text through LDS and builds its record there.
 #include <hip/hip_runtime.h>
 #include <cstddef>
 #include "acg_internal.h"
@@ -13,11 +12,6 @@
 #define MAXPERR 3
 #define ETX 0x83
 #define STX 0x02
-
-__device__ __forceinline__ unsigned short crc_upd(const unsigned short* tab, unsigned short crc, unsigned int c)
-{
-    return (unsigned short)((crc >> 8) ^ tab[(crc ^ c) & 0xff]);          // syndrom.h:49
-}
 
 __device__ __forceinline__ bool crc_acceptable(const unsigned short* synd, unsigned short crc)
 {
@@ -28,13 +22,22 @@ __device__ __forceinline__ bool crc_acceptable(const unsigned short* synd, unsig
     return false;
 }
 
-// Workgroups of 32 threads with one LDS row of 336 bytes each (a block's 256 text bytes; the split builds its 320-byte record
-// in the same row; 84 dwords: at most 8 lanes share a bank): 10.5 KiB per workgroup, small enough to sit in what the
-// down-converter's persistent workgroups leave free on a CU (16 KiB) -- with 64 rows + the syndrome table in LDS (22 KiB) the
-// pass only fitted beside the demodulator's waves, was starved by them (0.25-0.9 ms per pass) and took issue slots from the
-// one chain that sets the step at <= 2048 channels.  The syndrome table (only touched when a block needs repair) stays global.
-#define BLK_T 32
-#define BLK_ROW 336
+// ---- block repair: one WAVE per block -----------------------------------------------------------------------------------
+// Rounds 3-4 gave every block one thread that walked its text byte by byte (parity, table-driven CRC).  Beside a down-converter
+// that saturates HBM and LDS that is a chain of a few hundred dependent memory round trips per block: the pass measured 0.25 -
+// 4.4 ms per call (up to a third of the GPU time), sat between the host and its next call, and cost the whole job ~12 % at
+// >= 4096 channels.  The CRC is linear over GF(2) (CRC-CCITT, initial value 0, no final xor), and the reference's own syndrome
+// table IS its basis: synd[bit + 8 k] is the CRC of a message whose only set bit is `bit` of the byte that has k bytes behind it
+// (syndrom.h:52-295; fixprerr / fixdberr index it as 8 (len - i + 1) + bit, acars.c:45-88).  So
+//     crc(text, crc0, crc1) = XOR over every set bit of synd[bit + 8 (bytes behind it)]
+// -- identical to acars.c:159-165's table walk (tests/test_host_logic.py checks the identity against the oracle's update_crc),
+// and embarrassingly parallel: lane L takes bytes L, L + 64, L + 128, L + 192 (one coalesced 256-byte read per block), xors the
+// syndromes of their set bits out of an LDS copy of the table, and six butterfly steps fold the wave.  Parity errors are ballots.
+// The rare repairs (fixprerr, fixdberr) run replicated on every lane from wave-uniform values, in the reference's search order.
+#define BLK_T 32        // threads per workgroup of the field split below
+#define BLK_ROW 336     // its LDS row: a block's 256 text bytes, then the 320-byte record built in place (84 dwords: <= 8 lanes per bank)
+#define BLK_WAVES 4
+#define NSYND (8 * 243)
 
 // pulls block f's text (256 bytes, 16-byte aligned in the ring) into this thread's LDS row: sixteen independent loads
 __device__ __forceinline__ void stage_text(const AcgFrameRec* f, unsigned char* row)
@@ -47,42 +50,80 @@ __device__ __forceinline__ void stage_text(const AcgFrameRec* f, unsigned char* 
     for (int j = 0; j < 16; ++j) ((uint4*)row)[j] = v[j];
 }
 
-__global__ __launch_bounds__(BLK_T) void blk_repair_kernel(AcgFrameRec* frames, unsigned int cap, const unsigned int* upto,
-                                                           unsigned int* done_upto, unsigned int* done_ctr,
-                                                           const unsigned short* synd, const unsigned short* crctab_g)
+__device__ __forceinline__ unsigned int synd_of_bits(const unsigned short* synd, unsigned int byte, int k8)
+{
+    unsigned int x = 0;
+    while (byte) {
+        const int b = __ffs((int)byte) - 1;
+        x ^= synd[b + k8];
+        byte &= byte - 1;
+    }
+    return x;
+}
+
+__global__ __launch_bounds__(64 * BLK_WAVES) void blk_repair_kernel(AcgFrameRec* frames, unsigned int cap, const unsigned int* upto,
+                                                                    unsigned int* done_upto, unsigned int* done_ctr,
+                                                                    const unsigned short* synd_g, const unsigned short* crctab_g)
 {
     // The pass covers blocks [*done_upto, *upto): `upto` is the queue length the call's last demodulator launch published
     // (a host-mapped word), NOT the live counter -- the pass runs on a stream of its own beside the demodulator of the NEXT
     // call, which is appending records behind that mark.  At most one lap of the ring: if more than `cap` blocks were queued
     // since the last pass (the host reports that as ACG_EOVERFLOW), the surviving newest `cap` are each processed once.
-    __shared__ unsigned short crctab[256];
-    __shared__ __attribute__((aligned(16))) unsigned char rows[BLK_T * BLK_ROW];
-    for (int i = threadIdx.x; i < 256; i += BLK_T) crctab[i] = crctab_g[i];
+    (void)crctab_g;
+    __shared__ unsigned short synd[NSYND];
+    for (int i = threadIdx.x; i < NSYND; i += 64 * BLK_WAVES) synd[i] = synd_g[i];
     __syncthreads();
-    unsigned char* txt = rows + threadIdx.x * BLK_ROW;                       // this thread's row; nobody else touches it
     const unsigned int hi = __hip_atomic_load(upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned int from = *done_upto;
     const unsigned int lo = (hi - from > cap) ? hi - cap : from;
-    for (unsigned int q = lo + blockIdx.x * BLK_T + threadIdx.x; q - lo < hi - lo; q += gridDim.x * BLK_T) {
+    const int lane = threadIdx.x & 63;
+    const unsigned int wave = blockIdx.x * BLK_WAVES + (threadIdx.x >> 6), nwaves = gridDim.x * BLK_WAVES;
+    for (unsigned int q = lo + wave; q - lo < hi - lo; q += nwaves) {      // (q is wave-uniform: no divergence around the ballots)
         AcgFrameRec* f = frames + (q % cap);
         const int len = f->len;
-        const unsigned int c0 = f->crc[0], c1 = f->crc[1];
-        stage_text(f, txt);
-        if (len < 13) { f->status = 2; continue; }                         // acars.c:124
-        txt[12] = (unsigned char)((txt[12] & (ETX | STX)) | (ETX & STX));   // acars.c:132-133
-        int pn = 0, pr[MAXPERR];
-        unsigned short crc = 0;
-        for (int i = 0; i < len; ++i) {                                     // acars.c:136-144, 159-163
-            const unsigned int c = txt[i];
-            if ((__popc(c) & 1) == 0) {
-                if (pn < MAXPERR) pr[pn] = i;
-                ++pn;
-            }
-            crc = crc_upd(crctab, crc, c);
+        if (len < 13) {                                                    // acars.c:124
+            if (lane == 0) f->status = 2;
+            continue;
         }
-        if (pn > MAXPERR) { f->status = 2; continue; }                      // acars.c:145
-        crc = crc_upd(crctab, crc, c0);
-        crc = crc_upd(crctab, crc, c1);
+        unsigned char* txt = f->txt;
+        unsigned int c[4];
+        bool have[4];
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+            const int i = lane + 64 * s_;
+            have[s_] = i < len;                                            // (len <= 250)
+            c[s_] = have[s_] ? txt[i] : 0u;
+        }
+        if (lane == 12) c[0] = (c[0] & (ETX | STX)) | (ETX & STX);         // acars.c:132-133
+        // parity errors (acars.c:136-144) and the CRC over text + the two CRC bytes (acars.c:159-165)
+        unsigned long long bad[4];
+        unsigned int x = 0;
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+            bad[s_] = __ballot(have[s_] && (__popc(c[s_]) & 1) == 0);
+            if (have[s_]) x ^= synd_of_bits(synd, c[s_], 8 * (len - (lane + 64 * s_) + 1));
+        }
+        if (lane < 2) x ^= synd_of_bits(synd, f->crc[lane], 8 * (1 - lane));
+#pragma unroll
+        for (int off = 32; off; off >>= 1) x ^= (unsigned int)__shfl_xor((int)x, off);
+        const unsigned short crc = (unsigned short)x;
+        const int pn = __popcll(bad[0]) + __popcll(bad[1]) + __popcll(bad[2]) + __popcll(bad[3]);
+        if (pn > MAXPERR) {                                                // acars.c:145
+            if (lane == 0) f->status = 2;
+            continue;
+        }
+        int pr[MAXPERR] = {0, 0, 0};                                       // positions of the flagged bytes, ascending
+        {
+            int k = 0;
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) {
+                unsigned long long m = bad[s_];
+                while (m && k < MAXPERR) {
+                    pr[k++] = 64 * s_ + __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                }
+            }
+        }
         bool ok = true;
         if (pn) {
             // fixprerr: depth-first over bit positions of the pn flagged bytes, first byte outermost,
@@ -96,7 +137,14 @@ __global__ __launch_bounds__(BLK_T) void blk_repair_kernel(AcgFrameRec* frames, 
                     c2 ^= synd[bit + 8 * (len - pr[d] + 1)];
                 }
                 if (crc_acceptable(synd, c2)) {
-                    for (int d = 0; d < pn; ++d) txt[pr[d]] ^= (unsigned char)(1 << ((comb >> (3 * (pn - 1 - d))) & 7));
+                    for (int d = 0; d < pn; ++d)
+                        if (lane == (pr[d] & 63)) {
+                            const unsigned int flip = 1u << ((comb >> (3 * (pn - 1 - d))) & 7);
+                            if ((pr[d] >> 6) == 0) c[0] ^= flip;
+                            else if ((pr[d] >> 6) == 1) c[1] ^= flip;
+                            else if ((pr[d] >> 6) == 2) c[2] ^= flip;
+                            else c[3] ^= flip;
+                        }
                     ok = true;
                 }
             }
@@ -110,26 +158,32 @@ __global__ __launch_bounds__(BLK_T) void blk_repair_kernel(AcgFrameRec* frames, 
                     for (int j = 0; j < 8 && !ok; ++j) {
                         if (i == j) continue;
                         if ((crc ^ synd[i + bo] ^ synd[j + bo]) == 0) {
-                            txt[k] ^= (unsigned char)((1 << i) | (1 << j));
+                            if (lane == (k & 63)) {
+                                const unsigned int flip = (1u << i) | (1u << j);
+                                if ((k >> 6) == 0) c[0] ^= flip;
+                                else if ((k >> 6) == 1) c[1] ^= flip;
+                                else if ((k >> 6) == 2) c[2] ^= flip;
+                                else c[3] ^= flip;
+                            }
                             ok = true;
                         }
                     }
             }
         }
-        if (!ok) { f->status = 2; continue; }
-        int pn2 = 0;                                                         // acars.c:195-207
-        for (int i = 0; i < len; ++i) {
-            const unsigned int c = txt[i];
-            if ((__popc(c) & 1) == 0) ++pn2;
-            txt[i] = (unsigned char)(c & 0x7f);
+        if (!ok) {
+            if (lane == 0) f->status = 2;
+            continue;
         }
-        {   // back into the ring: the text as vectors (whole 16-byte groups up to len: the bytes behind len are the block's own)
-            uint4* dst = (uint4*)f->txt;
-            const int nv = (len + 15) >> 4;
-            for (int j = 0; j < nv; ++j) dst[j] = ((const uint4*)txt)[j];
+        int pn2 = 0;                                                        // acars.c:195-207: parity once more, then strip it
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+            pn2 += __popcll(__ballot(have[s_] && (__popc(c[s_]) & 1) == 0));
+            if (have[s_]) txt[lane + 64 * s_] = (unsigned char)(c[s_] & 0x7f);
         }
-        f->err = pn;                                                        // acars.c:156
-        f->status = pn2 ? 2 : 1;
+        if (lane == 0) {
+            f->err = pn;                                                    // acars.c:156
+            f->status = pn2 ? 2 : 1;
+        }
     }
     // the last workgroup out moves the mark (every workgroup has read it by then) and re-arms the counter
     __syncthreads();
@@ -235,6 +289,6 @@ extern "C" int acg_launch_blk_repair(AcgFrameRec* frames, unsigned int cap, cons
                                      unsigned int* done_upto, unsigned int* done_ctr, const unsigned short* synd,
                                      const unsigned short* crctab, void* stream)
 {
-    hipLaunchKernelGGL(blk_repair_kernel, dim3(128), dim3(BLK_T), 0, (hipStream_t)stream, frames, cap, upto, done_upto, done_ctr, synd, crctab);
+    hipLaunchKernelGGL(blk_repair_kernel, dim3(256), dim3(64 * BLK_WAVES), 0, (hipStream_t)stream, frames, cap, upto, done_upto, done_ctr, synd, crctab);
     return (int)hipGetLastError();
 }

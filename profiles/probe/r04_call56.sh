@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 4, GPU call 5: after the small-footprint block kernels -- the tests that touch them, the default bench line, stats per case
-R=$(pwd); O=$R/gpurun_out/r04_call5; mkdir -p $O; export TMPDIR=/tmp
+# round 4, GPU call 6: after the small-footprint block kernels -- the tests that touch them, the default bench line, stats per case
+R=$(pwd); O=$R/gpurun_out/r04_call6; mkdir -p $O; export TMPDIR=/tmp
 exec </dev/null
 ( time timeout 400 python -m pytest tests -m gpu -q --maxfail=10 -p no:cacheprovider -k "message or repair or msgs or bench_line_contract or multidev or soapy or host_fed or compat" ) > $O/pytest_subset.txt 2>&1
 tail -n 8 $O/pytest_subset.txt | cut -c 1-260

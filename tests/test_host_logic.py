@@ -366,3 +366,28 @@ def test_bench_compact_line_stays_under_4k_at_the_full_case_shape():
     assert c["parity"]["exact_given_gpu_dm"] is True and c["parity"]["msgs_exact"] is True and c["parity"]["ref_builds_differing"] == 1
     assert set(c["also"]) == {"wide", "stress", "cs16", "f32", "shard2048", "hostfed"}
     assert all(a["parity_ok"] is True and 0 < a["roofline_frac"] < 1 for a in c["also"].values())
+
+
+def test_crc_is_the_xor_of_the_syndromes_of_the_set_bits():
+    """blk.hip's repair kernel gives every block a wave and computes acars.c:159-165's CRC as the XOR, over every set bit of the
+    text and the two CRC bytes, of synd[bit + 8 * (bytes behind that byte)] -- the reference's own syndrome table (syndrom.h:52-295,
+    indexed as fixprerr / fixdberr index it, acars.c:45-88) is the basis of the linear map.  The identity against the oracle's
+    table-driven update_crc (pinned to the reference) on random blocks of every length, incl. the extra 243rd row the longest
+    block reaches."""
+    synd = O.syndrome_table(8 * 243)
+    rng = np.random.default_rng(20260926)
+    for n in list(range(13, 242)) + [241] * 20:
+        txt = rng.integers(0, 256, size=n, dtype=np.uint8)
+        c0, c1 = int(rng.integers(0, 256)), int(rng.integers(0, 256))
+        want = O.crc_ccitt(txt.tobytes() + bytes([c0, c1]))
+        x = 0
+        for i, b in enumerate(txt.tolist()):
+            for bit in range(8):
+                if (b >> bit) & 1:
+                    x ^= int(synd[bit + 8 * (n - i + 1)])
+        for bit in range(8):
+            if (c0 >> bit) & 1:
+                x ^= int(synd[bit + 8])
+            if (c1 >> bit) & 1:
+                x ^= int(synd[bit])
+        assert x == want, n
