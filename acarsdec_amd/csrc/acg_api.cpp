@@ -443,16 +443,10 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
                 else HIPCHK(c, hipStreamCreateWithPriority(&c->msk_stream, hipStreamNonBlocking, hi));
             }
         }
-        if (c->fir_stream) {
-            // (CU partition: the field split that acg_collect_msgs launches here stays off the demodulator's CUs as well)
-            int total = 256;
-            (void)hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, cfg->device);
-            uint32_t fm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int cu = total - c->fir_ncu; cu < total && cu < 256; ++cu) fm[cu >> 5] |= 1u << (cu & 31);
-            HIPCHK(c, hipExtStreamCreateWithCUMask(&c->copy_stream, 8, fm));
-        } else {
-            HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-        }
+        // (round 4 tried a CU mask on this stream and on the repair stream -- the down-converter's side of the partition, to keep
+        //  both off the demodulator's CUs: the runtime then performs the result copies as blit kernels on those saturated CUs,
+        //  the host gets its results later and the headline lost 6-10 %: profiles/LEDGER.md)
+        HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
         HIPCHK(c, hipEventCreateWithFlags(&c->in_ev, hipEventDisableTiming));
         c->fir_done.resize((size_t)cfg->max_blocks);
         c->msk_done.resize(2 * (size_t)cfg->max_blocks);
@@ -497,17 +491,7 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
             HIPCHK(c, hipMemcpy(c->d_crctab, tabs.data(), tabs.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
             HIPCHK(c, hipMalloc(&c->d_rep_upto, 2 * sizeof(unsigned int)));       // {blocks through the pass, workgroups finished}
             HIPCHK(c, hipMemset(c->d_rep_upto, 0, 2 * sizeof(unsigned int)));
-            // (with the CU partition the pass runs on the DOWN-CONVERTER's side of it: the demodulator's CUs carry the one chain
-            //  that sets the step at <= 2048 channels; the streaming stage does not miss the issue slots)
-            if (c->fir_stream) {
-                int total = 256;
-                (void)hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, cfg->device);
-                uint32_t fm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (int cu = total - c->fir_ncu; cu < total && cu < 256; ++cu) fm[cu >> 5] |= 1u << (cu & 31);
-                HIPCHK(c, hipExtStreamCreateWithCUMask(&c->post_stream, 8, fm));
-            } else {
-                HIPCHK(c, hipStreamCreateWithFlags(&c->post_stream, hipStreamNonBlocking));
-            }
+            HIPCHK(c, hipStreamCreateWithFlags(&c->post_stream, hipStreamNonBlocking));
             for (auto& e : c->msk_end) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
         float h[136] = {0};

@@ -374,9 +374,9 @@ def run_case(J, name, case, args, steps, warmup, headline):
         cb, ncall = nblk, 1                                # (plane layout: one call)
     repair = not args.raw_blocks
     def make_decoder():
-        # max_lag = 1: this host collects one call behind, so the block queue holds two calls' worth
+        # max_lag = --collect-lag: this host collects that many calls behind, and the block queue holds that many + 1 calls' worth
         d_ = D.Decoder(nch, decim=M, ntaps=ntaps, nstreams=nstreams, max_blocks=cb, device=J.local, bitlog=bool(args.bitlog), timing=True,
-                       repair=repair, max_lag=1)
+                       repair=repair, max_lag=max(1, args.collect_lag))
         d_.set_taps(taps)
         if share > 1:
             d_.set_channel_streams(np.arange(nch) // share)
@@ -392,9 +392,11 @@ def run_case(J, name, case, args, steps, warmup, headline):
     maxfr = max(8192, int(nch * (cb / 3.0 + 2)))
     cb_bytes = cb * 1024 * M * bps
 
-    def step(lag=1, sink=None, dec=None, dm_sink=None, frames=False):
+    def step(lag=None, sink=None, dec=None, dm_sink=None, frames=False):
         """one pass of the hot path over the batch; the results (acg_msg records; blocks with frames=True or --raw-blocks) are
-        delivered to the host one call behind (streaming double buffering: the newest call keeps the GPU busy while the host collects)"""
+        delivered to the host --collect-lag calls behind (default 2: the host then never waits for the block repair of the call
+        before the newest one before it may hand over the next -- with a lag of 1 that wait sat between every two calls)"""
+        lag = args.collect_lag if lag is None else lag
         n = 0
         dec = dec or dec0
         for k in range(ncall):
@@ -778,11 +780,11 @@ def run_case(J, name, case, args, steps, warmup, headline):
         "burst": burst,
         "data": "synthetic: " + data_desc,
         "config": {"workload": "%s: %d channels/GPU x %.1f Msps %s, one stream per channel, rtlMult=%d, ntaps=%d; step = %d pass(es) over a resident batch of "
-                               "%d callbacks/channel in calls of %d; FIR decimate + MSK demod + framing%s, delivered to the host one call behind"
+                               "%d callbacks/channel in calls of %d; FIR decimate + MSK demod + framing%s, delivered to the host %d call(s) behind"
                                % (case["tag"], nch, 12500 * M / 1e6, {"u8": "u8 IQ", "cs16": "CS16 IQ", "split16": "split int16 I/Q", "f32": "real f32"}[fmt_name],
-                                  M, ntaps, reps, nblk, cb, " + block repair + message split" if repair else ""),
+                                  M, ntaps, reps, nblk, cb, " + block repair + message split" if repair else "", args.collect_lag),
                    "signal_seconds_per_pass": round(nblk * 0.08192, 3),
-                   "callbacks_per_call": cb,
+                   "callbacks_per_call": cb, "collect_lag": args.collect_lag,
                    "case": name, "input_format": fmt_name, "channels_per_gpu": nch, "decim": M, "ntaps": ntaps, "blocks_per_step": nblk * reps, "blocks_per_pass": nblk, "passes_per_step": reps,
                    "input_bytes_per_gpu": int(nstreams * row),
                    "realtime_channels_equiv": int(value / (12500 * M / 1e6)),
@@ -1059,7 +1061,7 @@ def compact_line(full):
                                       "vs_baseline", "dtype")}
     line["data"] = _short(full.get("data", "synthetic"), 160)
     line["config"] = {"workload": _short(cfg.get("workload", ""), 300), "case": cfg.get("case"), "channels_per_gpu": cfg.get("channels_per_gpu"),
-                      "decim": cfg.get("decim"), "ntaps": cfg.get("ntaps"), "callbacks_per_call": cfg.get("callbacks_per_call"),
+                      "decim": cfg.get("decim"), "ntaps": cfg.get("ntaps"), "callbacks_per_call": cfg.get("callbacks_per_call"), "collect_lag": cfg.get("collect_lag"),
                       "passes_per_step": cfg.get("passes_per_step"), "input_format": cfg.get("input_format"),
                       "delivered": _short(cfg.get("delivered", ""), 60), "contexts": _short(cfg.get("contexts", ""), 60)}
     if cfg.get("placement"):
@@ -1138,6 +1140,10 @@ def main():
                          "config.placement.  The context that is timed is the FIRST one (what a host gets from acg_create) unless "
                          "--placement-keep best")
     ap.add_argument("--placement-keep", choices=["first", "best"], default="first")
+    ap.add_argument("--collect-lag", type=int, default=2,
+                    help="how many calls behind the newest the host collects results (acg_collect_msgs(lag)); the context's block queue is "
+                         "sized for it (acg_config.max_lag).  2 (default): two calls in flight, the host never waits on the newest call's "
+                         "predecessor; 1: classic double buffering (rounds 1-3)")
     ap.add_argument("--raw-blocks", action="store_true",
                     help="time the pre-repair blocks (acg_collect_frames without ACG_F_REPAIR) as rounds 1-3 did, instead of the "
                          "delivered acg_msg records")
