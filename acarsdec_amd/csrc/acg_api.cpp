@@ -1082,6 +1082,9 @@ extern "C" int acg_collect_frames(acg_ctx* ctx, int lag, acg_frame* out, int max
     const int slot = (int)(call % acg_ctx::NCALL);
     HIPCHK(ctx, hipEventSynchronize(ctx->call_done[slot]));                   // only that call, not newer ones
     const unsigned int upto = ctx->h_call_count[slot];
+    // (a drain may already have handed out more than that call had queued: its mark then lies BEHIND the consumer -- nothing
+    //  is pending; the counters are monotonic and wrap, so the comparison is a signed difference)
+    if ((int)(upto - ctx->consumed) <= 0) return ACG_OK;
     return fetch_frames(ctx, upto, out, max_frames, nframes);
 }
 
@@ -1169,6 +1172,7 @@ extern "C" int acg_collect_msgs(acg_ctx* ctx, int lag, acg_msg* out, int max_msg
     const unsigned long long call = ctx->call_seq - 1 - (unsigned long long)lag;
     const int slot = (int)(call % acg_ctx::NCALL);
     HIPCHK(ctx, hipEventSynchronize(ctx->call_done[slot]));
+    if ((int)(ctx->h_call_count[slot] - ctx->consumed) <= 0) return ACG_OK;      // (behind the consumer after a drain: see acg_collect_frames)
     return fetch_msgs(ctx, ctx->h_call_count[slot], out, max_msgs, nmsgs);
 }
 

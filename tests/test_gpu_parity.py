@@ -638,6 +638,29 @@ def test_message_drain_keeps_what_does_not_fit_and_records_are_fully_defined(D, 
     dec2.close()
 
 
+def test_collect_behind_a_drain_finds_nothing_pending(D, msgsplit_golden):
+    """A host that drains everything and then goes on collecting `lag` calls behind (bench.py: a pass ends with a drain, the next
+    pass collects with lag 2) asks for calls whose blocks the drain has already handed out: their published queue length lies
+    behind the consumer.  That is "nothing pending", not a lapped queue (round 4's first lag-2 run read the negative difference as
+    4 294 9xx xxx lost blocks)."""
+    from acarsdec_amd import _capi as K
+    pcm, want = msgsplit_golden
+    x = pcm.astype(np.float32) / 32768.0
+    chunk = 8192
+    x = np.concatenate([x, np.zeros((-x.size) % chunk, dtype=np.float32)])
+    dec = D.Decoder(2, decim=8, ntaps=8, max_blocks=chunk // 1024, repair=True, bitlog=False, max_lag=2)
+    got = []
+    for rnd in range(2):
+        for s in range(0, x.size, chunk):
+            dec.demod_msk(np.tile(x[s:s + chunk], (2, 1)))
+            got += dec.collect_msgs(lag=2, max_msgs=64)
+        got += dec.drain_msgs(64)                    # ... and the next round's first collects look behind this drain
+        n, buf = dec.collect_frames_raw(lag=2, max_frames=16)
+        assert n == 0
+    assert 2 * len(want) <= len(got) <= 2 * 2 * len(want) + 4          # (round 2 starts from round 1's loop state: nearly always the same messages)
+    dec.close()
+
+
 def test_collect_lag_is_bounded_by_what_the_block_queue_was_sized_for(D):
     """acg_max_lag(): the block queue holds the worst case of max_lag + 1 calls (it held two calls' worth while
     the API allowed a lag of 6), 6 where that costs <= 512 MiB, fewer for very wide contexts; a larger lag is refused."""
