@@ -801,7 +801,7 @@ static int end_of_call(acg_ctx* ctx)
         HIPCHK(ctx, hipEventRecord(ctx->msk_end[slot], ctx->msk_stream));
         HIPCHK(ctx, hipStreamWaitEvent(ctx->post_stream, ctx->msk_end[slot], 0));
         const int e = acg_launch_blk_repair(ctx->d_frames, ctx->frame_cap, ctx->d_call_count + slot, ctx->d_rep_upto, ctx->d_rep_upto + 1,
-                                            ctx->d_crctab + 256, ctx->d_crctab, ctx->post_stream);
+                                            ctx->d_crctab + 256, ctx->d_crctab, ctx->cfg.nch, ctx->post_stream);
         if (e != 0) return fail(ctx, ACG_EHIP, "block repair launch failed");
         HIPCHK(ctx, hipEventRecord(ctx->call_done[slot], ctx->post_stream));
     } else {

@@ -148,7 +148,7 @@ size_t acg_fir_lds_bytes(const FirArgs* a);
 int acg_launch_msk(const MskArgs* a, int lanes_per_channel, void* stream);
 int acg_launch_msk2(const MskArgs* a, int pairs_per_group, void* stream);     // msk2.hip: the stream split over two waves (8 lanes per channel)
 int acg_launch_blk_repair(AcgFrameRec* frames, unsigned int cap, const unsigned int* upto, unsigned int* done_upto,
-                          unsigned int* done_ctr, const unsigned short* synd, const unsigned short* crctab, void* stream);
+                          unsigned int* done_ctr, const unsigned short* synd, const unsigned short* crctab, int nch, void* stream);
 int acg_launch_msg_split(const AcgFrameRec* frames, unsigned int cap, unsigned int first, unsigned int n, AcgMsgRec* out, void* stream);
 int acg_launch_sincos_selftest(const double* x, double* s, double* c, int n, const double* sctab, void* stream);
 int acg_launch_div2_selftest(const double* n0, const double* n1, const double* d, double* out, int n, void* stream);
