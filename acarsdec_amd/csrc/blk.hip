@@ -32,7 +32,7 @@ __device__ __forceinline__ bool crc_acceptable(const unsigned short* synd, unsig
 //     crc(text, crc0, crc1) = XOR over every set bit of synd[bit + 8 (bytes behind it)]
 // -- identical to acars.c:159-165's table walk (tests/test_host_logic.py checks the identity against the oracle's update_crc),
 // and embarrassingly parallel: lane L takes bytes L, L + 64, L + 128, L + 192 (one coalesced 256-byte read per block), xors the
-// syndromes of their set bits (the 3.9 KB table stays in L2), and six butterfly steps fold the wave.  Parity errors are ballots.
+// syndromes of their set bits out of an LDS copy of the table, and six butterfly steps fold the wave.  Parity errors are ballots.
 // The rare repairs (fixprerr, fixdberr) run replicated on every lane from wave-uniform values, in the reference's search order.
 #define BLK_T 32        // threads per workgroup of the field split below
 #define BLK_ROW 336     // its LDS row: a block's 256 text bytes, then the 320-byte record built in place (84 dwords: <= 8 lanes per bank)
@@ -69,10 +69,12 @@ __global__ __launch_bounds__(64 * BLK_WAVES) void blk_repair_kernel(AcgFrameRec*
     // (a host-mapped word), NOT the live counter -- the pass runs on a stream of its own beside the demodulator of the NEXT
     // call, which is appending records behind that mark.  At most one lap of the ring: if more than `cap` blocks were queued
     // since the last pass (the host reports that as ACG_EOVERFLOW), the surviving newest `cap` are each processed once.
-    // (the table is read where it lies: 3.9 KB that stay in L2; staging it through LDS made every workgroup of the pass pay a
-    //  start-up of eight loads per thread and a barrier, most of them for nothing)
+    // (the table in LDS: read where it lies -- 3.9 KB that stay in L2 -- every look-up is a ~1.5 us round trip beside the
+    //  streaming down-converter and a block took ~50 us per wave: the pass fell behind the calls at 2048 channels, call 9)
     (void)crctab_g;
-    const unsigned short* __restrict__ synd = synd_g;
+    __shared__ unsigned short synd[NSYND];
+    for (int i = threadIdx.x; i < NSYND; i += 64 * BLK_WAVES) synd[i] = synd_g[i];
+    __syncthreads();
     const unsigned int hi = __hip_atomic_load(upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned int from = *done_upto;
     const unsigned int lo = (hi - from > cap) ? hi - cap : from;
@@ -289,10 +291,11 @@ extern "C" int acg_launch_blk_repair(AcgFrameRec* frames, unsigned int cap, cons
                                      unsigned int* done_upto, unsigned int* done_ctr, const unsigned short* synd,
                                      const unsigned short* crctab, int nch, void* stream)
 {
-    // a wave per block, the waves looping over the call's blocks (about one per channel per call of 8 callbacks): 64 waves up
-    // to 4096 channels, 256 at 16 384 -- a small pass beside the two stages, not a thousand waves that mostly find nothing
-    int wgs = nch / 256;
-    wgs = wgs < 16 ? 16 : wgs > 64 ? 64 : wgs;
+    // a wave per block, the waves looping over the call's blocks (about one per channel per call of 8 callbacks): one wave per 8
+    // channels, 128 ... 1024 waves -- enough that the pass keeps up with the calls at every width (64 waves did not at 2048
+    // channels), small enough not to crowd the demodulator's CUs at 1024 (1024 waves, most of them finding nothing, did)
+    int wgs = nch / (8 * BLK_WAVES);
+    wgs = wgs < 32 ? 32 : wgs > 256 ? 256 : wgs;
     hipLaunchKernelGGL(blk_repair_kernel, dim3(wgs), dim3(64 * BLK_WAVES), 0, (hipStream_t)stream, frames, cap, upto, done_upto, done_ctr, synd, crctab);
     return (int)hipGetLastError();
 }
