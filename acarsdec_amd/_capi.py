@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("ACARSDEC_AMD_LIB") or os.path.join(HERE, "lib", "liba
 LAB_PATH = os.path.join(HERE, "lib", "libacarsdec_amd_lab.so")
 
 OK, EINVAL, ENOMEM, EHIP, ENODEV, EOVERFLOW, ESTATE, EAGAIN = 0, -1, -2, -3, -4, -5, -6, -7
-F_BITLOG, F_TIMING, F_REPAIR, F_EXACT_FIR = 1, 2, 4, 8
+F_BITLOG, F_TIMING, F_REPAIR, F_EXACT_FIR, F_PRECISE_MIXER = 1, 2, 4, 8, 16
 INTRATE, BLOCK, MAXDECIM, FLEN, TXTMAX = 12500, 1024, 320, 11, 250
 MAXDECIM_SAMPLES = 1024
 FMT_CS16, FMT_S16_SPLIT, FMT_F32_REAL = 1, 2, 3

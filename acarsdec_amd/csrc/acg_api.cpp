@@ -725,6 +725,7 @@ static int launch_msk(acg_ctx* c, const float* dm_dev, size_t pitch_floats, int 
     a.done_ctr = c->d_msk_done;
     a.dm_vec_ok = ((((uintptr_t)dm_dev) & 15) == 0 && (pitch_floats % 4) == 0) ? 1 : 0;
     a.stamp = c->d_stamp;
+    a.precise_mixer = (g.flags & ACG_F_PRECISE_MIXER) ? 1 : 0;
     const bool timing = c->timing_mode == 1;
     EvPair ev{};
     if (timing) {

@@ -133,6 +133,7 @@ struct MskArgs {
     int high_prio;              // raise wave priority (latency mode)
     int dm_vec_ok;              // dm rows are 16-byte aligned: the window refill may use float4 loads
     unsigned long long* stamp;  // measurement build (ACG_MSK_STAMP) only: [waves][10] phase cycle sums, else null
+    int precise_mixer;          // ACG_F_PRECISE_MIXER: the < 1 ulp polynomial sin/cos instead of table + rotation
 };
 
 #ifdef __cplusplus

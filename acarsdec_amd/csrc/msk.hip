@@ -50,7 +50,10 @@
 
 // VEC: the launch's dm rows are 16-byte aligned and len is a multiple of 32 (every in_callback launch): the refill reads
 // 16 bytes per load instead of four clamped words.
-template <int LPC, int WPG, bool VEC>
+// POLY (run-time flag ACG_F_PRECISE_MIXER, a verification mode like ACG_F_EXACT_FIR): the mixer's sin/cos as the < 1 ulp
+// Cody-Waite + fdlibm-kernel evaluation instead of the 128-entry table + rotation (<= 2.1 ulp).  What the loop keeps are the
+// float-rounded products, and those are the same for both (tests); the flag lets a maintainer see that on his own input.
+template <int LPC, int WPG, bool VEC, bool POLY = false>
 __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
 {
     constexpr int CPW = 64 / LPC;                  // channels per wave
@@ -337,9 +340,10 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
                 // divide and the first filter taps around it (0.8 % per bit)
                 double sn, cs;
 #ifdef ACG_MSK_SINCOS_POLY
-                sincos_2pi(myp[j], &sn, &cs);                              // (A/B builds: the < 1 ulp polynomial version)
+                sincos_2pi(myp[j], &sn, &cs);                              // (checking build: the < 1 ulp polynomial version everywhere)
 #else
-                sincos_tab(myp[j], lds.sc, &sn, &cs);
+                if constexpr (POLY) sincos_2pi(myp[j], &sn, &cs);          // ACG_F_PRECISE_MIXER
+                else sincos_tab(myp[j], lds.sc, &sn, &cs);
 #endif
                 const double in = (double)in_cur[j];
                 unsigned int k = idx + (unsigned int)u;
@@ -541,8 +545,10 @@ extern "C" int acg_launch_msk(const MskArgs* a, int lpc, void* stream)
     const unsigned int grid = (waves + wpg - 1) / wpg;
     const dim3 blk(64 * wpg);
     hipStream_t s = (hipStream_t)stream;
-    const bool vec = ((uintptr_t)a->dm % 16 == 0) && (a->dm_pitch % 4 == 0) && (a->len % 32 == 0) && !acg_tune_has("ACG_MSK_NOVEC");
-#define MSK_LAUNCH(L_, W_) do { if (vec) hipLaunchKernelGGL((msk_demod_kernel<L_, W_, true>), dim3(grid), blk, 0, s, *a); \
+    const bool vec = ((uintptr_t)a->dm % 16 == 0) && (a->dm_pitch % 4 == 0) && (a->len % 32 == 0) && !acg_tune_has("ACG_MSK_NOVEC") && !a->precise_mixer;
+    // (the verification mode is instantiated for the scalar-refill shape only: six more kernels, not twelve)
+#define MSK_LAUNCH(L_, W_) do { if (a->precise_mixer) hipLaunchKernelGGL((msk_demod_kernel<L_, W_, false, true>), dim3(grid), blk, 0, s, *a); \
+                                else if (vec) hipLaunchKernelGGL((msk_demod_kernel<L_, W_, true>), dim3(grid), blk, 0, s, *a); \
                                 else hipLaunchKernelGGL((msk_demod_kernel<L_, W_, false>), dim3(grid), blk, 0, s, *a); } while (0)
     switch (lpc * 16 + wpg) {
     case 1 * 16 + 1: MSK_LAUNCH(1, 1); break;

@@ -64,7 +64,7 @@ def parse_freq_mhz(s):
 
 class Decoder:
     def __init__(self, nch, decim=160, ntaps=None, nstreams=None, max_blocks=1, device=0,
-                 bitlog=True, timing=False, repair=False, exact_fir=False, max_lag=0, lab=False):
+                 bitlog=True, timing=False, repair=False, exact_fir=False, max_lag=0, lab=False, precise_mixer=False):
         self.L = K.load(lab)          # lab=True: the lab build of the library (measurement variants; tests and probes only)
         self.nch, self.decim = int(nch), int(decim)
         self.ntaps = int(ntaps if ntaps is not None else decim)
@@ -72,7 +72,7 @@ class Decoder:
         self.max_blocks = int(max_blocks)
         cfg = K.Config(device, self.nch, self.nstreams, self.decim, self.ntaps, self.max_blocks,
                        (K.F_BITLOG if bitlog else 0) | (K.F_TIMING if timing else 0) | (K.F_REPAIR if repair else 0) |
-                       (K.F_EXACT_FIR if exact_fir else 0), int(max_lag))
+                       (K.F_EXACT_FIR if exact_fir else 0) | (K.F_PRECISE_MIXER if precise_mixer else 0), int(max_lag))
         self.ctx = C.c_void_p()
         rc = self.L.acg_create(C.byref(self.ctx), C.byref(cfg))
         if rc != K.OK:

@@ -58,6 +58,12 @@ extern "C" {
                                      The streaming kernels re-associate the sum (|d dm| <= 1e-5 |dm|, like the reference's own
                                      -Ofast build); this one is ~20x slower and exists to prove that nothing else differs */
 
+#define ACG_F_PRECISE_MIXER 16u   /* verification mode: the demodulator's mixer (msk.c:86-91, cexp) evaluates sin/cos with the < 1 ulp
+                                     polynomial instead of the product's table + rotation (<= 2.1 ulp).  The loop keeps only the
+                                     float-rounded products in*cos, in*(-sin), which are the same for both: this flag lets a
+                                     maintainer check that on his own input (every bit, state double and block must not change).
+                                     ~10 % slower per bit */
+
 typedef struct acg_ctx acg_ctx;
 
 typedef struct {

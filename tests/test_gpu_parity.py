@@ -1036,6 +1036,36 @@ def test_table_sincos_build_and_polynomial_sincos_build_agree_bit_for_bit(tmp_pa
     assert nbits > 2 * 6 * 9000
 
 
+@pytest.mark.parametrize("lpc", [8, 1])
+def test_precise_mixer_flag_changes_nothing_the_loop_keeps(D, testwav, lpc, tune):
+    """ACG_F_PRECISE_MIXER (the < 1 ulp sin/cos was a separate compile, not a run-time verification switch like
+    ACG_F_EXACT_FIR): the same product library, the demodulator launched with the polynomial sin/cos instead of table + rotation.
+    The golden recording's four channels plus two noise-only channels (resets ~19 times a second, razor-edge decisions) in ragged
+    calls: every soft bit, every level, the loop state doubles and every block are identical with and without the flag."""
+    tune("ACG_MSK_LPC", str(lpc))
+    x = testwav.T.copy()
+    rng = np.random.default_rng(5)
+    x = np.concatenate([x, rng.normal(0.2, 0.1, (2, x.shape[1])).astype(np.float32)])
+    cuts = list(range(0, x.shape[1], 4096)) + [x.shape[1]]
+    res = []
+    for precise in (False, True):
+        dec = D.Decoder(x.shape[0], decim=8, ntaps=8, max_blocks=4, precise_mixer=precise)
+        vo, lv, fr = [[] for _ in range(x.shape[0])], [[] for _ in range(x.shape[0])], []
+        for a0, a1 in zip(cuts[:-1], cuts[1:]):
+            dec.demod_msk(x[:, a0:a1])
+            fr += [D.frame_tuple(f) for f in dec.drain_frames()]
+            cnt, v, l = dec.bits_all()
+            for c in range(x.shape[0]):
+                vo[c].append(v[c, :cnt[c]].copy())
+                lv[c].append(l[c, :cnt[c]].copy())
+        st = [dec.state(c) for c in range(x.shape[0])]
+        dec.close()
+        res.append((sorted(fr), [np.concatenate(v_).tobytes() for v_ in vo], [np.concatenate(l_).tobytes() for l_ in lv],
+                    [(s_["MskPhi"], s_["MskDf"], s_["MskClk"], s_["MskLvlSum"], s_["MskS"], s_["idx"], s_["inb"].tobytes()) for s_ in st]))
+    assert res[0] == res[1]
+    assert len(res[0][0]) == 7 and sum(len(b) for b in res[0][1]) > 6 * 9000 * 4
+
+
 def test_streaming_collect_equals_blocking_drain(D, O, S):
     """acg_collect_frames(lag=1) (one call in flight) delivers exactly the blocks of acg_drain_frames,
     in the same per-channel order, over many calls on the rtl path with the stream pipeline on."""
