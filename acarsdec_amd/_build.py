@@ -173,6 +173,36 @@ def build_demo_soapy(force=False):
     return DEMO_SOAPY
 
 
+DEMO_AIR = os.path.join(LIBDIR, "acarsdec_gpu_air")
+DEMO_SDRPLAY = os.path.join(LIBDIR, "acarsdec_gpu_sdrplay")
+
+
+def _build_callback_demo(out, macro, front_end, standin, route_flag, force):
+    """Reference acarsdec.c + <front end>.c + acars.c + output.c ... UNCHANGED, compat_msk.c instead of msk.c, and a file-playing
+    vendor-library stand-in that hands every transfer to the compat entry point instead of the front end's own callback (the
+    one-line binding of INTEGRATION.md without touching the reference source); stub headers: oracle/stub."""
+    if not os.path.exists(os.path.join(REF, front_end)):
+        return out if os.path.exists(out) else None
+    build_lib()
+    demo_dir = os.path.join(CSRC, "demo")
+    stub = os.path.join(os.path.dirname(HERE), "oracle", "stub")
+    ref_units = ["acarsdec.c", "acars.c", front_end, "output.c", "label.c", "cJSON.c", "netout.c", "fileout.c"]
+    mine = [os.path.join(CSRC, "compat_msk.c"), os.path.join(demo_dir, standin)]
+    srcs = [os.path.join(REF, u) for u in ref_units] + mine
+    if force or _newer(srcs + [LIB, os.path.abspath(__file__)], out):
+        _run(["gcc", "-O2", "-w", "-D" + macro, "-D" + route_flag, "-I" + REF, "-I" + INC, "-I" + stub] + srcs +
+             ["-o", out, "-L" + LIBDIR, "-lacarsdec_amd", "-Wl,-rpath,$ORIGIN", "-lm", "-lpthread"])
+    return out
+
+
+def build_demo_air(force=False):
+    return _build_callback_demo(DEMO_AIR, "WITH_AIR", "air.c", "demo_airspy_file.c", "USE_AMD_RX_CALLBACK", force)
+
+
+def build_demo_sdrplay(force=False):
+    return _build_callback_demo(DEMO_SDRPLAY, "WITH_SDRPLAY", "sdrplay.c", "demo_sdrplay_file.c", "USE_AMD_STREAM_CALLBACK", force)
+
+
 MULTIDEV = os.path.join(LIBDIR, "host_multidev")
 
 
@@ -196,6 +226,8 @@ def build_all(force=False):
     demo = build_demo(force)
     build_demo_rtl(force)
     build_demo_soapy(force)
+    build_demo_air(force)
+    build_demo_sdrplay(force)
     build_multidev(force)
     return lib, demo
 

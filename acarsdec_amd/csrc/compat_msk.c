@@ -258,3 +258,85 @@ void acarsdec_amd_soapy_samples(const int16_t *iq, int nsamples)
 }
 #endif
 
+#if defined(WITH_AIR) || defined(WITH_SDRPLAY)
+/* the front ends whose DSP sits in a vendor callback: samples of any count per call, the partial window carried on the device */
+static acg_ctx *g_fe;
+static size_t g_fe_carry;
+
+static void fe_samples(int fmt, const void *p0, const void *p1, int nsamples, int mult, float complex *const *tables)
+{
+	unsigned int n;
+	int rc;
+	channel_t *chs[MAXNBCHANNELS];
+
+	if (nsamples <= 0)
+		return;
+	if (g_fe == NULL) {
+		acg_config cfg;
+		float *taps = malloc(sizeof(float) * 2 * (size_t)mult * nbch);
+		int k;
+		memset(&cfg, 0, sizeof(cfg));
+		cfg.nch = (int)nbch; cfg.nstreams = 1; cfg.decim = mult; cfg.ntaps = mult;
+		cfg.max_blocks = 2; cfg.flags = ACG_F_BITLOG; cfg.max_lag = 1;
+		if ((rc = acg_create(&g_fe, &cfg)) != ACG_OK)
+			die("acg_create", NULL, rc);
+		for (n = 0; n < nbch; n++)
+			for (k = 0; k < mult; k++) {
+				taps[2 * ((size_t)n * mult + k)] = crealf(tables[n][k]);
+				taps[2 * ((size_t)n * mult + k) + 1] = cimagf(tables[n][k]);
+			}
+		if ((rc = acg_set_taps(g_fe, 0, (int)nbch, taps)) != ACG_OK)
+			die("set_taps", g_fe, rc);
+		free(taps);
+	}
+	if ((g_fe_carry + (size_t)nsamples) / (size_t)mult == 0) {               /* no window completes: nothing to demodulate yet */
+		if ((rc = acg_feed_samples_host(g_fe, fmt, p0, p1, 0, (size_t)nsamples)) != ACG_OK)
+			die("feed_samples", g_fe, rc);
+		g_fe_carry += (size_t)nsamples;
+		return;
+	}
+	for (n = 0; n < nbch; n++) {
+		chs[n] = &channel[n];
+		upload(g_fe, (int)n, &channel[n]);
+	}
+	if ((rc = acg_feed_samples_host(g_fe, fmt, p0, p1, 0, (size_t)nsamples)) != ACG_OK)
+		die("feed_samples", g_fe, rc);
+	g_fe_carry = (g_fe_carry + (size_t)nsamples) % (size_t)mult;
+	if ((rc = acg_replay_bits(g_fe, bit_sink, chs)) != ACG_OK)
+		die("replay", g_fe, rc);
+	for (n = 0; n < nbch; n++)
+		download(g_fe, (int)n, &channel[n]);
+	discard_device_blocks(g_fe);
+}
+#endif
+
+#ifdef WITH_AIR
+/*
+ * The body of rx_callback() (air.c:291-341) for all channels: `count` real float32 samples of a transfer of any size; airmult
+ * is air.c's AIRMULT (static there; the call sits inside air.c, where it is in scope):
+ *     static int rx_callback(airspy_transfer_t *transfer)
+ *     {
+ *     +	acarsdec_amd_air_samples((float *)transfer->samples, transfer->sample_count, AIRMULT);
+ *     +	return 0;
+ *     -	... air.c:293-340
+ */
+void acarsdec_amd_air_samples(const float *samples, int count, int airmult)
+{
+	float complex *tab[MAXNBCHANNELS];
+	unsigned int n;
+	for (n = 0; n < nbch; n++) tab[n] = channel[n].wf;                       /* air.c:278-285 */
+	fe_samples(ACG_FMT_F32_REAL, samples, NULL, count, airmult, tab);
+}
+#endif
+
+#ifdef WITH_SDRPLAY
+/* The body of myStreamCallback() (sdrplay.c:215-236) for all channels: numSamples int16 I and Q samples; SDRPLAY_MULT = 160. */
+void acarsdec_amd_sdrplay_samples(const int16_t *xi, const int16_t *xq, int nsamples)
+{
+	float complex *tab[MAXNBCHANNELS];
+	unsigned int n;
+	for (n = 0; n < nbch; n++) tab[n] = channel[n].oscillator;               /* sdrplay.c:160-164 */
+	fe_samples(ACG_FMT_S16_SPLIT, xi, xq, nsamples, 160, tab);
+}
+#endif
+

@@ -20,6 +20,8 @@
  *             instead of uploading every shard once and calling acg_process_iq_u8_dev
  *   --msgs    ACG_F_REPAIR + acg_collect_msgs (the delivered records) instead of raw blocks
  *   --time R  afterwards R more passes over the input: all contexts together, then every context alone in turn
+ *   --shared-input  (with `random`, measurement aid) all contexts of one device read ONE input buffer instead of a buffer each:
+ *             separates "the context" from "the (input buffer, output buffer) pair" when equal contexts run at unequal rates
  *
  * stdout: one line per block / message, merged over all contexts and ordered by (global channel, end_bit):
  *   B <chn> <end_bit> <len> <err> <crc hex> <txt hex>          or          M <chn> <end_bit> <err> <mode> <addr> <label> <bid> <txt hex>
@@ -90,7 +92,7 @@ typedef struct {
 	uint8_t *d_iq;           /* device copy of the shard's rows (dev mode) */
 } shard_t;
 
-static int N, use_host, use_msgs;
+static int N, use_host, use_msgs, shared_input;
 static acg_frame *fbuf;
 static acg_msg *mbuf;
 static int cap;
@@ -151,6 +153,7 @@ int main(int argc, char **argv)
 	for (i = 8; i < argc; i++) {
 		if (!strcmp(argv[i], "--host")) use_host = 1;
 		else if (!strcmp(argv[i], "--msgs")) use_msgs = 1;
+		else if (!strcmp(argv[i], "--shared-input")) shared_input = 1;
 		else if (!strcmp(argv[i], "--time") && i + 1 < argc) reps = atoi(argv[++i]);
 	}
 	if (nch < 1 || decim < 8 || nblk < 1 || cb < 1 || nblk % cb || N < 1 || N > nch) {
@@ -199,7 +202,9 @@ int main(int argc, char **argv)
 		if ((rc = acg_create(&s->ctx, &cfg)) != ACG_OK) die("acg_create", NULL, rc);
 		for (j = 0; j < s->nk; j++)
 			if ((rc = acg_set_taps(s->ctx, j, 1, taps + (size_t)(j * N + k) * decim * 2)) != ACG_OK) die("acg_set_taps", s->ctx, rc);
-		if (!use_host) {
+		if (!use_host && shared_input && random_iq && k >= ndev) {
+			s->d_iq = sh[k % ndev].d_iq;              /* the buffer of the first context on this device (it is the largest shard) */
+		} else if (!use_host) {
 			/* the shard's rows (k, k + N, ...) uploaded once: source pitch N rows, destination dense */
 			if (hipSetDevice(s->dev) != hipSuccess || hipMalloc((void **)&s->d_iq, (size_t)s->nk * row) != hipSuccess ||
 			    (random_iq ? (acg_fill_random_u8_dev(s->d_iq, row, s->nk, row, 0xACA25u + (unsigned)k, NULL) != ACG_OK || hipDeviceSynchronize() != hipSuccess)
@@ -279,7 +284,7 @@ int main(int argc, char **argv)
 	}
 	for (k = 0; k < N; k++) {
 		acg_destroy(sh[k].ctx);
-		if (sh[k].d_iq) { hipSetDevice(sh[k].dev); hipFree(sh[k].d_iq); }
+		if (sh[k].d_iq && !(shared_input && k >= ndev)) { hipSetDevice(sh[k].dev); hipFree(sh[k].d_iq); }
 	}
 	return 0;
 }

@@ -1527,6 +1527,47 @@ def test_compat_soapy_program_output_equals_the_cpu_program(testwav, S, O, tmp_p
     assert outs[0] == outs[1] and sum(len(v) for v in outs[0].values()) == 7 and set(outs[0]) == {"#1", "#2", "#3", "#4"}
 
 
+@pytest.mark.parametrize("fe", ["air", "sdrplay"])
+def test_compat_callback_front_end_programs_equal_their_cpu_twins(fe, testwav, S, O, tmp_path):
+    """The Airspy and SDRplay paths end to end: the reference's UNCHANGED acarsdec.c + air.c / sdrplay.c + acars.c + output.c ...,
+    compat_msk.c instead of msk.c, and a file-playing vendor-library stand-in with ragged transfers that hands every transfer to
+    acarsdec_amd_air_samples() / acarsdec_amd_sdrplay_samples() instead of the front end's own callback (= the one-line change
+    inside rx_callback, air.c:291 / myStreamCallback, sdrplay.c:201).  The program must print what its CPU twin (the reference's own
+    callback and msk.c behind the same stand-in, oracle/_ref/acarsdec_cpu_<fe>) prints on the same sample file: the same messages
+    with the same levels and error counts, per channel in the same order."""
+    import re
+    gpu = os.path.join(ROOT, "acarsdec_amd", "lib", "acarsdec_gpu_" + fe)
+    cpu = os.path.join(ROOT, "oracle", "_ref", "acarsdec_cpu_" + fe)
+    if not (os.path.exists(gpu) and os.path.exists(cpu)):
+        pytest.skip("demo binaries not built (they need the reference tree at build time)")
+    freqs = ["131.525", "131.725", "131.825", "131.550"]
+    fr = [int(round(float(f) * 1e6)) for f in freqs]
+    env = S.pad_blocks(0.5 + 0.5 * testwav.T.astype(np.float64), 1024, 0.5)
+    env = np.concatenate([env, np.full((4, 1024 * 3), 0.5)], axis=1)
+    if fe == "air":
+        rate = 2500000
+        fc = O.air_choose_fc(fr)                                              # air.c:62
+        data = S.real_f32_from_envelopes(env, rate // 12500, [fc - f + rate / 4 for f in fr], phases=[0.3, 1.1, 2.2, 0.7], scale=0.15)
+        args = ["-o", "1", "-s", "0"] + freqs
+    else:
+        fc = 131850000                                                        # sdrplay.c's choice for these four (pinned by the CPU test of the twin)
+        data = S.iq_s16_from_envelopes(env, 160, [f - fc for f in fr], phases=[0.3, 1.1, 2.2, 0.7], full_scale=0.06)
+        args = ["-o", "1", "-s"] + freqs
+    path = tmp_path / ("t." + fe)
+    path.write_bytes(data.tobytes())
+    outs = []
+    for exe in (cpu, gpu):
+        r = subprocess.run([exe] + args, env=dict(os.environ, ACARSDEC_IQ_FILE=str(path)), capture_output=True, timeout=300)
+        assert r.returncode == 0, r.stderr.decode("latin-1")[-800:]
+        lines = re.sub(r"\d\d/\d\d/\d{4} \d\d:\d\d:\d\d\.\d{3} ", "", r.stdout.decode("latin-1")).splitlines()
+        per = {}
+        for l in lines:
+            if l.startswith("#"):
+                per.setdefault(l.split()[0], []).append(l)
+        outs.append(per)
+    assert outs[0] == outs[1] and sum(len(v) for v in outs[0].values()) == 7 and set(outs[0]) == {"#1", "#2", "#3", "#4"}
+
+
 def test_replay_sink_matches_device_blocks(D, O, testwav):
     """acg_replay_bits hands every bit to a putbit()-shaped sink; feeding an oracle FSM from it
     yields the same blocks the device assembled."""

@@ -392,3 +392,43 @@ def test_reference_soapy_program_decodes_the_golden_recording(tmp_path):
     assert r.returncode == 0 and out.count("\n") == 7, out + r.stderr.decode("latin-1")[-500:]
     for tail in ("PH-BXR KL1681 E 5V S53A", "LN-DYY DY083J 2 Q0 S46A", "F-GTAE AF7728 G H1 D65C", "G-DBCK BA031T E Q0 S63A"):
         assert tail in out, tail
+
+
+@pytest.mark.parametrize("fe", ["air", "sdrplay"])
+def test_reference_callback_front_end_programs_decode_the_golden_recording(fe, tmp_path):
+    """The CPU twins of the Airspy / SDRplay demos: the reference's UNCHANGED air.c / sdrplay.c + msk.c + acars.c + output.c behind
+    file-playing vendor-library stand-ins with ragged transfers (acarsdec_amd/csrc/demo/demo_{airspy,sdrplay}_file.c), fed the
+    golden recording as real float32 around Fs/4 / as int16 I/Q at the offsets the front end's own centre-frequency choice gives:
+    each prints the seven messages of SURVEY App. B.  The GPU test compares the bound programs with these."""
+    import re
+    import subprocess
+    from acarsdec_amd import synth as S
+    exe = os.path.join(os.path.dirname(O.ref_path()), "acarsdec_cpu_" + fe)
+    if not (os.path.exists(exe) and O.ref_available("_" + fe)):
+        pytest.skip("oracle/_ref not built")
+    freqs = ["131.525", "131.725", "131.825", "131.550"]
+    fr = [int(round(float(f) * 1e6)) for f in freqs]
+    pcm = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "testwav_pcm16.npz"))["pcm"]
+    wav = pcm.astype(np.float32) / np.float32(32768.0)
+    env = S.pad_blocks(0.5 + 0.5 * wav.T.astype(np.float64), 1024, 0.5)
+    env = np.concatenate([env, np.full((4, 1024 * 3), 0.5)], axis=1)
+    if fe == "air":
+        rate = 2500000
+        fc = O.air_choose_fc(fr)
+        data = S.real_f32_from_envelopes(env, rate // 12500, [fc - f + rate / 4 for f in fr], phases=[0.3, 1.1, 2.2, 0.7], scale=0.15)
+        args = ["-o", "1", "-s", "0"] + freqs
+    else:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(O.__file__)))
+        code = "import sys; sys.path.insert(0, %r); from oracle import oracle as O; print(O.Ref('_sdrplay').init_sdrplay(%r))" % (root, freqs)
+        fc = int(subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120).stdout.strip().splitlines()[-1])
+        assert fc == 131850000
+        data = S.iq_s16_from_envelopes(env, 160, [f - fc for f in fr], phases=[0.3, 1.1, 2.2, 0.7], full_scale=0.06)
+        args = ["-o", "1", "-s"] + freqs
+    path = tmp_path / ("t." + fe)
+    path.write_bytes(data.tobytes())
+    r = subprocess.run([exe] + args, env=dict(os.environ, ACARSDEC_IQ_FILE=str(path)), capture_output=True, timeout=300)
+    out = re.sub(r"\d\d/\d\d/\d{4} \d\d:\d\d:\d\d\.\d{3} ", "", r.stdout.decode("latin-1"))
+    msgs = [l for l in out.splitlines() if l.startswith("#")]
+    assert r.returncode == 0 and len(msgs) == 7, out + r.stderr.decode("latin-1")[-500:]
+    for tail in ("PH-BXR KL1681 E 5V S53A", "LN-DYY DY083J 2 Q0 S46A", "F-GTAE AF7728 G H1 D65C", "G-DBCK BA031T E Q0 S63A"):
+        assert tail in out, tail
