@@ -175,13 +175,11 @@ int  acg_process_dm_host(acg_ctx *ctx, const float *dm_host, size_t pitch_floats
 int  acg_fir_only_dev(acg_ctx *ctx, const uint8_t *iq_dev, size_t pitch_bytes, int nblocks,
 		      void *hip_stream);
 int  acg_sync(acg_ctx *ctx);
-/* Placement trial.  Where a decoder's own buffers happen to lie in HBM relative to the caller's input changes what the
- * down-converter's 1 % write stream costs its reads by up to 15 % (the same launch reads 0.75 or 0.84 of
- * spec; nothing in the virtual addresses tells which).  A host that wants the better placement creates a few contexts,
- * keeps them all alive (so that their allocations differ), calls this on each with a sample of its real input and
- * destroys all but the fastest.  Runs one untimed and `repeats` timed acg_process_iq_u8_dev calls (host clock around
- * a device sync), reports the mean in *ms_per_call, and returns the context to its reset state (acg_reset: channel
- * state, queues); the reference has no counterpart (its buffers are malloc'd once, rtl.c:264-287). */
+/* Diagnostic: times a context on a sample of the caller's input.  Runs one untimed and `repeats` timed acg_process_iq_u8_dev
+ * calls back to back (host clock around a device sync), reports the mean in *ms_per_call, and returns the context to its reset
+ * state (acg_reset: channel state, queues).  Rounds 2-3 used it to pick the fastest of several contexts; round 4 found that
+ * contexts timed for >= 0.25 s of streaming calls agree to 2 % and that what a short trial sees between them is mostly the
+ * trial (profiles/LEDGER.md): a host creates ONE context per device and uses it.  The reference has no counterpart. */
 int  acg_placement_trial(acg_ctx *ctx, const uint8_t *iq_dev, size_t pitch_bytes, int nblocks, int repeats,
 			 void *hip_stream, double *ms_per_call);
 
