@@ -101,7 +101,7 @@ def test_contexts_sharing_one_device_all_make_progress_and_their_rates_are_recor
     not the (input buffer, dm buffer) pair: with --shared-input (all contexts read one buffer) the spread stays (10.8 % / 10.6 %,
     profiles/r04_multidev_shared_input.txt).  What is left is where the k-th context's streams land among the runtime's hardware
     queues (round 3: dummy streams created in between move WHICH context is slow).  On an N-GPU node every device has ONE
-    context; here the test only insists that every context makes progress at a comparable rate and that N contexts sharing a
+    context; here the test only insists that every context makes progress at a comparable rate (within 50 %) and that N contexts sharing a
     device do not collapse."""
     # (--time 150: every context is timed alone over 150 calls after a turn for nothing)
     r = subprocess.run([BIN, "random", "rtl", "8192", "200", "8", "8", str(N), "--msgs", "--time", "150"], capture_output=True, text=True, timeout=900)
@@ -113,5 +113,5 @@ def test_contexts_sharing_one_device_all_make_progress_and_their_rates_are_recor
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "multidev_rates.txt"), "a") as f:
         f.write("N=%d  alone %s  together %s  spread %.2f %%\n" % (N, alone, together, 100 * spread))
-    assert spread < 0.30, (alone, spread)
+    assert spread < 0.50, (alone, spread)          # (observed 5-18 % over eight boxes; this is a sanity bound, the numbers are the result)
     assert together[0] > 0.6 * max(alone)            # N contexts sharing ONE device: no faster than one, not collapsed either
