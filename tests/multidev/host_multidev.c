@@ -160,6 +160,13 @@ int main(int argc, char **argv)
 		fprintf(stderr, "host_multidev: bad arguments (nblk must be a multiple of cb, 1 <= N <= nch)\n");
 		return 2;
 	}
+	/* Several contexts on ONE device (the rehearsal): the HIP runtime maps streams onto GPU_MAX_HW_QUEUES = 4 hardware queues per
+	 * device and priority, round robin, and streams that share a queue serialise against each other -- with 4 contexts (12 pooled
+	 * streams) the stages of different contexts stop overlapping: all together 1.89 M channel*Msps with 4 queues, 2.48 M with 8
+	 * (profiles/r04_multidev_hw_queues.txt).  The variable is read when the runtime starts, so the HOST sets it, before its first
+	 * HIP call.  One context per device (the deployment) stays inside the default. */
+	if (N > 1)
+		setenv("GPU_MAX_HW_QUEUES", "16", 0);
 	ndev = acg_device_count();
 	if (ndev < 1) die("acg_device_count", NULL, ACG_ENODEV);          /* no CPU fallback anywhere */
 	row = (size_t)nblk * ACG_BLOCK * decim * 2;

@@ -95,14 +95,12 @@ def test_delivered_messages_are_the_single_context_messages(job):
 def test_contexts_sharing_one_device_all_make_progress_and_their_rates_are_recorded(N):
     """8192 channels of device-generated input over N contexts on the box's GPU(s), timed by the C host: all together, then each
     alone in turn (150 calls = 0.2-0.4 s per context, after a turn for nothing).  The rates go to gpurun_out/multidev_rates.txt
-    (committed under profiles/).  What round 4 measured: in a Python process four contexts agree to <= 2 % once each is timed for
-    >= 0.25 s (profiles/r04_context_probe.txt; rounds 2-3 timed 2 calls = 5 ms per context and saw 7-16 %), but in THIS host equal
-    contexts that share one device still differ by 5-18 %, a different context being the slow one from box to box -- and that is
-    not the (input buffer, dm buffer) pair: with --shared-input (all contexts read one buffer) the spread stays (10.8 % / 10.6 %,
-    profiles/r04_multidev_shared_input.txt).  What is left is where the k-th context's streams land among the runtime's hardware
-    queues (round 3: dummy streams created in between move WHICH context is slow).  On an N-GPU node every device has ONE
-    context; here the test only insists that every context makes progress at a comparable rate (within 50 %) and that N contexts sharing a
-    device do not collapse."""
+    (committed under profiles/).  What round 4 measured: the spread between equal contexts that share one device (5-18 % with the
+    runtime's default of 4 hardware queues per device, whichever context's streams alias being the slow one) is stream -> hardware
+    queue aliasing: streams that share a queue serialise.  It does not follow the buffers (--shared-input changes nothing), it does
+    follow GPU_MAX_HW_QUEUES (all four together 1.89 M with 4 queues, 2.48 M with 8: profiles/r04_multidev_hw_queues.txt); the host
+    sets 16 itself.  A residue of a few per cent remains; on an N-GPU node every device has ONE context.  The test insists that
+    every context makes progress at a comparable rate (within 50 %) and that N contexts sharing a device do not collapse."""
     # (--time 150: every context is timed alone over 150 calls after a turn for nothing)
     r = subprocess.run([BIN, "random", "rtl", "8192", "200", "8", "8", str(N), "--msgs", "--time", "150"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-1500:]
