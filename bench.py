@@ -39,6 +39,14 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# This process creates one context after the other on one device (a case each, plus the gate's exact-order context beside them).
+# The HIP runtime maps streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues per device and priority, round robin, and
+# streams that share a queue serialise against each other: which case's context drew aliasing streams followed the order of the
+# cases (the same case: 2.45 M channel*Msps as the first of a run, 2.13 M as the fourth; profiles/LEDGER.md round 4).  So this
+# host does what INTEGRATION.md tells every host with several contexts per device to do, before the runtime starts.  A process
+# with ONE context is indifferent to the setting (profiles/r04_single_context_hw_queues.txt).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4-copy ceiling)
 COPY_CEILING_GBS = 6290.0
 
@@ -784,7 +792,7 @@ def run_case(J, name, case, args, steps, warmup, headline):
                                % (case["tag"], nch, 12500 * M / 1e6, {"u8": "u8 IQ", "cs16": "CS16 IQ", "split16": "split int16 I/Q", "f32": "real f32"}[fmt_name],
                                   M, ntaps, reps, nblk, cb, " + block repair + message split" if repair else "", args.collect_lag),
                    "signal_seconds_per_pass": round(nblk * 0.08192, 3),
-                   "callbacks_per_call": cb, "collect_lag": args.collect_lag,
+                   "callbacks_per_call": cb, "collect_lag": args.collect_lag, "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
                    "case": name, "input_format": fmt_name, "channels_per_gpu": nch, "decim": M, "ntaps": ntaps, "blocks_per_step": nblk * reps, "blocks_per_pass": nblk, "passes_per_step": reps,
                    "input_bytes_per_gpu": int(nstreams * row),
                    "realtime_channels_equiv": int(value / (12500 * M / 1e6)),
