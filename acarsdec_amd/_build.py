@@ -76,7 +76,7 @@ def build_lib(force=False, stamp=False, poly=False, lab=False):
     defs = (["-DACG_LAB"] if (lab or stamp or poly) else []) + (["-DACG_MSK_STAMP"] if stamp else []) + (["-DACG_MSK_SINCOS_POLY"] if poly else [])
     out_lib = LIB_STAMP if stamp else LIB_POLY if poly else LIB_LAB if lab else LIB
     hdrs = [os.path.join(CSRC, "acg_internal.h"), os.path.join(CSRC, "msk_common.h"), os.path.join(INC, "acarsdec_amd.h"),
-            os.path.abspath(__file__)]   # flags live here
+            os.path.join(INC, "acarsdec_amd_lab.h"), os.path.abspath(__file__)]   # flags live here
     objs = []
     hc = hipcc()
     for name, flags, in_product in UNITS:
@@ -94,9 +94,35 @@ def build_lib(force=False, stamp=False, poly=False, lab=False):
     if force or _newer([src] + hdrs, obj):
         _run(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-I" + INC, "-c", src, "-o", obj])
     objs.append(obj)
-    if force or _newer(objs, out_lib):
-        _run([hc, "--offload-arch=" + ARCH, "-shared", "-o", out_lib] + objs + ["-ldl", "-lm"])
+    # The library exports exactly what include/acarsdec_amd.h and include/acarsdec_amd_lab.h declare (a linker version script
+    # made from the headers; the kernel launchers, the tuning look-ups and host_setup.c's helpers are local).  The stamp
+    # build's two extra entry points are declared in the lab header and simply absent from the other builds.
+    vs = os.path.join(OBJDIR, "exports.map")
+    vs = os.path.join(OBJDIR, "exports_stamp.map" if stamp else "exports.map")
+    names = [n for n in declared_symbols() if stamp or n not in STAMP_ONLY]
+    text = "{\n  global:\n" + "".join("    %s;\n" % n for n in names) + "  local: *;\n};\n"
+    if not os.path.exists(vs) or open(vs).read() != text:
+        with open(vs, "w") as f:
+            f.write(text)
+    if force or _newer(objs + [vs], out_lib):
+        _run([hc, "--offload-arch=" + ARCH, "-shared", "-o", out_lib] + objs + ["-Wl,--version-script=" + vs, "-ldl", "-lm"])
     return out_lib
+
+
+STAMP_ONLY = ("acg_msk_stamp_read", "acg_msk_lanes_per_channel")
+
+
+def declared_symbols(headers=("acarsdec_amd.h", "acarsdec_amd_lab.h")):
+    """names of the functions the public headers declare, in order (comments stripped; a declaration is `name(` at the start
+    of a line after its return type)"""
+    import re
+    names = []
+    for h in headers:
+        src = re.sub(r"/\*.*?\*/", "", open(os.path.join(INC, h)).read(), flags=re.S)
+        for m in re.finditer(r"^(?:const\s+)?(?:unsigned\s+)?[A-Za-z_][A-Za-z0-9_]*\s*\**\s*(ac(?:g|arsdec_amd)_[A-Za-z0-9_]+)\s*\(", src, flags=re.M):
+            if m.group(1) not in names:
+                names.append(m.group(1))
+    return names
 
 
 def build_demo(force=False):
@@ -116,91 +142,105 @@ def build_demo(force=False):
 DEMO_RTL = os.path.join(LIBDIR, "acarsdec_gpu_rtl")
 
 
-def build_demo_rtl(force=False):
-    """Reference acarsdec.c + rtl.c + acars.c + output.c ... UNCHANGED, with compat_msk.c instead of msk.c
-    and a file-playing librtlsdr stand-in that hands the buffers to acarsdec_amd_in_callback()."""
-    if not os.path.exists(os.path.join(REF, "rtl.c")):
-        return DEMO_RTL if os.path.exists(DEMO_RTL) else None
-    build_lib()
-    demo_dir = os.path.join(CSRC, "demo")
-    ref_units = ["acarsdec.c", "acars.c", "rtl.c", "output.c", "label.c", "cJSON.c", "netout.c", "fileout.c"]
-    mine = [os.path.join(CSRC, "compat_msk.c"), os.path.join(demo_dir, "demo_rtlsdr_file.c")]
-    srcs = [os.path.join(REF, u) for u in ref_units] + mine
-    if force or _newer(srcs + [LIB], DEMO_RTL):
-        _run(["gcc", "-O2", "-w", "-DWITH_RTL", "-DUSE_AMD_IN_CALLBACK", "-I" + REF, "-I" + INC, "-I" + demo_dir] + srcs +
-             ["-o", DEMO_RTL, "-L" + LIBDIR, "-lacarsdec_amd", "-Wl,-rpath,$ORIGIN", "-lm", "-lpthread"])
-    return DEMO_RTL
-
-
 DEMO_SOAPY = os.path.join(LIBDIR, "acarsdec_gpu_soapy")
-SOAPY_OLD_TAIL = "\t\tcurrent_index = (current_index + res) % rateMult;\n"
+DEMO_AIR = os.path.join(LIBDIR, "acarsdec_gpu_air")
+DEMO_SDRPLAY = os.path.join(LIBDIR, "acarsdec_gpu_sdrplay")
+COMPAT_INCLUDE = '#include "acarsdec_amd_compat.h"      /* acarsdec_amd */\n'
+
+
+def _cut(src, start, end, what):
+    """(a, b): the span from the first `start` to the end of the first `end` behind it; both must be there exactly as written"""
+    assert src.count(start) == 1, "%s: anchor %r occurs %d times" % (what, start, src.count(start))
+    a = src.index(start)
+    b = src.index(end, a) + len(end)
+    return a, b
+
+
+def patched_source(front_end):
+    """The reference's <front_end>.c with the ONE binding hunk of INTEGRATION.md applied, as text (never written to the repo:
+    it goes to the compiler through stdin).  Everything else of the file -- init*, chooseFc, the tap / oscillator tables, the
+    watchdog, open / close -- is the reference's own text.
+
+      rtl.c      rtl.c:364: librtlsdr gets a callback that keeps the watchdog reset of rtl.c:318-320 and hands the buffer to
+                 acarsdec_amd_in_callback() instead of the static in_callback()
+      soapy.c    soapy.c:228-254: the per-channel loop of the reader thread becomes acarsdec_amd_soapy_samples(soapyInBuf, res)
+      air.c      air.c:293-338: the body of rx_callback() becomes acarsdec_amd_air_samples(samples, sample_count, AIRMULT)
+      sdrplay.c  sdrplay.c:213-236: the body of myStreamCallback() becomes acarsdec_amd_sdrplay_samples(xi, xq, numSamples)"""
+    src = open(os.path.join(REF, front_end)).read()
+    if front_end == "rtl.c":
+        old = "\trtlsdr_read_async(dev, in_callback, NULL, 4, rtlInBufSize);\n"
+        assert src.count(old) == 1 and src.count("in_callback") == 2          # its definition and this one use
+        wrapper = ("static void in_callback_amd(unsigned char *buf, uint32_t nread, void *ctx)      /* acarsdec_amd: replaces in_callback at rtl.c:364 */\n"
+                   "{\n\tpthread_mutex_lock(&cbMutex);\n\twatchdogCounter = 50;\n\tpthread_mutex_unlock(&cbMutex);\n"
+                   "\tacarsdec_amd_in_callback(buf, nread, ctx);\n}\n\n")
+        a = src.index("static void *readThreadEntryPoint(void *arg)")
+        src = src[:a] + COMPAT_INCLUDE + wrapper + src[a:]
+        return src.replace(old, "\trtlsdr_read_async(dev, in_callback_amd, NULL, 4, rtlInBufSize);\n")
+    if front_end == "soapy.c":
+        a, b = _cut(src, "\t\tint n, i;\n\t\tint\tlocal_ind;", "\t\tcurrent_index = (current_index + res) % rateMult;\n", front_end)
+        assert "demodMSK(ch, SOAPYOUTBUFSZ)" in src[a:b] and src.count("demodMSK(") == 1
+        return (src[:a] + "\t\t{ extern void acarsdec_amd_soapy_samples(const int16_t *iq, int nsamples);\n"
+                "\t\t  acarsdec_amd_soapy_samples(soapyInBuf, res); }          /* acarsdec_amd: replaces soapy.c:228-254 */\n" + src[b:])
+    if front_end == "air.c":
+        a, b = _cut(src, "\tfloat* pt_rx_buffer;\n", "        ind=ben;\n", front_end)
+        assert src.index("static int rx_callback(airspy_transfer_t* transfer)") < a and "demodMSK(ch,m);" in src[a:b] and src.count("demodMSK(") == 1
+        src = (src[:a] + "\tacarsdec_amd_air_samples((const float *)transfer->samples, transfer->sample_count, AIRMULT);"
+               "          /* acarsdec_amd: replaces air.c:293-338 */\n" + src[b:])
+        a = src.index("int ind=0;\nstatic int rx_callback")
+        return src[:a] + COMPAT_INCLUDE + src[a:]
+    if front_end == "sdrplay.c":
+        a, b = _cut(src, "int n, i;\nint\tlocal_ind;\n", "\tcurrent_index\t= (current_index + numSamples) % SDRPLAY_MULT;\n", front_end)
+        assert src.index("void myStreamCallback (") < a and "demodMSK (ch, 512);" in src[a:b] and src.count("demodMSK (") == 1
+        src = (src[:a] + "\tacarsdec_amd_sdrplay_samples(xi, xq, (int)numSamples);          /* acarsdec_amd: replaces sdrplay.c:213-236 */\n" + src[b:])
+        a = src.index("static\nint current_index = 0;")
+        return src[:a] + COMPAT_INCLUDE + src[a:]
+    raise ValueError(front_end)
 
 
 def patched_soapy_source():
-    """The reference's soapy.c with the ONE hunk of INTEGRATION.md applied, as text (never written to the repo): the
-    per-channel loop of the reader thread (soapy.c:228-254: `int n, i; ... current_index = (current_index + res) % rateMult;`)
-    becomes a call of acarsdec_amd_soapy_samples() (compat_msk.c).  Everything else -- initSoapy, chooseFc, the oscillator
-    tables, the watchdog, open / close -- is the reference's own text."""
-    src = open(os.path.join(REF, "soapy.c")).read()
-    a = src.index("\t\tint n, i;\n\t\tint\tlocal_ind;")
-    b = src.index(SOAPY_OLD_TAIL, a) + len(SOAPY_OLD_TAIL)
-    assert "demodMSK(ch, SOAPYOUTBUFSZ)" in src[a:b] and src.count("demodMSK(") == 1
-    return (src[:a] + "\t\t{ extern void acarsdec_amd_soapy_samples(const int16_t *iq, int nsamples);\n"
-            "\t\t  acarsdec_amd_soapy_samples(soapyInBuf, res); }          /* acarsdec_amd: replaces soapy.c:228-254 */\n" + src[b:])
+    return patched_source("soapy.c")
 
 
-def build_demo_soapy(force=False):
-    """Reference acarsdec.c + acars.c + output.c ... UNCHANGED and soapy.c with the one-hunk binding, compat_msk.c instead of
-    msk.c, and a file-playing SoapySDR stand-in (csrc/demo/demo_soapy_file.c; headers: oracle/stub/SoapySDR).  The patched
-    soapy.c goes to the compiler through stdin: no reference text is written anywhere in the repo."""
-    if not os.path.exists(os.path.join(REF, "soapy.c")):
-        return DEMO_SOAPY if os.path.exists(DEMO_SOAPY) else None
-    build_lib()
-    demo_dir = os.path.join(CSRC, "demo")
-    stub = os.path.join(os.path.dirname(HERE), "oracle", "stub")
-    ref_units = ["acarsdec.c", "acars.c", "output.c", "label.c", "cJSON.c", "netout.c", "fileout.c"]
-    mine = [os.path.join(CSRC, "compat_msk.c"), os.path.join(demo_dir, "demo_soapy_file.c")]
-    srcs = [os.path.join(REF, u) for u in ref_units] + mine
-    if force or _newer(srcs + [LIB, os.path.join(REF, "soapy.c"), os.path.abspath(__file__)], DEMO_SOAPY):
-        obj = os.path.join(OBJDIR, "soapy_bound.o")
-        r = subprocess.run(["gcc", "-O2", "-w", "-DWITH_SOAPY", "-I" + REF, "-I" + INC, "-I" + stub, "-x", "c", "-c", "-", "-o", obj],
-                           input=patched_soapy_source(), capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("soapy.c (bound) failed to compile:\n" + r.stderr)
-        _run(["gcc", "-O2", "-w", "-DWITH_SOAPY", "-I" + REF, "-I" + INC, "-I" + stub] + srcs + [obj] +
-             ["-o", DEMO_SOAPY, "-L" + LIBDIR, "-lacarsdec_amd", "-Wl,-rpath,$ORIGIN", "-lm", "-lpthread"])
-        os.remove(obj)
-    return DEMO_SOAPY
-
-
-DEMO_AIR = os.path.join(LIBDIR, "acarsdec_gpu_air")
-DEMO_SDRPLAY = os.path.join(LIBDIR, "acarsdec_gpu_sdrplay")
-
-
-def _build_callback_demo(out, macro, front_end, standin, route_flag, force):
-    """Reference acarsdec.c + <front end>.c + acars.c + output.c ... UNCHANGED, compat_msk.c instead of msk.c, and a file-playing
-    vendor-library stand-in that hands every transfer to the compat entry point instead of the front end's own callback (the
-    one-line binding of INTEGRATION.md without touching the reference source); stub headers: oracle/stub."""
+def _build_bound_demo(out, macro, front_end, standin, force, extra_inc=()):
+    """The reference program on one front end, bound to the GPU library the way INTEGRATION.md documents: acarsdec.c + acars.c +
+    output.c ... UNCHANGED, <front_end>.c with its one-hunk binding applied (patched_source), compat_msk.c instead of msk.c,
+    and a file-playing vendor-library stand-in (csrc/demo/; stub headers: oracle/stub) that knows nothing about the GPU: it
+    calls whatever callback / returns whatever read the front end asks for, exactly as for the CPU twin in oracle/_ref."""
     if not os.path.exists(os.path.join(REF, front_end)):
         return out if os.path.exists(out) else None
     build_lib()
     demo_dir = os.path.join(CSRC, "demo")
     stub = os.path.join(os.path.dirname(HERE), "oracle", "stub")
-    ref_units = ["acarsdec.c", "acars.c", front_end, "output.c", "label.c", "cJSON.c", "netout.c", "fileout.c"]
+    ref_units = ["acarsdec.c", "acars.c", "output.c", "label.c", "cJSON.c", "netout.c", "fileout.c"]
     mine = [os.path.join(CSRC, "compat_msk.c"), os.path.join(demo_dir, standin)]
     srcs = [os.path.join(REF, u) for u in ref_units] + mine
-    if force or _newer(srcs + [LIB, os.path.abspath(__file__)], out):
-        _run(["gcc", "-O2", "-w", "-D" + macro, "-D" + route_flag, "-I" + REF, "-I" + INC, "-I" + stub] + srcs +
+    incs = ["-I" + REF, "-I" + INC] + ["-I" + i for i in extra_inc] + ["-I" + stub]
+    if force or _newer(srcs + [LIB, os.path.join(REF, front_end), os.path.join(INC, "acarsdec_amd_compat.h"), os.path.abspath(__file__)], out):
+        obj = os.path.join(OBJDIR, front_end + "_bound.o")
+        r = subprocess.run(["gcc", "-O2", "-w", "-D" + macro] + incs + ["-x", "c", "-c", "-", "-o", obj],
+                           input=patched_source(front_end), capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("%s (bound) failed to compile:\n%s" % (front_end, r.stderr))
+        _run(["gcc", "-O2", "-w", "-D" + macro] + incs + srcs + [obj] +
              ["-o", out, "-L" + LIBDIR, "-lacarsdec_amd", "-Wl,-rpath,$ORIGIN", "-lm", "-lpthread"])
+        os.remove(obj)
     return out
 
 
+def build_demo_rtl(force=False):
+    return _build_bound_demo(DEMO_RTL, "WITH_RTL", "rtl.c", "demo_rtlsdr_file.c", force, extra_inc=(os.path.join(CSRC, "demo"),))
+
+
+def build_demo_soapy(force=False):
+    return _build_bound_demo(DEMO_SOAPY, "WITH_SOAPY", "soapy.c", "demo_soapy_file.c", force)
+
+
 def build_demo_air(force=False):
-    return _build_callback_demo(DEMO_AIR, "WITH_AIR", "air.c", "demo_airspy_file.c", "USE_AMD_RX_CALLBACK", force)
+    return _build_bound_demo(DEMO_AIR, "WITH_AIR", "air.c", "demo_airspy_file.c", force)
 
 
 def build_demo_sdrplay(force=False):
-    return _build_callback_demo(DEMO_SDRPLAY, "WITH_SDRPLAY", "sdrplay.c", "demo_sdrplay_file.c", "USE_AMD_STREAM_CALLBACK", force)
+    return _build_bound_demo(DEMO_SDRPLAY, "WITH_SDRPLAY", "sdrplay.c", "demo_sdrplay_file.c", force)
 
 
 MULTIDEV = os.path.join(LIBDIR, "host_multidev")

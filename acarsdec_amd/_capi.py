@@ -31,21 +31,22 @@ class ChanState(C.Structure):
 class Frame(C.Structure):
     _fields_ = [("chn", C.c_int), ("len", C.c_int), ("err", C.c_int), ("lvl", C.c_float),
                 ("crc", C.c_ubyte * 2), ("txt", C.c_ubyte * TXTMAX),
-                ("end_bit", C.c_longlong), ("end_sample", C.c_longlong)]
+                ("end_bit", C.c_longlong), ("end_sample", C.c_longlong), ("soh_sample", C.c_longlong)]
 
 
 class Msg(C.Structure):
     """acg_msg: outputmsg()'s field split as a fixed binary record"""
     _fields_ = [("chn", C.c_int), ("err", C.c_int), ("lvl", C.c_float), ("txt_len", C.c_int),
-                ("end_bit", C.c_longlong), ("end_sample", C.c_longlong), ("reserved0", C.c_double), ("reserved1", C.c_int),
+                ("end_bit", C.c_longlong), ("end_sample", C.c_longlong), ("soh_sample", C.c_longlong), ("reserved1", C.c_int),
                 ("reserved2", C.c_char), ("mode", C.c_char), ("addr", C.c_char * 8), ("ack", C.c_char), ("label", C.c_char * 3),
                 ("bid", C.c_char), ("no", C.c_char * 5), ("fid", C.c_char * 7), ("bs", C.c_char), ("be", C.c_char),
-                ("down", C.c_char), ("txt", C.c_ubyte * 242)]
+                ("down", C.c_char), ("txt", C.c_ubyte * 242), ("reserved3", C.c_int)]
 
 
 BIT_SINK = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_float, C.c_float)
 
-# name -> (restype, argtypes): every symbol include/acarsdec_amd.h declares
+# name -> (restype, argtypes): every symbol include/acarsdec_amd.h (the product API) and include/acarsdec_amd_lab.h (measurement
+# and diagnostics: LAB_SYMBOLS below) declare; the library exports exactly these (tests/test_host_logic.py)
 SYMBOLS = {
     "acg_device_count": (C.c_int, []),
     "acg_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(Config)]),
@@ -63,9 +64,6 @@ SYMBOLS = {
     "acg_process_dm_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "acg_process_dm_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
     "acg_fir_only_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
-    "acg_placement_trial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double)]),
-    "acg_placement_trial_samples": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_void_p,
-                                              C.POINTER(C.c_double)]),
     "acg_sync": (C.c_int, [C.c_void_p]),
     "acg_soapy_taps": (C.c_int, [C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "acg_sdrplay_taps": (C.c_int, [C.c_float, C.c_uint, C.c_void_p]),
@@ -85,15 +83,25 @@ SYMBOLS = {
     "acg_read_bits_all": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "acg_bit_capacity": (C.c_int, [C.c_void_p]),
     "acg_max_lag": (C.c_int, [C.c_void_p]),
-    "acg_tune": (C.c_int, [C.c_char_p, C.c_char_p]),
-    "acg_is_lab_build": (C.c_int, []),
     "acg_read_dm": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "acg_get_state": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(ChanState)]),
     "acg_set_state": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(ChanState)]),
+    "acg_get_state_n": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(ChanState)]),
+    "acg_set_state_n": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(ChanState)]),
+    "acg_read_dm_n": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int]),
     "acg_replay_bits": (C.c_int, [C.c_void_p, BIT_SINK, C.c_void_p]),
     "acg_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int),
                                  C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "acg_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+}
+
+# include/acarsdec_amd_lab.h: measurement / diagnostics (exported by the product library too: bench.py times the product)
+LAB_SYMBOLS = {
+    "acg_placement_trial": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_double)]),
+    "acg_placement_trial_samples": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.c_void_p,
+                                              C.POINTER(C.c_double)]),
+    "acg_tune": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "acg_is_lab_build": (C.c_int, []),
     "acg_fill_random_u8_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_uint64, C.c_void_p]),
     "acg_synth_iq_u8_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_uint64, C.c_void_p]),
@@ -101,7 +109,11 @@ SYMBOLS = {
     "acg_probe_read_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "acg_selftest_div2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "acg_selftest_sincos": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "acg_lab_set_block_counter": (C.c_int, [C.c_void_p, C.c_uint]),
+    "acg_lab_block_ring_size": (C.c_uint, [C.c_void_p]),
 }
+# declared in acarsdec_amd_lab.h, present in the stamp build only (-DACG_MSK_STAMP)
+STAMP_SYMBOLS = ("acg_msk_stamp_read", "acg_msk_lanes_per_channel")
 
 _lib = None
 _lab = None
@@ -119,7 +131,7 @@ def _open(path):
     except Exception:  # pragma: no cover - torch is plumbing, not required by the library
         pass
     L = C.CDLL(path)
-    for name, (res, args) in SYMBOLS.items():
+    for name, (res, args) in list(SYMBOLS.items()) + list(LAB_SYMBOLS.items()):
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args

@@ -28,6 +28,8 @@ struct AcgChan {
     unsigned int crc0;          // blk->crc[0] (held between CRC1 and CRC2)
     long long nbit_total;       // bits produced since reset
     long long nsamp_total;      // 12.5 kHz samples consumed since reset
+    unsigned int soh32;         // low 32 bits of the sample index at which the block's SOH byte completed (acars.c:290 stamps blk->tv there)
+    unsigned int pad_;
 };
 
 // One queued block (device layout; converted to acg_frame on the host).
@@ -41,7 +43,8 @@ struct AcgFrameRec {
     long long end_sample;
     unsigned char crc[2];
     unsigned char status;       // 0 raw (as queued by decodeAcars), 1 processed + kept, 2 processed + dropped
-    unsigned char pad[5];
+    unsigned char pad[1];
+    int soh_back;               // end_sample - (sample at which the SOH byte completed): where the reference stamps blk->tv (acars.c:290)
     unsigned char txt[256];     // 16-byte aligned, 16-byte multiples for vector copies
 };
 
@@ -67,6 +70,7 @@ struct AcgMsgRec {
     char bs, be;
     char down;
     char txt[ACG_MSG_TXT];
+    int soh_back;               // (acg_msg: the host turns it into soh_sample) end_sample - sample of the SOH byte
 };
 
 struct FirArgs {

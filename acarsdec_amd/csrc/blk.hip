@@ -33,22 +33,10 @@ __device__ __forceinline__ bool crc_acceptable(const unsigned short* synd, unsig
 // -- identical to acars.c:159-165's table walk (tests/test_host_logic.py checks the identity against the oracle's update_crc),
 // and embarrassingly parallel: lane L takes bytes L, L + 64, L + 128, L + 192 (one coalesced 256-byte read per block), xors the
 // syndromes of their set bits out of an LDS copy of the table, and six butterfly steps fold the wave.  Parity errors are ballots.
-// The rare repairs (fixprerr, fixdberr) run replicated on every lane from wave-uniform values, in the reference's search order.
-#define BLK_T 32        // threads per workgroup of the field split below
-#define BLK_ROW 336     // its LDS row: a block's 256 text bytes, then the 320-byte record built in place (84 dwords: <= 8 lanes per bank)
+// The repairs (fixprerr, fixdberr) are searched 64 candidates at a time in the reference's search order (see below).
+#define BLK_ROW 336     // LDS row of the field split: a block's 256 text bytes, then the 320-byte record built in place
 #define BLK_WAVES 4
 #define NSYND (8 * 243)
-
-// pulls block f's text (256 bytes, 16-byte aligned in the ring) into this thread's LDS row: sixteen independent loads
-__device__ __forceinline__ void stage_text(const AcgFrameRec* f, unsigned char* row)
-{
-    const uint4* src = (const uint4*)f->txt;
-    uint4 v[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = src[j];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) ((uint4*)row)[j] = v[j];
-}
 
 __device__ __forceinline__ unsigned int synd_of_bits(const unsigned short* synd, unsigned int byte, int k8)
 {
@@ -75,13 +63,18 @@ __global__ __launch_bounds__(64 * BLK_WAVES) void blk_repair_kernel(AcgFrameRec*
     __shared__ unsigned short synd[NSYND];
     for (int i = threadIdx.x; i < NSYND; i += 64 * BLK_WAVES) synd[i] = synd_g[i];
     __syncthreads();
-    const unsigned int hi = __hip_atomic_load(upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned int mark = __hip_atomic_load(upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned int from = *done_upto;
+    // A mark at or BEHIND what has been processed means nothing to do (the counters are monotonic and wrap: a signed
+    // difference).  It cannot move the pass backwards: re-processing blocks whose parity has already been stripped would
+    // fail their parity check and drop valid messages (a pass that reads a mark word which a later call
+    // has already re-used; the host also keeps the words from being re-used early, acg_api.cpp begin_call).
+    const unsigned int hi = (int)(mark - from) > 0 ? mark : from;
     const unsigned int lo = (hi - from > cap) ? hi - cap : from;
     const int lane = threadIdx.x & 63;
     const unsigned int wave = blockIdx.x * BLK_WAVES + (threadIdx.x >> 6), nwaves = gridDim.x * BLK_WAVES;
     for (unsigned int q = lo + wave; q - lo < hi - lo; q += nwaves) {      // (q is wave-uniform: no divergence around the ballots)
-        AcgFrameRec* f = frames + (q % cap);
+        AcgFrameRec* f = frames + (q & (cap - 1));                          // (cap is a power of two)
         const int len = f->len;
         if (len < 13) {                                                    // acars.c:124
             if (lane == 0) f->status = 2;
@@ -126,22 +119,30 @@ __global__ __launch_bounds__(64 * BLK_WAVES) void blk_repair_kernel(AcgFrameRec*
                 }
             }
         }
+        // The two searches are the reference's, candidate for candidate, but the WAVE walks them 64 candidates at a time in the
+        // reference's visiting order and takes the first hit of the first 64-group that has one (ballot + find-first): a search
+        // that fails -- every block cut by noise whose parity happens to hold, 512 candidates or 250 x 56 -- is then a few
+        // microseconds instead of the 0.5 - 1.7 ms one lane took for it (rounds 3-4 ran them replicated on every lane; those
+        // passes were the 12 - 14 % of GPU time of profiles/r04_*_stats.txt).
         bool ok = true;
         if (pn) {
             // fixprerr: depth-first over bit positions of the pn flagged bytes, first byte outermost,
             // i.e. lexicographic order of (i0, i1, i2) -- the recursion's visiting order (acars.c:45-50)
             ok = false;
             const int ncomb = 1 << (3 * pn);
-            for (int comb = 0; comb < ncomb && !ok; ++comb) {
+            for (int c0 = 0; c0 < ncomb && !ok; c0 += 64) {
+                const int comb = c0 + lane;
                 unsigned short c2 = crc;
                 for (int d = 0; d < pn; ++d) {
                     const int bit = (comb >> (3 * (pn - 1 - d))) & 7;
                     c2 ^= synd[bit + 8 * (len - pr[d] + 1)];
                 }
-                if (crc_acceptable(synd, c2)) {
+                const unsigned long long hit = __ballot(comb < ncomb && crc_acceptable(synd, c2));
+                if (hit) {
+                    const int first = c0 + __ffsll((long long)hit) - 1;
                     for (int d = 0; d < pn; ++d)
                         if (lane == (pr[d] & 63)) {
-                            const unsigned int flip = 1u << ((comb >> (3 * (pn - 1 - d))) & 7);
+                            const unsigned int flip = 1u << ((first >> (3 * (pn - 1 - d))) & 7);
                             if ((pr[d] >> 6) == 0) c[0] ^= flip;
                             else if ((pr[d] >> 6) == 1) c[1] ^= flip;
                             else if ((pr[d] >> 6) == 2) c[2] ^= flip;
@@ -151,25 +152,33 @@ __global__ __launch_bounds__(64 * BLK_WAVES) void blk_repair_kernel(AcgFrameRec*
                 }
             }
         } else if (crc) {
-            // fixdberr (acars.c:66-90)
-            ok = false;
-            for (int i = 0; i < 16 && !ok; ++i) ok = synd[i] == crc;
-            for (int k = 0; k < len && !ok; ++k) {
-                const int bo = 8 * (len - k + 1);
-                for (int i = 0; i < 8 && !ok; ++i)
-                    for (int j = 0; j < 8 && !ok; ++j) {
-                        if (i == j) continue;
-                        if ((crc ^ synd[i + bo] ^ synd[j + bo]) == 0) {
-                            if (lane == (k & 63)) {
-                                const unsigned int flip = (1u << i) | (1u << j);
-                                if ((k >> 6) == 0) c[0] ^= flip;
-                                else if ((k >> 6) == 1) c[1] ^= flip;
-                                else if ((k >> 6) == 2) c[2] ^= flip;
-                                else c[3] ^= flip;
-                            }
-                            ok = true;
-                        }
+            // fixdberr (acars.c:66-90): the CRC bytes first, then text bytes in ascending order, bit pairs (i, j) in the loops' order
+            ok = __ballot(lane < 16 && synd[lane & 15] == crc) != 0;
+            for (int k0 = 0; k0 < len && !ok; k0 += 64) {
+                const int k = k0 + lane;
+                unsigned int flip = 0;
+                if (k < len) {
+                    const int bo = 8 * (len - k + 1);
+                    unsigned short sy[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) sy[i] = synd[i + bo];
+#pragma unroll
+                    for (int i = 7; i >= 0; --i)                           // (descending: the last assignment is the first pair of the loops)
+#pragma unroll
+                        for (int j = 7; j >= 0; --j)
+                            if (i != j && (unsigned short)(crc ^ sy[i] ^ sy[j]) == 0) flip = (1u << i) | (1u << j);
+                }
+                const unsigned long long hit = __ballot(flip != 0);
+                if (hit) {
+                    const int first = __ffsll((long long)hit) - 1;      // lowest lane = lowest k of this group
+                    if (lane == first) {
+                        if ((k >> 6) == 0) c[0] ^= flip;
+                        else if ((k >> 6) == 1) c[1] ^= flip;
+                        else if ((k >> 6) == 2) c[2] ^= flip;
+                        else c[3] ^= flip;
                     }
+                    ok = true;
+                }
             }
         }
         if (!ok) {
@@ -201,28 +210,36 @@ __global__ __launch_bounds__(64 * BLK_WAVES) void blk_repair_kernel(AcgFrameRec*
 
 // SURVEY 8f.4 -- the field split of outputmsg() (output.c:486-560,566-568,623-631, the build without libacars) on the
 // device: processed blocks [first, first + n) of the queue -> fixed binary records (AcgMsgRec == acg_msg, see
-// include/acarsdec_amd.h), one thread per block.  valid = 0 marks blocks the repair dropped (acars.c:124-207) and
+// include/acarsdec_amd.h), one WAVE per block.  valid = 0 marks blocks the repair dropped (acars.c:124-207) and
 // blocks the repair has not seen.  The level (a log10) is filled in on the host, like for acg_frame.
-__global__ __launch_bounds__(BLK_T) void msg_split_kernel(const AcgFrameRec* frames, unsigned int cap, unsigned int first, unsigned int n, AcgMsgRec* out)
+//
+// Round 4 gave every block one THREAD with a 336-byte LDS row (10.5 KiB per 32-thread workgroup) that moved the text byte by
+// byte.  Beside the down-converter (8 x 18 KiB of a CU's 160 KiB) and a demodulator workgroup (9 KiB) such a workgroup does not
+// FIT on most CUs: the trace of BASELINE configs[4] (profiles/r05_tails.md) has one launch in ten waiting ~1 ms for a
+// down-converter workgroup to retire -- and acg_collect_msgs waits for it.  Now: 336 bytes of LDS per block (1.3 KiB per
+// workgroup of four waves), the text moved by all 64 lanes at once, the record leaving as twenty 16-byte stores.
+#define SPLIT_WAVES 4
+__global__ __launch_bounds__(64 * SPLIT_WAVES) void msg_split_kernel(const AcgFrameRec* frames, unsigned int cap, unsigned int first, unsigned int n, AcgMsgRec* out)
 {
-    // The record is BUILT IN the thread's LDS row and leaves as twenty 16-byte stores (byte-wise stores of up to 240 text bytes
-    // per message into global memory took 0.9 ms per collect beside the streaming down-converter): the block's text is staged
-    // into row[0, 256), moved to its place in the record (row + 74: behind its source, so the move runs from the end), then the
-    // header goes over the start of the row -- whose bytes have been read into registers first.
-    static_assert(sizeof(AcgMsgRec) == 320 && offsetof(AcgMsgRec, txt) == 74 && offsetof(AcgMsgRec, valid) == 44, "record layout");
-    __shared__ __attribute__((aligned(16))) unsigned char rows[BLK_T * BLK_ROW];
-    const unsigned int q = blockIdx.x * BLK_T + threadIdx.x;
+    static_assert(sizeof(AcgMsgRec) == 320 && offsetof(AcgMsgRec, txt) == 74 && offsetof(AcgMsgRec, valid) == 44 &&
+                  offsetof(AcgMsgRec, soh_back) == 316, "record layout");
+    __shared__ __attribute__((aligned(16))) unsigned char rows[SPLIT_WAVES][BLK_ROW];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned int q = blockIdx.x * SPLIT_WAVES + wv;                   // wave-uniform
     if (q >= n) return;
-    const AcgFrameRec* f = frames + ((first + q) % cap);
-    unsigned char* t = rows + threadIdx.x * BLK_ROW;
+    const AcgFrameRec* f = frames + ((first + q) & (cap - 1));              // (cap is a power of two)
+    unsigned char* t = rows[wv];
     const int len = f->len;
-    const int chn = f->chn, err = f->err, bitcount = f->bitcount;
+    const int chn = f->chn, err = f->err, bitcount = f->bitcount, soh_back = f->soh_back;
     const long long end_bit = f->end_bit, end_sample = f->end_sample;
     const double lvlsum = f->lvlsum;
     const bool valid = f->status == 1 && len >= 13;
-    stage_text(f, t);
-    AcgMsgRec* m = (AcgMsgRec*)t;                                           // the record, in place (LDS)
-    // ---- the fields, read out of the text before anything is overwritten
+    // the block's text (256 bytes, 16-byte aligned in the ring) into the row: one 16-byte load per lane
+    if (lane < 16) ((uint4*)t)[lane] = ((const uint4*)f->txt)[lane];
+    // (LDS operations of one wave execute in order; the fences keep the compiler from moving them across each other)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- the fields, read out of the text before anything is overwritten (every lane the same: broadcast reads)
     char mode = 0, addr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ack = 0, label[3] = {0, 0, 0}, bid = 0, no[5] = {0, 0, 0, 0, 0}, fid[7] = {0, 0, 0, 0, 0, 0, 0};
     char bs = 0, be = 0, down = 0;
     int k = 0, tl = 0;
@@ -250,40 +267,56 @@ __global__ __launch_bounds__(BLK_T) void msg_split_kernel(const AcgFrameRec* fra
             if (tl < 0) tl = 0;
         }
     }
-    // ---- the text to its place (destination 74 + i lies behind source k + i: last byte first), the rest of the text area zeroed
-    for (int i = tl - 1; i >= 0; --i) t[74 + i] = t[k + i];
-    for (int i = 74 + tl; i < 320; ++i) t[i] = 0;
-    // ---- the header (every byte of the record is defined: nothing stale crosses the ABI)
-    m->chn = chn;
-    m->err = err;
-    m->lvl = 0.f;
-    m->txt_len = tl;
-    m->end_bit = end_bit;
-    m->end_sample = end_sample;
-    m->lvlsum = lvlsum;
-    m->bitcount = bitcount;
-    m->valid = valid ? 1 : 0;
-    m->mode = mode;
-    for (int i = 0; i < 8; ++i) m->addr[i] = addr[i];
-    m->ack = ack;
-    for (int i = 0; i < 3; ++i) m->label[i] = label[i];
-    m->bid = bid;
-    for (int i = 0; i < 5; ++i) m->no[i] = no[i];
-    for (int i = 0; i < 7; ++i) m->fid[i] = fid[i];
-    m->bs = bs;
-    m->be = be;
-    m->down = down;
-    // ---- out
-    uint4* dst = (uint4*)(out + q);
+    // ---- the text to its place: all of it is read (lane L: bytes L, L + 64, ...) before any of it is written; the rest of
+    // the text area is zeroed by the same stores (every byte of the record is defined: nothing stale crosses the ABI)
+    unsigned char mv[4];
 #pragma unroll
-    for (int j = 0; j < 20; ++j) dst[j] = ((const uint4*)t)[j];
+    for (int s_ = 0; s_ < 4; ++s_) {
+        const int i = lane + 64 * s_;
+        mv[s_] = i < tl ? t[k + i] : (unsigned char)0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+        const int i = lane + 64 * s_;
+        if (i < ACG_MSG_TXT) t[74 + i] = mv[s_];
+    }
+    // ---- the header
+    if (lane == 0) {
+        AcgMsgRec* m = (AcgMsgRec*)t;                                       // the record, in place (LDS)
+        m->chn = chn;
+        m->err = err;
+        m->lvl = 0.f;
+        m->txt_len = tl;
+        m->end_bit = end_bit;
+        m->end_sample = end_sample;
+        m->lvlsum = lvlsum;
+        m->bitcount = bitcount;
+        m->valid = valid ? 1 : 0;
+        m->mode = mode;
+        for (int i = 0; i < 8; ++i) m->addr[i] = addr[i];
+        m->ack = ack;
+        for (int i = 0; i < 3; ++i) m->label[i] = label[i];
+        m->bid = bid;
+        for (int i = 0; i < 5; ++i) m->no[i] = no[i];
+        for (int i = 0; i < 7; ++i) m->fid[i] = fid[i];
+        m->bs = bs;
+        m->be = be;
+        m->down = down;
+        m->soh_back = soh_back;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- out: twenty 16-byte stores
+    if (lane < 20) ((uint4*)(out + q))[lane] = ((const uint4*)t)[lane];
 }
 
 extern "C" int acg_launch_msg_split(const AcgFrameRec* frames, unsigned int cap, unsigned int first, unsigned int n,
                                     AcgMsgRec* out, void* stream)
 {
     if (n == 0) return 0;
-    hipLaunchKernelGGL(msg_split_kernel, dim3((n + BLK_T - 1) / BLK_T), dim3(BLK_T), 0, (hipStream_t)stream, frames, cap, first, n, out);
+    hipLaunchKernelGGL(msg_split_kernel, dim3((n + SPLIT_WAVES - 1) / SPLIT_WAVES), dim3(64 * SPLIT_WAVES), 0, (hipStream_t)stream, frames, cap, first, n, out);
     return (int)hipGetLastError();
 }
 

@@ -18,8 +18,12 @@
  * the framing FSM, needed because decodeAcars() writes MskDf/MskS back into the loop,
  * acars.c:242,259,274); every decided bit comes back as {soft symbol, level} and is replayed here
  * through the reference's putbit() arithmetic (msk.c:53-63,112-113) into the UNCHANGED
- * decodeAcars().  channel_t stays the state carrier exactly as in the reference: its MSK fields
- * are uploaded before and downloaded after every call.
+ * decodeAcars().  channel_t stays the state carrier exactly as in the reference: after every call
+ * the MSK fields of ALL channels come back in one transfer; before a call they go up (one
+ * transfer) only if the caller's channel_t no longer holds what the device has -- a host that
+ * re-initialised or edited a channel is honoured, the steady state pays nothing for it.
+ * dm_buffer (rtl.c:353) is copied back only on request (acarsdec_amd_compat_keep_dm): nothing in
+ * the reference reads it after demodMSK().
  *
  * There is no CPU fallback: if the GPU library fails the process exits like the reference does
  * on "Unable to init internal decoders" (acarsdec.c:456-459).
@@ -28,14 +32,56 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdint.h>
+#include <time.h>
 #include "acarsdec.h"
 #include "acarsdec_amd.h"
+#include "acarsdec_amd_compat.h"
 
 #define FLEN ((INTRATE / 1200) + 1)
+
+static int g_keep_dm;
+static double g_secs;
+static unsigned long g_calls;
+
+void acarsdec_amd_compat_keep_dm(int on) { g_keep_dm = on; }
+void acarsdec_amd_compat_stats(double *seconds, unsigned long *calls)
+{
+	if (seconds) *seconds = g_secs;
+	if (calls) *calls = g_calls;
+}
+
+static double now_s(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* ACARSDEC_AMD_STATS=1 in the environment: the time spent inside the legacy entry points is printed at exit (bench.py's
+ * rtl8 case reads it: ms per callback against the 81.92 ms a callback's signal lasts, rtl.c:49,213) */
+static void print_stats(void)
+{
+	if (g_calls)
+		fprintf(stderr, "acarsdec_amd compat: %lu calls, %.6f s inside the legacy entry points, %.4f ms per call\n",
+			g_calls, g_secs, 1e3 * g_secs / (double)g_calls);
+}
+static void account(double t0)
+{
+	static int hooked;
+	if (!hooked) {
+		const char *e = getenv("ACARSDEC_AMD_STATS");
+		hooked = 1;
+		if (e && *e && *e != '0')
+			atexit(print_stats);
+	}
+	g_secs += now_s() - t0;
+	g_calls++;
+}
 
 static acg_ctx *g_msk;          /* 1-channel context behind demodMSK() */
 static int g_msk_blocks;
 static acg_ctx *g_rtl;          /* nbch-channel context behind acarsdec_amd_in_callback() */
+static channel_t *g_msk_last;   /* the channel whose state the demodMSK() context holds */
 
 static void die(const char *what, acg_ctx *c, int rc)
 {
@@ -56,37 +102,61 @@ int initMsk(channel_t *ch)
 	return 0;
 }
 
-static void upload(acg_ctx *c, int slot, const channel_t *ch)
+/* what the device holds for the channels of one context, as of the last download: the upload is skipped while the caller's
+ * channel_t still says the same */
+typedef struct {
+	acg_chan_state st[MAXNBCHANNELS];
+	int valid;
+} shadow_t;
+
+static void pack(acg_chan_state *st, const channel_t *ch)
 {
-	acg_chan_state st;
-	int i, rc;
-	memset(&st, 0, sizeof(st));
-	st.MskPhi = ch->MskPhi; st.MskDf = ch->MskDf; st.MskLvlSum = ch->MskLvlSum;
-	st.MskClk = ch->MskClk; st.MskBitCount = ch->MskBitCount;
-	st.MskS = ch->MskS; st.idx = ch->idx;
+	int i;
+	memset(st, 0, sizeof(*st));
+	st->MskPhi = ch->MskPhi; st->MskDf = ch->MskDf; st->MskLvlSum = ch->MskLvlSum;
+	st->MskClk = ch->MskClk; st->MskBitCount = ch->MskBitCount;
+	st->MskS = ch->MskS; st->idx = ch->idx;
 	for (i = 0; i < FLEN; i++) {
-		st.inb[2 * i] = crealf(ch->inb[i]);
-		st.inb[2 * i + 1] = cimagf(ch->inb[i]);
+		st->inb[2 * i] = crealf(ch->inb[i]);
+		st->inb[2 * i + 1] = cimagf(ch->inb[i]);
 	}
-	st.outbits = ch->outbits; st.nbits = ch->nbits; st.Acarsstate = ch->Acarsstate;
-	st.blk_len = ch->blk ? ch->blk->len : 0;
-	st.blk_err = ch->blk ? ch->blk->err : 0;
-	if ((rc = acg_set_state(c, slot, &st)) != ACG_OK)
+	st->outbits = ch->outbits; st->nbits = ch->nbits; st->Acarsstate = ch->Acarsstate;
+	st->blk_len = ch->blk ? ch->blk->len : 0;
+	st->blk_err = ch->blk ? ch->blk->err : 0;
+}
+
+static shadow_t g_msk_sh, g_rtl_sh, g_front_sh;
+
+/* channels chs[0..n) -> device slots 0..n-1, one transfer, and only if anything differs from what the device has */
+static void upload_all(acg_ctx *c, shadow_t *sh, channel_t *const *chs, int n)
+{
+	acg_chan_state st[MAXNBCHANNELS];
+	int i, rc;
+	for (i = 0; i < n; i++)
+		pack(&st[i], chs[i]);
+	if (sh->valid && memcmp(st, sh->st, sizeof(st[0]) * (size_t)n) == 0)
+		return;
+	if ((rc = acg_set_state_n(c, 0, n, st)) != ACG_OK)
 		die("set_state", c, rc);
 }
 
-static void download(acg_ctx *c, int slot, channel_t *ch)
+/* the loop state lives on the device; the framing state was advanced by the replay through the real decodeAcars() and is
+ * already in *ch -- and it is what the device's mirror of the state machine has arrived at as well, which is why the shadow
+ * (the device's view) and the caller's channel_t agree before the next call */
+static void download_all(acg_ctx *c, shadow_t *sh, channel_t *const *chs, int n)
 {
-	acg_chan_state st;
-	int i, rc;
-	if ((rc = acg_get_state(c, slot, &st)) != ACG_OK)
+	int i, k, rc;
+	if ((rc = acg_get_state_n(c, 0, n, sh->st)) != ACG_OK)
 		die("get_state", c, rc);
-	/* the loop state lives on the device; the framing state was advanced by the replay below
-	 * through the real decodeAcars() and is already in *ch */
-	ch->MskPhi = st.MskPhi; ch->MskDf = st.MskDf; ch->MskClk = st.MskClk;
-	ch->MskS = st.MskS; ch->idx = st.idx;
-	for (i = 0; i < FLEN; i++)
-		ch->inb[i] = st.inb[2 * i] + st.inb[2 * i + 1] * I;
+	sh->valid = 1;
+	for (k = 0; k < n; k++) {
+		channel_t *ch = chs[k];
+		const acg_chan_state *st = &sh->st[k];
+		ch->MskPhi = st->MskPhi; ch->MskDf = st->MskDf; ch->MskClk = st->MskClk;
+		ch->MskS = st->MskS; ch->idx = st->idx;
+		for (i = 0; i < FLEN; i++)
+			ch->inb[i] = st->inb[2 * i] + st->inb[2 * i + 1] * I;
+	}
 }
 
 /* msk.c:112-113 + putbit() msk.c:53-63, on the caller's channel_t */
@@ -121,6 +191,7 @@ void demodMSK(channel_t *ch, int len)
 {
 	int rc;
 	channel_t *one[1];
+	const double t0 = now_s();
 
 	if (len <= 0)
 		return;
@@ -138,15 +209,20 @@ void demodMSK(channel_t *ch, int len)
 		cfg.max_lag = 1;                              /* drained after every call */
 		if ((rc = acg_create(&g_msk, &cfg)) != ACG_OK)
 			die("acg_create", NULL, rc);
+		g_msk_sh.valid = 0;
 	}
 	one[0] = ch;
-	upload(g_msk, 0, ch);
+	if (ch != g_msk_last)                                 /* the reference calls demodMSK() for one channel after the other */
+		g_msk_sh.valid = 0;
+	g_msk_last = ch;
+	upload_all(g_msk, &g_msk_sh, one, 1);
 	if ((rc = acg_process_dm_host(g_msk, ch->dm_buffer, (size_t)len, len)) != ACG_OK)
 		die("process_dm", g_msk, rc);
 	if ((rc = acg_replay_bits(g_msk, bit_sink, one)) != ACG_OK)
 		die("replay", g_msk, rc);
-	download(g_msk, 0, ch);
+	download_all(g_msk, &g_msk_sh, one, 1);
 	discard_device_blocks(g_msk);
+	account(t0);
 }
 
 #ifdef WITH_RTL
@@ -155,6 +231,7 @@ void acarsdec_amd_in_callback(unsigned char *rtlinbuff, uint32_t nread, void *ct
 	unsigned int n;
 	int rc;
 	channel_t *chs[MAXNBCHANNELS];
+	const double t0 = now_s();
 	(void)ctx;
 
 	if (nread != (uint32_t)(ACG_BLOCK * rtlMult * 2)) {          /* rtl.c:322-326 */
@@ -179,19 +256,20 @@ void acarsdec_amd_in_callback(unsigned char *rtlinbuff, uint32_t nread, void *ct
 			die("set_taps", g_rtl, rc);
 		free(taps);
 	}
-	for (n = 0; n < nbch; n++) {
+	for (n = 0; n < nbch; n++)
 		chs[n] = &channel[n];
-		upload(g_rtl, (int)n, &channel[n]);
-	}
+	upload_all(g_rtl, &g_rtl_sh, chs, (int)nbch);
 	if ((rc = acg_process_iq_u8_host(g_rtl, rtlinbuff, (size_t)nread, 1)) != ACG_OK)
 		die("process_iq", g_rtl, rc);
-	for (n = 0; n < nbch; n++)                                   /* rtl.c:353: dm_buffer stays observable */
-		acg_read_dm(g_rtl, (int)n, channel[n].dm_buffer, ACG_BLOCK);
+	if (g_keep_dm)                                               /* rtl.c:353: dm_buffer observable on request */
+		for (n = 0; n < nbch; n++)
+			if ((rc = acg_read_dm(g_rtl, (int)n, channel[n].dm_buffer, ACG_BLOCK)) != ACG_OK)
+				die("read_dm", g_rtl, rc);
 	if ((rc = acg_replay_bits(g_rtl, bit_sink, chs)) != ACG_OK)       /* rtl.c:357-360 order */
 		die("replay", g_rtl, rc);
-	for (n = 0; n < nbch; n++)
-		download(g_rtl, (int)n, &channel[n]);
+	download_all(g_rtl, &g_rtl_sh, chs, (int)nbch);
 	discard_device_blocks(g_rtl);
+	account(t0);
 }
 #endif
 
@@ -215,6 +293,7 @@ void acarsdec_amd_soapy_samples(const int16_t *iq, int nsamples)
 	unsigned int n;
 	int rc;
 	channel_t *chs[MAXNBCHANNELS];
+	const double t0 = now_s();
 
 	if (nsamples <= 0)
 		return;
@@ -241,20 +320,20 @@ void acarsdec_amd_soapy_samples(const int16_t *iq, int nsamples)
 		if ((rc = acg_feed_samples_host(g_soapy, ACG_FMT_CS16, iq, NULL, 0, (size_t)nsamples)) != ACG_OK)
 			die("feed_samples", g_soapy, rc);
 		g_soapy_carry += (size_t)nsamples;
+		account(t0);
 		return;
 	}
-	for (n = 0; n < nbch; n++) {
+	for (n = 0; n < nbch; n++)
 		chs[n] = &channel[n];
-		upload(g_soapy, (int)n, &channel[n]);
-	}
+	upload_all(g_soapy, &g_front_sh, chs, (int)nbch);
 	if ((rc = acg_feed_samples_host(g_soapy, ACG_FMT_CS16, iq, NULL, 0, (size_t)nsamples)) != ACG_OK)
 		die("feed_samples", g_soapy, rc);
 	g_soapy_carry = (g_soapy_carry + (size_t)nsamples) % (size_t)rateMult;
 	if ((rc = acg_replay_bits(g_soapy, bit_sink, chs)) != ACG_OK)           /* channel order, as soapy.c:231 iterates */
 		die("replay", g_soapy, rc);
-	for (n = 0; n < nbch; n++)
-		download(g_soapy, (int)n, &channel[n]);
+	download_all(g_soapy, &g_front_sh, chs, (int)nbch);
 	discard_device_blocks(g_soapy);
+	account(t0);
 }
 #endif
 
@@ -268,6 +347,7 @@ static void fe_samples(int fmt, const void *p0, const void *p1, int nsamples, in
 	unsigned int n;
 	int rc;
 	channel_t *chs[MAXNBCHANNELS];
+	const double t0 = now_s();
 
 	if (nsamples <= 0)
 		return;
@@ -293,20 +373,20 @@ static void fe_samples(int fmt, const void *p0, const void *p1, int nsamples, in
 		if ((rc = acg_feed_samples_host(g_fe, fmt, p0, p1, 0, (size_t)nsamples)) != ACG_OK)
 			die("feed_samples", g_fe, rc);
 		g_fe_carry += (size_t)nsamples;
+		account(t0);
 		return;
 	}
-	for (n = 0; n < nbch; n++) {
+	for (n = 0; n < nbch; n++)
 		chs[n] = &channel[n];
-		upload(g_fe, (int)n, &channel[n]);
-	}
+	upload_all(g_fe, &g_front_sh, chs, (int)nbch);
 	if ((rc = acg_feed_samples_host(g_fe, fmt, p0, p1, 0, (size_t)nsamples)) != ACG_OK)
 		die("feed_samples", g_fe, rc);
 	g_fe_carry = (g_fe_carry + (size_t)nsamples) % (size_t)mult;
 	if ((rc = acg_replay_bits(g_fe, bit_sink, chs)) != ACG_OK)
 		die("replay", g_fe, rc);
-	for (n = 0; n < nbch; n++)
-		download(g_fe, (int)n, &channel[n]);
+	download_all(g_fe, &g_front_sh, chs, (int)nbch);
 	discard_device_blocks(g_fe);
+	account(t0);
 }
 #endif
 

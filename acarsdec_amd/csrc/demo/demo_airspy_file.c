@@ -4,10 +4,9 @@
  * path (stub header: oracle/stub/libairspy/airspy.h).  Transfers have RAGGED sizes (never a whole number of decimation windows), so
  * the carry of air.c:299-338 (`ind`, ch->D) is exercised at every callback.
  *
- * Built twice:
- *   plain                   -> transfers go to the callback air.c passes (its own rx_callback): CPU      (_ref/acarsdec_cpu_air)
- *   -DUSE_AMD_RX_CALLBACK   -> transfers go to acarsdec_amd_air_samples() from compat_msk.c: this stands for the one-line
- *                              change in rx_callback without touching the reference source (lib/acarsdec_gpu_air)
+ * It knows nothing about the GPU: every transfer goes to the callback air.c registers -- the reference's own rx_callback in the
+ * CPU twin (oracle/_ref/acarsdec_cpu_air), the bound one in lib/acarsdec_gpu_air, whose air.c carries the one hunk of
+ * INTEGRATION.md (applied to the reference's text at build time, acarsdec_amd/_build.py patched_source).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -15,10 +14,6 @@
 #include <stdint.h>
 #include <pthread.h>
 #include <libairspy/airspy.h>
-
-#ifdef USE_AMD_RX_CALLBACK
-void acarsdec_amd_air_samples(const float *samples, int count, int airmult);
-#endif
 
 static uint32_t g_rate;
 static volatile int g_streaming;
@@ -75,11 +70,7 @@ static void *player(void *arg)
 		t.samples = buf;
 		t.sample_count = (int)got;
 		t.sample_type = AIRSPY_SAMPLE_FLOAT32_REAL;
-#ifdef USE_AMD_RX_CALLBACK
-		acarsdec_amd_air_samples(buf, (int)got, (int)(rate() / 12500u));
-#else
 		g_cb(&t);
-#endif
 	}
 	if (f) fclose(f);
 	free(buf);

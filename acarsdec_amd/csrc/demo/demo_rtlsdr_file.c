@@ -2,20 +2,15 @@
  * demo_rtlsdr_file.c -- a "dongle" that plays a file of interleaved u8 I/Q (env ACARSDEC_IQ_FILE)
  * through the reference's UNCHANGED rtl.c, for the end-to-end drop-in demo of the RTL path.
  *
- * Built twice:
- *   plain                  -> buffers go to the callback rtl.c passes (its own in_callback): CPU
- *   -DUSE_AMD_IN_CALLBACK  -> buffers go to acarsdec_amd_in_callback() from compat_msk.c: this
- *                             stands for the one-line change at rtl.c:364
- *                             without touching the reference source.
+ * It knows nothing about the GPU: every buffer goes to the callback rtl.c hands to
+ * rtlsdr_read_async() -- the reference's own in_callback in the CPU twin (oracle/_ref/acarsdec_cpu_rtl),
+ * the bound callback in lib/acarsdec_gpu_rtl, whose rtl.c carries the one hunk of INTEGRATION.md
+ * (applied to the reference's text at build time, acarsdec_amd/_build.py patched_source).
  */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include "rtl-sdr.h"
-
-#ifdef USE_AMD_IN_CALLBACK
-void acarsdec_amd_in_callback(unsigned char *buf, uint32_t nread, void *ctx);
-#endif
 
 static int g_dev;
 static volatile int g_cancel;
@@ -53,12 +48,7 @@ int rtlsdr_read_async(rtlsdr_dev_t *dev, rtlsdr_read_async_cb_t cb, void *ctx, u
 		return -1;
 	}
 	while (!g_cancel && fread(buf, 1, buf_len, f) == buf_len) {
-#ifdef USE_AMD_IN_CALLBACK
-		(void)cb;
-		acarsdec_amd_in_callback(buf, buf_len, ctx);
-#else
 		cb(buf, buf_len, ctx);
-#endif
 	}
 	fclose(f);
 	free(buf);

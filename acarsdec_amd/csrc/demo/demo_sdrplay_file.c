@@ -5,9 +5,9 @@
  * The reference's runSdrplaySample() never returns (`while (1) sleep(2)`, sdrplay.c:284-285): the player ends the process at end of
  * file, after giving the block thread a moment to print what is queued.
  *
- * Built twice:
- *   plain                      -> packets go to the callback sdrplay.c passes (its own myStreamCallback): CPU   (_ref/acarsdec_cpu_sdrplay)
- *   -DUSE_AMD_STREAM_CALLBACK  -> packets go to acarsdec_amd_sdrplay_samples() from compat_msk.c           (lib/acarsdec_gpu_sdrplay)
+ * It knows nothing about the GPU: every packet goes to the callback sdrplay.c registers -- the reference's own myStreamCallback in
+ * the CPU twin (oracle/_ref/acarsdec_cpu_sdrplay), the bound one in lib/acarsdec_gpu_sdrplay, whose sdrplay.c carries the one hunk
+ * of INTEGRATION.md (applied to the reference's text at build time, acarsdec_amd/_build.py patched_source).
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -16,10 +16,6 @@
 #include <unistd.h>
 #include <pthread.h>
 #include <mirsdrapi-rsp.h>
-
-#ifdef USE_AMD_STREAM_CALLBACK
-void acarsdec_amd_sdrplay_samples(const int16_t *xi, const int16_t *xq, int nsamples);
-#endif
 
 static mir_sdr_StreamCallback_t g_cb;
 static pthread_t g_thread;
@@ -59,11 +55,7 @@ static void *player(void *arg)
 		if (got == 0)
 			break;
 		for (i = 0; i < got; i++) { xi[i] = pair[2 * i]; xq[i] = pair[2 * i + 1]; }
-#ifdef USE_AMD_STREAM_CALLBACK
-		acarsdec_amd_sdrplay_samples(xi, xq, (int)got);
-#else
 		g_cb(xi, xq, first, 0, 0, 0, (unsigned int)got, 0, 0, NULL);
-#endif
 		first += (unsigned int)got;
 	}
 	usleep(500 * 1000);                           /* the block thread prints what is queued (acars.c:93-215) */

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
     L.phi = st->phi; L.df = st->df; L.lvlsum = st->lvlsum;
     L.clk = st->clk; L.bitcount = st->bitcount; L.S = st->S; L.idx = st->idx;
     L.nbits = st->nbits; L.astate = st->astate; L.blen = st->blen; L.berr = st->berr;
-    L.outbits = st->outbits; L.crc0 = st->crc0; L.nbit_total = st->nbit_total;
+    L.outbits = st->outbits; L.crc0 = st->crc0; L.nbit_total = st->nbit_total; L.soh = st->soh32;
     const long long samp0 = st->nsamp_total;
     if (leader) {
 #pragma unroll
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
         st->phi = p; st->df = L.df; st->lvlsum = L.lvlsum;
         st->clk = L.clk; st->bitcount = L.bitcount; st->S = L.S; st->idx = idx;
         st->nbits = L.nbits; st->astate = L.astate; st->blen = L.blen; st->berr = L.berr;
-        st->outbits = L.outbits; st->crc0 = L.crc0; st->nbit_total = L.nbit_total;
+        st->outbits = L.outbits; st->crc0 = L.crc0; st->nbit_total = L.nbit_total; st->soh32 = L.soh;
         st->nsamp_total = samp0 + len;
 #pragma unroll
         for (int j = 0; j < FLEN; ++j) {

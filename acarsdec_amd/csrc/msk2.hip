@@ -62,7 +62,7 @@ struct alignas(8) HState {
     int bitcount;
     unsigned int S;
     int nbits, astate, blen, berr;
-    unsigned int outbits, crc0;
+    unsigned int outbits, crc0, soh;
     int nb;
 };
 
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(128 * PAIRS) void msk_demod2_kernel(const MskArgs a
         {
             const HState& h = P.hst[slot];
             L.phi = p; L.df = df; L.lvlsum = h.lvlsum; L.clk = h.clk; L.bitcount = h.bitcount; L.S = h.S; L.idx = idx;
-            L.nbits = h.nbits; L.astate = h.astate; L.blen = h.blen; L.berr = h.berr; L.outbits = h.outbits; L.crc0 = h.crc0;
+            L.nbits = h.nbits; L.astate = h.astate; L.blen = h.blen; L.berr = h.berr; L.outbits = h.outbits; L.crc0 = h.crc0; L.soh = h.soh;
             L.nbit_total = h.nbit_total;
         }
         int nb = P.hst[slot].nb;
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(128 * PAIRS) void msk_demod2_kernel(const MskArgs a
             st->phi = p; st->df = L.df; st->lvlsum = L.lvlsum;
             st->clk = L.clk; st->bitcount = L.bitcount; st->S = L.S; st->idx = idx;
             st->nbits = L.nbits; st->astate = L.astate; st->blen = L.blen; st->berr = L.berr;
-            st->outbits = L.outbits; st->crc0 = L.crc0; st->nbit_total = L.nbit_total;
+            st->outbits = L.outbits; st->crc0 = L.crc0; st->nbit_total = L.nbit_total; st->soh32 = L.soh;
             st->nsamp_total = samp0 + len;
 #pragma unroll
             for (int j = 0; j < FLEN; ++j) {
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(128 * PAIRS) void msk_demod2_kernel(const MskArgs a
         L.phi = 0; L.df = st->df; L.lvlsum = st->lvlsum;
         L.clk = st->clk; L.bitcount = st->bitcount; L.S = st->S; L.idx = 0;
         L.nbits = st->nbits; L.astate = st->astate; L.blen = st->blen; L.berr = st->berr;
-        L.outbits = st->outbits; L.crc0 = st->crc0; L.nbit_total = st->nbit_total;
+        L.outbits = st->outbits; L.crc0 = st->crc0; L.nbit_total = st->nbit_total; L.soh = st->soh32;
         float2* bits = a.bits ? a.bits + (size_t)chc * a.bit_cap : (float2*)(txt + 248);     // (no bit log: scratch slot, see msk.hip)
         const int bit_cap = a.bits ? a.bit_cap : 1;
         int nb = (a.bit_append && active) ? a.nbits_out[ch] : 0;
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(128 * PAIRS) void msk_demod2_kernel(const MskArgs a
         if (leader) {
             HState& h = P.hst[slot];
             h.lvlsum = L.lvlsum; h.nbit_total = L.nbit_total; h.clk = L.clk; h.bitcount = L.bitcount; h.S = L.S;
-            h.nbits = L.nbits; h.astate = L.astate; h.blen = L.blen; h.berr = L.berr; h.outbits = L.outbits; h.crc0 = L.crc0;
+            h.nbits = L.nbits; h.astate = L.astate; h.blen = L.blen; h.berr = L.berr; h.outbits = L.outbits; h.crc0 = L.crc0; h.soh = L.soh;
             h.nb = nb;
         }
         __syncthreads();                                                   // T1

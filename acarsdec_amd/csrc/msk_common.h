@@ -29,6 +29,7 @@ struct Lane {
     unsigned int S, idx;
     int nbits, astate, blen, berr;
     unsigned int outbits, crc0;
+    unsigned int soh;           // low 32 bits of the 12.5 kHz sample index at which the block's SOH byte completed
     long long nbit_total;
 };
 
@@ -47,7 +48,7 @@ __device__ __forceinline__ void put_frame(Lane& L, const MskArgs& a, int ch, uns
     // the queue is a ring with a monotonic counter: the host consumes behind it (acg_collect_frames)
     if (leader) {
         const unsigned int slot = atomicAdd(a.frame_count, 1u);
-        AcgFrameRec* f = a.frames + (slot % a.frame_cap);
+        AcgFrameRec* f = a.frames + (slot & (a.frame_cap - 1));   // frame_cap is a power of two: consistent across the counter's wrap
         f->chn = ch;
         f->len = L.blen;
         f->err = L.berr;
@@ -58,6 +59,10 @@ __device__ __forceinline__ void put_frame(Lane& L, const MskArgs& a, int ch, uns
         f->crc[0] = (unsigned char)L.crc0;
         f->crc[1] = crc1;
         f->status = 0;
+        f->pad[0] = 0;
+        // where the reference stamps the block's time: at its SOH (acars.c:290 gettimeofday(&blk->tv)), as a distance back from
+        // the closing bit (a block is < 2^16 samples long: the 32-bit difference is exact across the index's wrap)
+        f->soh_back = (int)((unsigned int)sample_index - L.soh);
         const uint4* s = (const uint4*)txt;
         uint4* d = (uint4*)f->txt;
         const int nv = (L.blen + 15) >> 4;
@@ -90,6 +95,7 @@ __device__ __forceinline__ void decode_acars(Lane& L, const MskArgs& a, int ch, 
             L.nbits = 8;
             L.lvlsum = 0;
             L.bitcount = 0;
+            L.soh = (unsigned int)sample_index;                    // acars.c:290: the block's time stamp is taken here
             return;
         }
         reset_acars(L);

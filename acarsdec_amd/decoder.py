@@ -13,9 +13,10 @@ import numpy as np
 from . import _capi as K
 
 
-def _chk(ctx, rc, allow=()):
+def _chk(ctx, rc, allow=(), lib=None):
+    """lib = the library that owns ctx (a lab-build context must not be handed to the product library's acg_last_error)"""
     if rc != K.OK and rc not in allow:
-        msg = K.load().acg_last_error(ctx).decode() if ctx else ""
+        msg = (lib or K.load()).acg_last_error(ctx).decode() if ctx else ""
         raise K.AcgError(rc, msg)
     return rc
 
@@ -82,6 +83,9 @@ class Decoder:
         self.max_lag = self.L.acg_max_lag(self.ctx)
         self.Fc = None
 
+    def _chk(self, rc, allow=()):
+        return _chk(self.ctx, rc, allow, self.L)
+
     def close(self):
         if self.ctx:
             self.L.acg_destroy(self.ctx)
@@ -95,16 +99,16 @@ class Decoder:
 
     # ---- set-up -------------------------------------------------------------------------
     def reset(self):
-        _chk(self.ctx, self.L.acg_reset(self.ctx))
+        self._chk(self.L.acg_reset(self.ctx))
 
     def set_taps(self, taps, ch0=0):
         taps = np.ascontiguousarray(taps, dtype=np.float32).reshape(-1, self.ntaps, 2)
-        _chk(self.ctx, self.L.acg_set_taps(self.ctx, ch0, taps.shape[0], taps.ctypes.data))
+        self._chk(self.L.acg_set_taps(self.ctx, ch0, taps.shape[0], taps.ctypes.data))
 
     def set_channel_streams(self, stream_of):
         a = np.ascontiguousarray(stream_of, dtype=np.int32)
         assert a.size == self.nch
-        _chk(self.ctx, self.L.acg_set_channel_streams(self.ctx, a.ctypes.data))
+        self._chk(self.L.acg_set_channel_streams(self.ctx, a.ctypes.data))
 
     def init_rtl(self, freqs_mhz):
         """One dongle, nch channels sharing its stream: rtl.c:243-287.  Returns Fc."""
@@ -139,9 +143,9 @@ class Decoder:
         nblocks = nblocks or nbytes_row // row
         p, dev = self._ptr(iq)
         if dev:
-            _chk(self.ctx, self.L.acg_process_iq_u8_dev(self.ctx, p, pitch, nblocks, stream))
+            self._chk(self.L.acg_process_iq_u8_dev(self.ctx, p, pitch, nblocks, stream))
         else:
-            _chk(self.ctx, self.L.acg_process_iq_u8_host(self.ctx, p, pitch, nblocks))
+            self._chk(self.L.acg_process_iq_u8_host(self.ctx, p, pitch, nblocks))
 
     def feed(self, fmt, samples, q_plane=None):
         """Host samples of any length (the SDR drivers' shape): [nstreams, n] int16 pairs / planes / float32."""
@@ -155,35 +159,35 @@ class Decoder:
         else:
             a = np.ascontiguousarray(samples, dtype=np.float32).reshape(self.nstreams, -1)
             n, pitch = a.shape[1], a.shape[1]
-        _chk(self.ctx, self.L.acg_feed_samples_host(self.ctx, fmt, a.ctypes.data,
+        self._chk(self.L.acg_feed_samples_host(self.ctx, fmt, a.ctypes.data,
                                                      q_plane.ctypes.data if q_plane is not None else None, pitch, n))
 
     def process_samples(self, fmt, dev_tensor, nblocks, pitch, plane=0, stream=None):
-        _chk(self.ctx, self.L.acg_process_samples_dev(self.ctx, fmt, dev_tensor.data_ptr(), pitch, plane, nblocks, stream))
+        self._chk(self.L.acg_process_samples_dev(self.ctx, fmt, dev_tensor.data_ptr(), pitch, plane, nblocks, stream))
 
     def fir_only(self, iq_dev, nblocks, pitch, stream=None):
-        _chk(self.ctx, self.L.acg_fir_only_dev(self.ctx, iq_dev.data_ptr(), pitch, nblocks, stream))
+        self._chk(self.L.acg_fir_only_dev(self.ctx, iq_dev.data_ptr(), pitch, nblocks, stream))
 
     def placement_trial(self, iq_dev, nblocks, pitch, repeats=2, stream=None):
         """ms per in_callback-sized call on this decoder's placement (acg_placement_trial); the decoder comes back reset."""
         ms = C.c_double(0)
-        _chk(self.ctx, self.L.acg_placement_trial(self.ctx, iq_dev.data_ptr(), pitch, nblocks, repeats, stream, C.byref(ms)))
+        self._chk(self.L.acg_placement_trial(self.ctx, iq_dev.data_ptr(), pitch, nblocks, repeats, stream, C.byref(ms)))
         return ms.value
 
     def placement_trial_samples(self, fmt, dev_tensor, nblocks, pitch, plane=0, repeats=2, stream=None):
         """the same for a sample-format input (acg_placement_trial_samples)"""
         ms = C.c_double(0)
-        _chk(self.ctx, self.L.acg_placement_trial_samples(self.ctx, fmt, dev_tensor.data_ptr(), pitch, plane, nblocks, repeats, stream, C.byref(ms)))
+        self._chk(self.L.acg_placement_trial_samples(self.ctx, fmt, dev_tensor.data_ptr(), pitch, plane, nblocks, repeats, stream, C.byref(ms)))
         return ms.value
 
     def demod_msk(self, dm):
         """demodMSK() for all channels from 12.5 kHz samples: dm float32 [nch, len]."""
         dm = np.ascontiguousarray(dm, dtype=np.float32)
         dm = dm.reshape(self.nch, dm.size // self.nch)
-        _chk(self.ctx, self.L.acg_process_dm_host(self.ctx, dm.ctypes.data, dm.shape[1], dm.shape[1]))
+        self._chk(self.L.acg_process_dm_host(self.ctx, dm.ctypes.data, dm.shape[1], dm.shape[1]))
 
     def sync(self):
-        _chk(self.ctx, self.L.acg_sync(self.ctx))
+        self._chk(self.L.acg_sync(self.ctx))
 
     # ---- results ------------------------------------------------------------------------
     def drain_frames(self, max_frames=4096):
@@ -196,11 +200,12 @@ class Decoder:
                 return out
 
     def _frames_call(self, fn, max_frames, *lead):
+        max_frames = max(1, int(max_frames))          # (a zero-length buffer would make every EAGAIN loop spin without progress)
         if getattr(self, "_fbuf_cap", 0) < max_frames:
             self._fbuf = (K.Frame * max_frames)()
             self._fbuf_cap = max_frames
         n = C.c_int(0)
-        rc = _chk(self.ctx, fn(self.ctx, *lead, self._fbuf, self._fbuf_cap, C.byref(n)), allow=(K.EAGAIN,))
+        rc = self._chk(fn(self.ctx, *lead, self._fbuf, self._fbuf_cap, C.byref(n)), allow=(K.EAGAIN,))
         return n.value, self._fbuf, rc == K.EAGAIN
 
     def drain_frames_raw(self, max_frames=4096):
@@ -229,7 +234,7 @@ class Decoder:
         out = []
         while True:
             n = C.c_int(0)
-            rc = _chk(self.ctx, self.L.acg_drain_msgs(self.ctx, buf, self._mbuf_cap, C.byref(n)), allow=(K.EAGAIN,))
+            rc = self._chk(self.L.acg_drain_msgs(self.ctx, buf, self._mbuf_cap, C.byref(n)), allow=(K.EAGAIN,))
             out += [K.Msg.from_buffer_copy(buf[i]) for i in range(n.value)]
             if rc == K.OK:
                 return out
@@ -238,7 +243,7 @@ class Decoder:
         """(count, ctypes array, more): one acg_drain_msgs call, no per-message Python objects"""
         buf = self._msg_buf(max(1, max_msgs))
         n = C.c_int(0)
-        rc = _chk(self.ctx, self.L.acg_drain_msgs(self.ctx, buf, self._mbuf_cap, C.byref(n)), allow=(K.EAGAIN,))
+        rc = self._chk(self.L.acg_drain_msgs(self.ctx, buf, self._mbuf_cap, C.byref(n)), allow=(K.EAGAIN,))
         return n.value, buf, rc == K.EAGAIN
 
     def collect_msgs_raw(self, lag=1, max_msgs=4096):
@@ -246,7 +251,7 @@ class Decoder:
         is True when the buffer was too small and the rest stays queued for the next collect (nothing is lost)."""
         buf = self._msg_buf(max(1, max_msgs))
         n = C.c_int(0)
-        rc = _chk(self.ctx, self.L.acg_collect_msgs(self.ctx, lag, buf, self._mbuf_cap, C.byref(n)), allow=(K.EAGAIN,))
+        rc = self._chk(self.L.acg_collect_msgs(self.ctx, lag, buf, self._mbuf_cap, C.byref(n)), allow=(K.EAGAIN,))
         return n.value, buf, rc == K.EAGAIN
 
     def collect_msgs(self, lag=1, max_msgs=4096):
@@ -262,24 +267,24 @@ class Decoder:
         vo = np.zeros(self.bit_cap, dtype=np.float32)
         lvl = np.zeros(self.bit_cap, dtype=np.float32)
         n = C.c_int(0)
-        _chk(self.ctx, self.L.acg_read_bits(self.ctx, ch, vo.ctypes.data, lvl.ctypes.data, self.bit_cap, C.byref(n)))
+        self._chk(self.L.acg_read_bits(self.ctx, ch, vo.ctypes.data, lvl.ctypes.data, self.bit_cap, C.byref(n)))
         return vo[: n.value].copy(), lvl[: n.value].copy()
 
     def bits_all(self):
         counts = np.zeros(self.nch, dtype=np.int32)
         vo = np.zeros((self.nch, self.bit_cap), dtype=np.float32)
         lvl = np.zeros((self.nch, self.bit_cap), dtype=np.float32)
-        _chk(self.ctx, self.L.acg_read_bits_all(self.ctx, counts.ctypes.data, vo.ctypes.data, lvl.ctypes.data))
+        self._chk(self.L.acg_read_bits_all(self.ctx, counts.ctypes.data, vo.ctypes.data, lvl.ctypes.data))
         return counts, vo, lvl
 
     def dm(self, ch, n):
         out = np.zeros(n, dtype=np.float32)
-        _chk(self.ctx, self.L.acg_read_dm(self.ctx, ch, out.ctypes.data, n))
+        self._chk(self.L.acg_read_dm(self.ctx, ch, out.ctypes.data, n))
         return out
 
     def state(self, ch):
         s = K.ChanState()
-        _chk(self.ctx, self.L.acg_get_state(self.ctx, ch, C.byref(s)))
+        self._chk(self.L.acg_get_state(self.ctx, ch, C.byref(s)))
         return dict(MskPhi=s.MskPhi, MskDf=s.MskDf, MskClk=s.MskClk, MskLvlSum=s.MskLvlSum,
                     MskBitCount=s.MskBitCount, MskS=s.MskS, idx=s.idx,
                     inb=np.array(s.inb[:], dtype=np.float32), outbits=s.outbits, nbits=s.nbits,
@@ -287,12 +292,12 @@ class Decoder:
 
     def set_timing(self, mode):
         """0 = off, 1 = both stages, 2 = down-converter launches only."""
-        _chk(self.ctx, self.L.acg_set_timing(self.ctx, int(mode)))
+        self._chk(self.L.acg_set_timing(self.ctx, int(mode)))
 
     def timing(self):
         f, m = C.c_double(0), C.c_double(0)
         nf, nm = C.c_int(0), C.c_int(0)
-        _chk(self.ctx, self.L.acg_get_timing(self.ctx, C.byref(f), C.byref(nf), C.byref(m), C.byref(nm)))
+        self._chk(self.L.acg_get_timing(self.ctx, C.byref(f), C.byref(nf), C.byref(m), C.byref(nm)))
         return dict(fir_ms=f.value, fir_launches=nf.value, msk_ms=m.value, msk_launches=nm.value)
 
 

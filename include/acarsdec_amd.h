@@ -12,10 +12,12 @@
  * SDR callback thread, rtl.c:363-364).
  *
  * Two layers:
- *   1. batched API (acg_*): thousands of channels per GPU, state resident in HBM across calls;
- *   2. legacy view (compat_msk.c, built inside the reference tree): initMsk()/demodMSK() with
- *      the reference's own signatures (acarsdec.h:190-191) on top of (1), so acars.c/output.c
- *      link unchanged.  See INTEGRATION.md.
+ *   1. batched API (acg_*, this header): thousands of channels per GPU, state resident in HBM across calls;
+ *   2. legacy view (compat_msk.c, built inside the reference tree; entry points: acarsdec_amd_compat.h):
+ *      initMsk()/demodMSK() with the reference's own signatures (acarsdec.h:190-191) on top of (1), so
+ *      acars.c/output.c link unchanged.  See INTEGRATION.md.
+ * Measurement and diagnostic entry points (tuning switches, probes, self tests, generators) are NOT product API: they are
+ * declared in acarsdec_amd_lab.h.  The shared library exports exactly what these three headers declare.
  */
 #ifndef ACARSDEC_AMD_H
 #define ACARSDEC_AMD_H
@@ -33,7 +35,9 @@ extern "C" {
 #define ACG_EHIP       -3   /* HIP runtime error (acg_last_error has the text) */
 #define ACG_ENODEV     -4   /* no usable GPU: the library has NO CPU fallback */
 #define ACG_EOVERFLOW  -5   /* results were LOST: the device lapped the block queue (the host collected too rarely), or a per-bit
-                               log was longer than its buffer; what could be handed out has been */
+                               log was longer than its buffer; what could be handed out has been.  From acg_drain_* /
+                               acg_collect_* it reports the loss ONCE and may still leave blocks queued (the caller's buffer was
+                               smaller than what survived): call again -- the next call returns ACG_OK or ACG_EAGAIN */
 #define ACG_ESTATE     -6   /* call sequence error */
 #define ACG_EAGAIN     -7   /* drain/collect: the caller's buffer is full and more results are queued -- nothing is lost,
                                call again */
@@ -101,7 +105,13 @@ typedef struct {
 	unsigned char crc[2];
 	unsigned char txt[ACG_TXTMAX];
 	long long end_bit;            /* per-channel index of the bit that completed the block */
-	long long end_sample;         /* per-channel 12.5 kHz sample index of that bit (replaces tv) */
+	long long end_sample;         /* per-channel 12.5 kHz sample index of that bit */
+	long long soh_sample;         /* per-channel 12.5 kHz sample index of the bit that completed the block's SOH byte: the
+	                                 moment the reference stamps blk->tv (acars.c:290 gettimeofday), which every printer and
+	                                 JSON sink reports (output.c:162,227,244,361).  Epoch rule: a host that noted the wall
+	                                 clock t0 of the channel's first sample since acg_reset sets
+	                                     tv = t0 + soh_sample / 12500 s
+	                                 (INTEGRATION.md "time stamps"); soh_sample <= end_sample, both count from acg_reset */
 } acg_frame;
 
 /* A message as outputmsg() splits it out of a processed block (acarsmsg_t, acarsdec.h:108-124; output.c:486-560,
@@ -115,7 +125,7 @@ typedef struct {
 	float lvl;                    /* dB, acars.c:351 */
 	int txt_len;
 	long long end_bit, end_sample;   /* as in acg_frame */
-	double reserved0;
+	long long soh_sample;         /* as in acg_frame: where blk->tv is taken (acars.c:290); msg->tv = t0 + soh_sample / 12500 s */
 	int reserved1;
 	char reserved2;
 	char mode;
@@ -128,6 +138,7 @@ typedef struct {
 	char bs, be;                  /* start / end of text characters (STX or ETX / ETX or ETB) */
 	char down;
 	char txt[ACG_MSGTXTMAX];
+	int reserved3;
 } acg_msg;
 
 /* ---- lifetime ---------------------------------------------------------------------------- */
@@ -175,17 +186,6 @@ int  acg_process_dm_host(acg_ctx *ctx, const float *dm_host, size_t pitch_floats
 int  acg_fir_only_dev(acg_ctx *ctx, const uint8_t *iq_dev, size_t pitch_bytes, int nblocks,
 		      void *hip_stream);
 int  acg_sync(acg_ctx *ctx);
-/* Diagnostic: times a context on a sample of the caller's input.  Runs one untimed and `repeats` timed acg_process_iq_u8_dev
- * calls back to back (host clock around a device sync), reports the mean in *ms_per_call, and returns the context to its reset
- * state (acg_reset: channel state, queues).  Rounds 2-3 used it to pick the fastest of several contexts; round 4 found that
- * contexts timed for >= 0.25 s of streaming calls agree to 2 % and that what a short trial sees between them is mostly the
- * trial (profiles/LEDGER.md): a host creates ONE context per device and uses it.  The reference has no counterpart. */
-int  acg_placement_trial(acg_ctx *ctx, const uint8_t *iq_dev, size_t pitch_bytes, int nblocks, int repeats,
-			 void *hip_stream, double *ms_per_call);
-
-/* the same for the acg_process_samples_dev formats (declared below) */
-int  acg_placement_trial_samples(acg_ctx *ctx, int fmt, const void *dev, size_t pitch_bytes, size_t plane_bytes, int nblocks,
-				 int repeats, void *hip_stream, double *ms_per_call);
 
 /* ---- the other front ends' sample formats ----------------------------------- */
 #define ACG_FMT_CS16       1   /* interleaved int16 I,Q: soapy.c:238-241 (dm = |D| with the /32768 of soapy.c:241) */
@@ -249,6 +249,11 @@ int  acg_bit_capacity(const acg_ctx *ctx);
 int  acg_read_dm(acg_ctx *ctx, int ch, float *dm, int n);
 int  acg_get_state(acg_ctx *ctx, int ch, acg_chan_state *st);
 int  acg_set_state(acg_ctx *ctx, int ch, const acg_chan_state *st);
+/* the same for channels ch0 .. ch0+n-1 in ONE transfer each way (the legacy view moves all of a dongle's channels per
+ * callback: rtl.c:344-360), and dm_buffer of the last call for n channels: row i at dm + i*pitch_floats, nfloats each */
+int  acg_get_state_n(acg_ctx *ctx, int ch0, int n, acg_chan_state *st);
+int  acg_set_state_n(acg_ctx *ctx, int ch0, int n, const acg_chan_state *st);
+int  acg_read_dm_n(acg_ctx *ctx, int ch0, int n, float *dm, size_t pitch_floats, int nfloats);
 
 /* Replays the bit records of the last call through a putbit()-shaped sink, channel by channel
  * in channel order: for every bit sink(user, ch, vo, lvl).  The legacy shim's sink performs
@@ -256,50 +261,13 @@ int  acg_set_state(acg_ctx *ctx, int ch, const acg_chan_state *st);
 typedef void (*acg_bit_sink)(void *user, int ch, float vo, float lvl);
 int  acg_replay_bits(acg_ctx *ctx, acg_bit_sink sink, void *user);
 
-/* ---- measurement -------------------------------------------------------------------------- */
-/* Measurement / layout switches (ACG_PIPE_BLOCKS, ACG_MSK_LPC, ACG_FIR_WAVES_PER_WG, ...: profiles/LEDGER.md).  A production
- * process has none and pays one atomic load per look-up.  This call sets one (value NULL removes it).  The environment is
- * read ONCE per process, at the library's first look-up, and only if ACG_ALLOW_TUNING=1 is set too (otherwise stray ACG_*
- * variables are named on stderr and ignored).  The measurement-only kernel variants and debug shapes exist only in the lab
- * build of the library (libacarsdec_amd_lab.so, which tests and probes load; it always takes the environment).
- * Not product configuration. */
-int  acg_tune(const char *name, const char *value);
-int  acg_is_lab_build(void);
+/* ---- timing ------------------------------------------------------------------------------- */
 /* Sums of HIP-event-bracketed kernel time since the last call (ACG_F_TIMING), in ms, and the
  * number of launches they cover.  Synchronises. */
 int  acg_get_timing(acg_ctx *ctx, double *fir_ms, int *fir_launches, double *msk_ms, int *msk_launches);
 /* 0 = no events, 1 = both stages (what ACG_F_TIMING starts with), 2 = down-converter launches only:
  * event records on the demodulator stream sit on its serial launch chain (~10 us per launch). */
 int  acg_set_timing(acg_ctx *ctx, int mode);
-/* device-side generator for large synthetic workloads: fills [nstreams] rows with seeded
- * uniform bytes */
-int  acg_fill_random_u8_dev(uint8_t *dev, size_t pitch_bytes, int nrows, size_t row_bytes,
-			    uint64_t seed, void *hip_stream);
-
-/* measurement aid: a pure streaming reader (non-temporal 16-byte loads, nothing else) over `bytes` of
- * device memory, `repeats` back-to-back launches timed with HIP events on the default stream: the read
- * bandwidth this GPU delivers to a kernel that only reads.  Synchronises. */
-int  acg_probe_read_dev(const void *dev, size_t bytes, int repeats, double *gb_per_s);
-
-/* measurement aid: `repeats` synchronous host-to-device copies of `bytes` (after one for nothing), host clock: the rate
- * the *_host entry points can at best be fed at from that host memory (pinned or pageable) */
-int  acg_probe_h2d(void *dev, const void *host, size_t bytes, int repeats, double *gb_per_s);
-
-/* device-side AM up-converter: row r = scale*env[env_index[r]][n/decim] *
- * exp(j(2*pi*off_hz[r]*n/(12500*decim) + phase[r])) + N(0, noise_sigma^2), quantised like an RTL
- * dongle (u8 = clip(rint(127.37 + 127.5 x))).  All pointers are device pointers. */
-int  acg_synth_iq_u8_dev(uint8_t *iq_dev, size_t pitch_bytes, int nrows, int nout, int decim,
-			 const float *env_dev, size_t env_pitch_floats, const int *env_index_dev,
-			 const float *off_hz_dev, const float *phase_dev, float scale, float noise_sigma,
-			 uint64_t seed, void *hip_stream);
-/* diagnostics: the device sin/cos used by the mixer (msk.c:90 calls cexp), evaluated on the GPU
- * for n host arguments in [0, 2*pi) -- lets a test bound its error against libm */
-int  acg_selftest_sincos(const double *x_host, double *sin_host, double *cos_host, int n);
-/* diagnostics: the loop's f64 divisions and square root as the device computes them (msk.c:103,110-111: shared
- * reciprocal, no exponent scaling) next to the compiler's IEEE forms, for n host triples:
- * out[8i..8i+7] = {n0/d, n1/d (shared reciprocal), n0/d, n1/d (IEEE), sqrt(x), sqrt(x) (IEEE), n0/d (single), x}
- * with x = n0^2 + n1^2 -- a test checks the pairs are bit-identical over the operand range the loop produces */
-int  acg_selftest_div2(const double *n0_host, const double *n1_host, const double *d_host, double *out_host, int n);
 
 #ifdef __cplusplus
 }

@@ -315,6 +315,8 @@ static void put_frame(orc_chan *ch)                 /* acars.c:350-369 */
 		if (ch->blk_len > 0)
 			memcpy(f->txt, ch->blk_txt, (size_t)ch->blk_len);
 		f->end_bit = ch->nbit_total;
+		f->end_sample = ch->cur_sample;
+		f->soh_sample = ch->soh_sample;
 	}
 	ch->frames_n++;
 	ch->Acarsstate = ORC_END;
@@ -361,6 +363,7 @@ static void decode_acars(orc_chan *ch)              /* acars.c:246-375 */
 			ch->nbits = 8;
 			ch->MskLvlSum = 0;
 			ch->MskBitCount = 0;
+			ch->soh_sample = ch->cur_sample;      /* acars.c:290: gettimeofday(&(ch->blk->tv)) sits here */
 			return;
 		}
 		reset_acars(ch);
@@ -522,6 +525,7 @@ void orc_demod_msk(orc_chan *ch, const float *dm, int len)
 					ch->bitlog[ch->bitlog_n].lvl = lvl;
 				}
 				ch->bitlog_n++;
+				ch->cur_sample = ch->nsamp_total + n;
 				putbit(sv, ch);
 				ch->nbit_total++;
 			}
@@ -534,6 +538,7 @@ void orc_demod_msk(orc_chan *ch, const float *dm, int len)
 
 	ch->idx = idx;
 	ch->MskPhi = p;
+	ch->nsamp_total += len;
 }
 
 /* rtl.c:314-361: all channels share the stream; then demodMSK per channel */

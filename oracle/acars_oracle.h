@@ -42,6 +42,8 @@ typedef struct {
 	unsigned char crc[2];
 	unsigned char txt[ORC_TXTMAX];
 	long long end_bit;      /* index (per channel, from 0) of the bit that completed the block */
+	long long end_sample;   /* index (per channel, from 0) of the 12.5 kHz sample whose bit completed the block */
+	long long soh_sample;   /* ... whose bit completed the block's SOH byte: where acars.c:290 takes blk->tv */
 } orc_frame;
 
 /* per-bit log entry (what putbit() receives + the level, msk.c:110-126) */
@@ -67,6 +69,9 @@ typedef struct {
 	unsigned char blk_txt[ORC_TXTMAX + 6];
 	unsigned char blk_crc[2];
 	long long nbit_total;           /* bits produced so far (not in the reference; bookkeeping) */
+	long long nsamp_total;          /* 12.5 kHz samples consumed by earlier orc_demod_msk calls (bookkeeping) */
+	long long cur_sample;           /* index of the sample being processed (bookkeeping) */
+	long long soh_sample;           /* cur_sample when the running block's SOH byte completed (acars.c:290) */
 
 	/* sinks (may be NULL) */
 	orc_bit *bitlog; size_t bitlog_cap, bitlog_n;

@@ -33,7 +33,8 @@ def build(verbose=False):
 # --------------------------------------------------------------------------- restatement
 class OrcFrame(C.Structure):
     _fields_ = [("chn", C.c_int), ("len", C.c_int), ("err", C.c_int), ("lvl", C.c_float),
-                ("crc", C.c_ubyte * 2), ("txt", C.c_ubyte * TXTMAX), ("end_bit", C.c_longlong)]
+                ("crc", C.c_ubyte * 2), ("txt", C.c_ubyte * TXTMAX), ("end_bit", C.c_longlong),
+                ("end_sample", C.c_longlong), ("soh_sample", C.c_longlong)]
 
 
 class OrcBit(C.Structure):
@@ -47,7 +48,7 @@ class OrcChan(C.Structure):
                 ("outbits", C.c_ubyte), ("nbits", C.c_int), ("Acarsstate", C.c_int),
                 ("blk_len", C.c_int), ("blk_err", C.c_int),
                 ("blk_txt", C.c_ubyte * (TXTMAX + 6)), ("blk_crc", C.c_ubyte * 2),
-                ("nbit_total", C.c_longlong),
+                ("nbit_total", C.c_longlong), ("nsamp_total", C.c_longlong), ("cur_sample", C.c_longlong), ("soh_sample", C.c_longlong),
                 ("bitlog", C.POINTER(OrcBit)), ("bitlog_cap", C.c_size_t), ("bitlog_n", C.c_size_t),
                 ("frames", C.POINTER(OrcFrame)), ("frames_cap", C.c_size_t), ("frames_n", C.c_size_t)]
 

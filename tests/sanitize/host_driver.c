@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include "acarsdec_amd.h"
+#include "acarsdec_amd_lab.h"
 
 void acg_host_msk_h(float *h);
 float acg_host_level_db(double lvlsum, int bitcount);
@@ -118,6 +119,9 @@ int main(void)
 		CHECK(acg_read_bits(NULL, 0, buf, buf, 4, &n) == ACG_EINVAL && acg_read_bits_all(NULL, &n, buf, buf) == ACG_EINVAL);
 		CHECK(acg_bit_capacity(NULL) == 0 && acg_read_dm(NULL, 0, buf, 4) == ACG_EINVAL);
 		CHECK(acg_get_state(NULL, 0, &st) == ACG_EINVAL && acg_set_state(NULL, 0, &st) == ACG_EINVAL);
+		CHECK(acg_get_state_n(NULL, 0, 1, &st) == ACG_EINVAL && acg_set_state_n(NULL, 0, 1, &st) == ACG_EINVAL);
+		CHECK(acg_read_dm_n(NULL, 0, 1, buf, 4, 4) == ACG_EINVAL);
+		CHECK(acg_lab_set_block_counter(NULL, 1u) == ACG_EINVAL && acg_lab_block_ring_size(NULL) == 0u);
 		CHECK(acg_replay_bits(NULL, NULL, NULL) == ACG_EINVAL);
 		CHECK(acg_get_timing(NULL, &ms, &n, &ms, &n) == ACG_EINVAL && acg_set_timing(NULL, 1) == ACG_EINVAL);
 		CHECK(acg_fill_random_u8_dev(NULL, 16, 1, 16, 1, NULL) == ACG_EINVAL);
