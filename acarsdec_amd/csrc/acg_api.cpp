@@ -144,6 +144,7 @@ struct acg_ctx {
     hipStream_t copy_stream = nullptr;  // result copies that must not queue behind running kernels
     hipStream_t post_stream = nullptr;  // ACG_F_REPAIR: the block thread's pass over a call's blocks, OFF the demodulator's serial chain
     hipEvent_t msk_end[8] = {};         // per call slot: the call's last demodulator launch has finished
+    hipEvent_t last_guard = nullptr;    // the dm guard recorded behind the newest demodulator launch of the call being issued (or none)
     hipEvent_t in_ev = nullptr;
     hipStream_t fir_stream = nullptr;   // CU partition: down-converter on the CUs the demodulator does not own
     hipEvent_t fir_in = nullptr, fir_out = nullptr;
@@ -392,23 +393,27 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
     c->msk_lpc = cfg->nch <= 8192 ? 8 : cfg->nch <= 16384 ? 4 : cfg->nch <= 32768 ? 2 : 1;
     // pipeline chunk: 4 callbacks per launch pair.  Few large launches beat many small ones at every size
     // measured (1024 ... 16384 channels: launch tails, event packets); with the two dm buffers the chunks of a
-    // call only serve to let its demodulator start before its down-converter has finished.  Up to 1024
-    // channels even that is not worth a second pair: the down-converter of call i+1 hides under the
-    // demodulator of call i entirely (0 = whole calls).
-    c->pipe_blocks = cfg->nch <= 1024 ? 0 : 4;
+    // call only serve to let its demodulator start before its down-converter has finished.  Up to 2048
+    // channels even that is not worth a second pair: there the demodulator is the longer stage, the down-converter of call
+    // i+1 hides under the demodulator of call i entirely, and every extra demodulator launch costs its prologue / epilogue
+    // and the gap between two launches on the serial chain (0 = whole calls; 2048 channels, round 5: whole calls +3.5 ... +13 %
+    // over chunks of 4 on two boxes, chunks of 2 -3 %: profiles/r05_shard2048_sweep.txt).
+    c->pipe_blocks = cfg->nch <= 2048 ? 0 : 4;
     c->pipe_blocks = std::max(0, acg_tune_get("ACG_PIPE_BLOCKS", c->pipe_blocks));
     c->msk_high_prio = cfg->nch <= 8192 ? 1 : 0;   // <= 8192: its chain is the longer stage (neutral at 4096, +7 % at 8192)
     c->timing_mode = (cfg->flags & ACG_F_TIMING) ? 1 : 0;
     // few channels: the demodulator's serial chain is the critical path -> give its waves CUs of their own
-    // (one wave per SIMD), the down-converter keeps the rest (it is HBM-bound and loses nothing)
+    // (one wave per SIMD), the down-converter keeps the rest (it is HBM-bound and needs ~176 CUs to reach 0.75 of the spec).
     // Measured (profiles/r02_experiments/bench_variants.txt): the job gets faster as the demodulator's share grows past
     // the one-wave-per-SIMD minimum n -- 1024 channels (n = 32): 32 CUs 1.13 M, 64: 1.16, 80: 1.17, 96: 1.18 channel*Msps
-    // while the down-converter still reaches 0.75 of the HBM spec on the other 176; 2048 channels (n = 64): 64 CUs 2.03 M,
-    // 128: 2.18 (the demodulator is the longer stage there, and it is bound by the shader clock, which a narrower
-    // streaming stage leaves higher).  So: 2.5 n, at most half the chip.
+    // while the down-converter still reaches 0.75 of the HBM spec on the other 176.  Round 4 gave 2048 channels (n = 64)
+    // 128 CUs; round 5's sweep (profiles/r05_shard2048_sweep.txt), taken after the block repair stopped occupying the
+    // demodulator's SIMDs for most of every call, has the optimum where the down-converter keeps its 176 CUs: 80 for the
+    // demodulator (whole job 0.53 -> 0.61 on the same box together with whole-call launches; 96: 0.60, 112: 0.59, 160: 0.52).
+    // So: 2.5 n, at most 80.
     if (cfg->nch <= 2048) {
         const int need = std::max(1, (cfg->nch * c->msk_lpc / 64 + 3) / 4);
-        c->msk_cus_default = std::min(128, (5 * need + 1) / 2);
+        c->msk_cus_default = std::min(80, (5 * need + 1) / 2);
     }
     c->msk_high_prio = acg_tune_get("ACG_MSK_PRIO", c->msk_high_prio) ? 1 : 0;
     {
@@ -623,6 +628,7 @@ static int guard_wait(acg_ctx* ctx, hipStream_t s, int j0, int j1)
 static int guard_record(acg_ctx* ctx, int j0, int j1)
 {
     HIPCHK(ctx, hipEventRecord(ctx->msk_done[(size_t)(ctx->gbase + j0)], ctx->msk_stream));
+    ctx->last_guard = ctx->msk_done[(size_t)(ctx->gbase + j0)];          // (recorded right behind the newest demodulator launch)
     for (int j = ctx->gbase + j0; j < ctx->gbase + j1; ++j) ctx->msk_done_owner[(size_t)j] = ctx->gbase + j0;
     return ACG_OK;
 }
@@ -823,8 +829,13 @@ static int end_of_call(acg_ctx* ctx)
         // call's last demodulator launch: the demodulator of the next call does not wait for it (on its stream the pass sat on
         // the serial chain that sets the step at <= 2048 channels and cost 30 % of the headline: profiles/LEDGER.md round 4).
         // The pass ends at the call's published queue length, not at the live counter the next call is already moving.
-        HIPCHK(ctx, hipEventRecord(ctx->msk_end[slot], ctx->msk_stream));
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->post_stream, ctx->msk_end[slot], 0));
+        // (the dm guard recorded behind the call's last demodulator launch is that very point of the stream: no second record)
+        if (ctx->last_guard) {
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->post_stream, ctx->last_guard, 0));
+        } else {
+            HIPCHK(ctx, hipEventRecord(ctx->msk_end[slot], ctx->msk_stream));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->post_stream, ctx->msk_end[slot], 0));
+        }
         const int e = acg_launch_blk_repair(ctx->d_frames, ctx->frame_cap, ctx->d_call_count + slot, ctx->d_rep_upto, ctx->d_rep_upto + 1,
                                             ctx->d_crctab + 256, ctx->d_crctab, ctx->cfg.nch, ctx->post_stream);
         if (e != 0) return fail(ctx, ACG_EHIP, "block repair launch failed");
@@ -832,6 +843,7 @@ static int end_of_call(acg_ctx* ctx)
     } else {
         HIPCHK(ctx, hipEventRecord(ctx->call_done[slot], ctx->msk_stream));
     }
+    ctx->last_guard = nullptr;
     ctx->call_seq++;
     return ACG_OK;
 }
@@ -874,13 +886,19 @@ extern "C" int acg_process_iq_u8_dev(acg_ctx* ctx, const uint8_t* iq_dev, size_t
         // persistent workgroups left over and run ~20 % slower): wait until the demodulator stream has
         // reached that launch.  Costs one cross-queue signal per chunk; the down-converter is then at
         // most two chunks ahead, which is all the run-ahead the pipeline needs.
-        if (ctx->msk_go_valid) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->msk_go, 0));
+        // (with a CU partition the two stages cannot take each other's CUs: no ordering of the dispatches is needed, and the
+        //  demodulator's serial chain is spared one barrier packet per launch -- every packet between two of its kernels is
+        //  ~7 us during which the stage that sets the step stands still)
+        const bool order_dispatch = ctx->fir_stream == nullptr;
+        if (order_dispatch && ctx->msk_go_valid) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->msk_go, 0));
         r = launch_fir(ctx, iq_dev, pitch_bytes, nb, s, b0);
         if (r != ACG_OK) return r;
         HIPCHK(ctx, hipEventRecord(ctx->fir_done[(size_t)k], s));
         HIPCHK(ctx, hipStreamWaitEvent(ctx->msk_stream, ctx->fir_done[(size_t)k], 0));
-        HIPCHK(ctx, hipEventRecord(ctx->msk_go, ctx->msk_stream));
-        ctx->msk_go_valid = true;
+        if (order_dispatch) {
+            HIPCHK(ctx, hipEventRecord(ctx->msk_go, ctx->msk_stream));
+            ctx->msk_go_valid = true;
+        }
         r = launch_msk(ctx, ctx->d_dm + (size_t)b0 * ACG_BLOCK, ctx->dm_pitch, nb * ACG_BLOCK, ctx->msk_stream, b0 > 0);
         if (r != ACG_OK) return r;
         if ((r = guard_record(ctx, b0, b0 + nb)) != ACG_OK) return r;
@@ -1473,7 +1491,8 @@ static int run_fmt(acg_ctx* ctx, int fmt, FirArgs* a, hipStream_t caller)
             if ((r = get_event(ctx, &ev.a)) != ACG_OK || (r = get_event(ctx, &ev.b)) != ACG_OK) return r;
             HIPCHK(ctx, hipEventRecord(ev.a, s));
         }
-        if (ctx->msk_go_valid) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->msk_go, 0));   // see acg_process_iq_u8_dev
+        const bool order_dispatch = ctx->fir_stream == nullptr;                       // see acg_process_iq_u8_dev
+        if (order_dispatch && ctx->msk_go_valid) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->msk_go, 0));
         int e;
         {
             RoctxRange range("acg:down-converter");
@@ -1489,8 +1508,10 @@ static int run_fmt(acg_ctx* ctx, int fmt, FirArgs* a, hipStream_t caller)
         }
         HIPCHK(ctx, hipEventRecord(ctx->fir_done[(size_t)k], s));
         HIPCHK(ctx, hipStreamWaitEvent(ctx->msk_stream, ctx->fir_done[(size_t)k], 0));
-        HIPCHK(ctx, hipEventRecord(ctx->msk_go, ctx->msk_stream));
-        ctx->msk_go_valid = true;
+        if (order_dispatch) {
+            HIPCHK(ctx, hipEventRecord(ctx->msk_go, ctx->msk_stream));
+            ctx->msk_go_valid = true;
+        }
         int r = launch_msk(ctx, ctx->d_dm + w0, ctx->dm_pitch, nw, ctx->msk_stream, w0 > 0);
         if (r != ACG_OK) return r;
         if ((r = guard_record(ctx, j0, j1)) != ACG_OK) return r;

@@ -251,6 +251,78 @@ def make_taps(D, fmt_name, offs, M, ntaps):
     return taps
 
 
+def _probe_ab(args, J, step, drain, steps, nch, nout, M):
+    """measurement aid (--ab): the same decoder, buffers and placement, timed again under each value of a per-launch switch in
+    turn (acg_tune: ACG_FIR_VARIANT, ACG_MSK_LPC_LIVE, ...), two rounds -- not part of the reported value"""
+    import torch
+    from acarsdec_amd import _capi as K
+    ab = {}
+    ab_name, _, ab_vals = args.ab.rpartition("=")                # "5,55,8" or "ACG_MSK_LPC_LIVE=2,4"
+    ab_name = ab_name or "ACG_FIR_VARIANT"
+    for rnd in range(2):
+        for v in ab_vals.split(","):
+            K.tune(ab_name, v)
+            step()
+            drain()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            clk_ab = None
+            for i_ in range(steps):
+                step()
+                if i_ == steps - 2:
+                    clk_ab = gpu_telemetry(J.local)
+            drain()
+            torch.cuda.synchronize()
+            ab.setdefault(v, []).append(round(nch * nout * M * steps / (time.perf_counter() - t1) / 1e6, 0))
+            ab.setdefault(v + " telemetry", []).append(clk_ab)
+    K.tune(ab_name, os.environ.get(ab_name))
+    return ab
+
+
+def _probe_decoders(args, J, make_decoder, step, drain, steps, reps, dt_local, nch, nout, M, dev):
+    """measurement aid (--decoders N): further decoders in the same process (each with its own allocations, all kept alive), the
+    same input, timed the same way -- how much of the run-to-run spread is where the decoder's buffers happen to lie.  Probe
+    switches: ACG_BENCH_SPACER_MB changes where the next decoder's buffers land without touching its streams;
+    ACG_BENCH_DUMMY_STREAMS creates streams in between, which shifts the decoder's streams to other hardware queues without
+    touching its memory; ACG_BENCH_DECODERS_ALT times each decoder once more under another FIR variant"""
+    import torch
+    from acarsdec_amd import _capi as K
+    trials = [round(nch * nout * M * steps * reps / dt_local / 1e6, 0)]
+    others, spacers, dummies, trials_alt = [], [], [], []
+    for k in range(1, args.decoders):
+        sp = int(os.environ.get("ACG_BENCH_SPACER_MB", "53"))
+        if sp:
+            spacers.append(torch.empty((((k * sp) << 20) + 4096 * k,), dtype=torch.uint8, device=dev))
+        for _ in range(int(os.environ.get("ACG_BENCH_DUMMY_STREAMS", "0"))):
+            dummies.append(torch.cuda.Stream(priority=-1))
+            dummies.append(torch.cuda.Stream())
+        d2 = make_decoder()
+        others.append(d2)
+
+        def timed():
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                step(dec=d2)
+            drain(d2)
+            torch.cuda.synchronize()
+            return round(nch * nout * M * steps / (time.perf_counter() - t1) / 1e6, 0)
+        for _ in range(2):
+            step(dec=d2)
+        drain(d2)
+        trials.append(timed())
+        alt = os.environ.get("ACG_BENCH_DECODERS_ALT")
+        if alt:
+            K.tune("ACG_FIR_VARIANT", alt)
+            step(dec=d2)
+            drain(d2)
+            trials_alt.append(timed())
+            K.tune("ACG_FIR_VARIANT", os.environ.get("ACG_FIR_VARIANT"))
+    for d2 in others:
+        d2.close()
+    return dict(default=trials, alt_variant=trials_alt) if trials_alt else trials
+
+
 def run_case(J, name, case, args, steps, warmup, headline):
     """Builds the input of one workload in J.iq, checks the first pass against the oracle, times `steps`
     steps.  Returns the dict that goes into the JSON line (rank 0) or None."""
@@ -570,18 +642,24 @@ def run_case(J, name, case, args, steps, warmup, headline):
                          means="the library in ACG_F_EXACT_FIR mode (rtl.c:335-353 in the reference's order) -> the same GPU demodulator: "
                                "everything identical to oracle down-converter -> oracle demodulator, so the streaming path's only deviation is "
                                "the re-associated sum of its down-converter")
-        # (4b) the reference's own builds against each other on the same bytes and taps
+        # (4b) the reference's own builds against each other on the same bytes and taps: rtl.c in_callback for u8, soapy.c's reader
+        # loop for CS16, air.c rx_callback for real f32 (oracle/_ref: the unmodified sources, -O2 and the reference's -Ofast)
         refs = None
-        if fmt == 0 and share == 1 and ncheck and not args.no_ref_leg:
+        front = {0: "rtl", K.FMT_CS16: "soapy", K.FMT_F32_REAL: "air"}.get(fmt)
+        if front and share == 1 and ncheck and not args.no_ref_leg:
             rows_ = [host_rows[c] for c in range(ncheck)]
             wf_ = [taps[c] for c in range(ncheck)]
             t_ref = time.perf_counter()
             which = "out" if repair else "raw"
             pick = lambda d: None if d is None else d[which]
-            b_o2 = pick(O.ref_blocks("", rows_, M, wf_))
-            b_fast, fast_label = pick(O.ref_blocks("_fast", rows_, M, wf_)), "-Ofast -march=native"
-            if b_fast is None:
-                b_fast, fast_label = pick(O.ref_blocks("_v3", rows_, M, wf_)), "-Ofast -march=x86-64-v3"
+            if front == "rtl":
+                b_o2 = pick(O.ref_blocks("", rows_, M, wf_))
+                b_fast, fast_label = pick(O.ref_blocks("_fast", rows_, M, wf_)), "-Ofast -march=native"
+                if b_fast is None:
+                    b_fast, fast_label = pick(O.ref_blocks("_v3", rows_, M, wf_)), "-Ofast -march=x86-64-v3"
+            else:
+                b_o2 = pick(O.ref_blocks("_" + front, rows_, M, wf_, front=front))
+                b_fast, fast_label = pick(O.ref_blocks("_%s_fast" % front, rows_, M, wf_, front=front)), "-Ofast -march=x86-64-v3"
             if b_o2 is not None and b_fast is not None:
                 strip = lambda lst: [t[1:] for t in lst]
                 refs = dict(o2_blocks=sum(len(x) for x in b_o2), ofast_blocks=sum(len(x) for x in b_fast),
@@ -589,11 +667,16 @@ def run_case(J, name, case, args, steps, warmup, headline):
                             oracle_vs_ref_o2_blocks_differing=sum(len(set(x) ^ set(strip(y))) for x, y in zip(b_o2, e2e_want)),
                             gpu_vs_ref_o2_blocks_differing=sum(len(set(x) ^ set(strip(got.get(c, [])))) for c, x in enumerate(b_o2)),
                             gpu_vs_ref_ofast_blocks_differing=sum(len(set(x) ^ set(strip(got.get(c, [])))) for c, x in enumerate(b_fast)),
-                            builds="oracle/_ref/libacarsref.so (-O2, IEEE) vs the reference's own flags (%s): unmodified rtl.c in_callback + msk.c + "
+                            builds="oracle/_ref (-O2, IEEE) vs the reference's own flags (%s): unmodified %s + msk.c + "
                                    "acars.c (%s) on the GPU's input bytes and tap tables, one channel per pass, each build in a child interpreter"
-                                   % (fast_label, "blocks as its blk_thread hands them to outputmsg()" if repair else "blocks as decodeAcars queues them"),
+                                   % (fast_label, {"rtl": "rtl.c in_callback", "soapy": "soapy.c reader loop", "air": "air.c rx_callback"}[front],
+                                      "blocks as its blk_thread hands them to outputmsg()" if repair else "blocks as decodeAcars queues them"),
                             cpu_seconds=round(time.perf_counter() - t_ref, 1))
-        allowed = (refs["ref_fast_vs_ref_o2_blocks_differing"] if refs else 0) + 1
+        # What the streaming path may differ from the IEEE oracle by: exactly what the reference's own -O2 and -Ofast builds differ
+        # from each other on these bytes (MEASURED above; no slack on top of it -- VERDICT r04), and, where the -Ofast leg ran, NOT
+        # AT ALL from the reference as shipped (its -Ofast build).  Without a reference leg (split planes, shared streams,
+        # --no-ref-leg) the oracle is the only yardstick and nothing may differ.
+        allowed = refs["ref_fast_vs_ref_o2_blocks_differing"] if refs else 0
         parity = dict(channels_checked=ncheck, blocks=nblocks, blocks_exact_given_gpu_dm=bool(ok),
                       blocks_are=("what outputmsg() receives: checked / repaired by the device (ACG_F_REPAIR, acars.c:93-215), parity stripped, "
                                   "dropped blocks omitted" if repair else "as decodeAcars queues them (pre-repair, --raw-blocks)"),
@@ -605,12 +688,15 @@ def run_case(J, name, case, args, steps, warmup, headline):
                       dm_within_1e5_rel=bool(dm_ok), dm_max_abs_err=dm_err, dm_samples_per_channel=nout,
                       exact_order_mode=exact,
                       end_to_end=dict(blocks_differing=e2e_blocks_off, channels=e2e_channels_off, exact=bool(e2e_blocks_off == 0),
-                                      allowed=allowed, allowed_means="what the reference's -O2 and -Ofast builds differ by on this input, plus one",
+                                      allowed=allowed, allowed_means="what the reference's -O2 and -Ofast builds differ by on this input (measured in this run); "
+                                                                     "and zero against the reference's -Ofast build",
+                                      gpu_vs_ref_ofast=(refs["gpu_vs_ref_ofast_blocks_differing"] if refs else None),
                                       note="streaming down-converter -> GPU demodulator against oracle down-converter -> oracle demodulator; a differing "
                                            "block = a razor-edge soft decision (|vo| < 1e-3 in noise) flipped by the 1e-7 re-association of dm"),
                       reference_builds=refs,
                       blocks_first_pass_all_channels=len(first))
         bad = (not (ok and dm_ok and msgs_ok) or e2e_blocks_off > allowed or
+               (refs is not None and (refs["gpu_vs_ref_ofast_blocks_differing"] != 0 or refs["oracle_vs_ref_o2_blocks_differing"] != 0)) or
                (exact is not None and not (exact["dm_bit_identical_to_oracle"] and exact["blocks_identical_end_to_end"])))
         if bad:
             raise SystemExit("bench[%s]: GPU output differs from the oracle: %r; first mismatch: %r %r" % (name, parity, first_bad, first_bad_msg))
@@ -664,76 +750,11 @@ def run_case(J, name, case, args, steps, warmup, headline):
     step_ms = sorted((b - a) * 1e3 for a, b in zip(marks[:-1], marks[1:]))
     dt, nfr_total = shard.reduce_timing(dt_local, nfr, world, J.coll, cdev)
     per_rank = shard.gather_scalars(dt_local, world, J.coll, cdev)
-    ab = None
-    if args.ab and world == 1:
-        # measurement aid: the same decoder, buffers and placement, timed again under each value of a per-launch switch in
-        # turn (acg_tune: ACG_FIR_VARIANT, ACG_MSK_LPC_LIVE, ...), two rounds -- not part of the reported value
-        ab = {}
-        ab_name, _, ab_vals = args.ab.rpartition("=")                # "5,55,8" or "ACG_MSK_LPC_LIVE=2,4"
-        ab_name = ab_name or "ACG_FIR_VARIANT"
-        for rnd in range(2):
-            for v in ab_vals.split(","):
-                K.tune(ab_name, v)
-                step()
-                drain()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                clk_ab = None
-                for i_ in range(steps):
-                    step()
-                    if i_ == steps - 2:
-                        clk_ab = gpu_telemetry(J.local)
-                drain()
-                torch.cuda.synchronize()
-                ab.setdefault(v, []).append(round(nch * nout * M * steps / (time.perf_counter() - t1) / 1e6, 0))
-                ab.setdefault(v + " telemetry", []).append(clk_ab)
-        K.tune(ab_name, os.environ.get(ab_name))
-    trials = None
-    if args.decoders > 1 and world == 1:
-        # measurement aid: further decoders in the same process (each with its own allocations, all kept alive), the same
-        # input, timed the same way -- how much of the run-to-run spread is where the decoder's buffers happen to lie
-        trials = [round(nch * nout * M * steps * reps / dt_local / 1e6, 0)]
-        others, spacers = [], []
-        dummies, trials_alt = [], []
-        for k in range(1, args.decoders):
-            # (probe switches: ACG_BENCH_SPACER_MB changes where the next decoder's buffers land without touching its streams;
-            #  ACG_BENCH_DUMMY_STREAMS creates streams in between, which shifts the decoder's streams to other hardware queues
-            #  without touching its memory)
-            sp = int(os.environ.get("ACG_BENCH_SPACER_MB", "53"))
-            if sp:
-                spacers.append(torch.empty((((k * sp) << 20) + 4096 * k,), dtype=torch.uint8, device=dev))
-            for _ in range(int(os.environ.get("ACG_BENCH_DUMMY_STREAMS", "0"))):
-                dummies.append(torch.cuda.Stream(priority=-1))
-                dummies.append(torch.cuda.Stream())
-            d2 = make_decoder()
-            others.append(d2)
-            for _ in range(2):
-                step(dec=d2)
-            drain(d2)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(steps):
-                step(dec=d2)
-            drain(d2)
-            torch.cuda.synchronize()
-            trials.append(round(nch * nout * M * steps / (time.perf_counter() - t1) / 1e6, 0))
-            alt = os.environ.get("ACG_BENCH_DECODERS_ALT")        # probe: the same decoder once more under another FIR variant
-            if alt:
-                K.tune("ACG_FIR_VARIANT", alt)
-                step(dec=d2)
-                drain(d2)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(steps):
-                    step(dec=d2)
-                drain(d2)
-                torch.cuda.synchronize()
-                trials_alt.append(round(nch * nout * M * steps / (time.perf_counter() - t1) / 1e6, 0))
-                K.tune("ACG_FIR_VARIANT", os.environ.get("ACG_FIR_VARIANT"))
-        for d2 in others:
-            d2.close()
-        if trials_alt:
-            trials = dict(default=trials, alt_variant=trials_alt)
+    # measurement aids (--ab, --decoders: same-process A/B of a per-launch switch, further decoders in the same process); not part
+    # of the reported value, dead in the default run, and kept out of this function (the timed path must be auditable)
+    ab = _probe_ab(args, J, step, drain, steps, nch, nout, M) if (args.ab and world == 1) else None
+    trials = (_probe_decoders(args, J, make_decoder, step, drain, steps, reps, dt_local, nch, nout, M, dev)
+              if (args.decoders > 1 and world == 1) else None)
     dec.close()
     if rank != 0:
         return None
@@ -1035,6 +1056,137 @@ MULTI_GPU_NOTE = ("no N>1 run has been measured by the builder (1-GPU boxes only
                   "(weak scaling, no data-path collective; RCCL carries the 32 B/channel config scatter, barriers and reductions)")
 
 
+# ------------------------------------------------------------------------------------------ BASELINE configs[1]: the rtl.c shape
+RTL8 = dict(tag="BASELINE configs[1]: one dongle, 8 channels on ONE 2.0 Msps u8 stream (rtl.c's shape)", decim=160, callbacks=32)
+
+
+def rtl8_cpu_child(variant, nfreq, path):
+    """child process: the UNMODIFIED reference (oracle/_ref, its own flags) -- initRtl for the dongle's channels, then in_callback
+    (rtl.c:314-361: mix + decimate for all channels, demodMSK per channel, decodeAcars) over the file's callbacks on one core"""
+    import numpy as np
+    from oracle import oracle as O
+    M = RTL8["decim"]
+    freqs = rtl8_freqs(int(nfreq))
+    os.dup2(os.open(os.devnull, os.O_WRONLY), 2)
+    ref = O.Ref(variant)
+    ref.init_rtl(freqs, M)
+    iq = np.fromfile(path, dtype=np.uint8)
+    blk = 1024 * M * 2
+    bufs = [np.ascontiguousarray(iq[b * blk:(b + 1) * blk]) for b in range(iq.size // blk)]
+    ref.in_callback(bufs[0])
+    ref.init_rtl(freqs, M)
+    t0 = time.perf_counter()
+    for b in bufs:
+        ref.in_callback(b)
+    dt = time.perf_counter() - t0
+    print(json.dumps(dict(ms_per_callback=dt / len(bufs) * 1e3, callbacks=len(bufs))))
+
+
+def rtl8_freqs(nch):
+    return ["%.3f" % (131.025 + 0.050 * k) for k in range(nch)]
+
+
+def rtl8_oneline(chn, lvl, err, addr, fid, mode, label, no, txt):
+    """printoneline() (output.c:327-346) without the date"""
+    t = txt.split(b"\0")[0][:59].replace(b"\n", b" ").replace(b"\r", b" ")
+    dec = lambda b: b.split(b"\0")[0].decode("latin-1")
+    return "#%1d (L:%+5.1f E:%1d) %7s %6s %1s %2s %4s %s" % (chn + 1, lvl, err, dec(addr), dec(fid), dec(mode) or "\0", dec(label), dec(no), t.decode("latin-1"))
+
+
+def run_rtl8(J, args):
+    """BASELINE configs[1] and the path the north star names: nbch channels of ONE dongle on one 2.0 Msps u8 I/Q stream, handed
+    over from host memory one reference callback (1024 outputs = 81.92 ms of signal, rtl.c:49,213) at a time.
+      legacy   the reference's UNCHANGED acarsdec.c + acars.c + output.c + rtl.c with the one-hunk binding on
+               compat_msk.c: acarsdec_amd_in_callback -> GPU -> every bit replayed through the unchanged decodeAcars() on the
+               reference's own channel[] (lib/acarsdec_gpu_rtl, a file-playing librtlsdr stand-in); time inside the entry point
+      batched  the same bytes through acg_process_iq_u8_host (nstreams = 1) + acg_collect_msgs one call behind
+      cpu      the unmodified reference's in_callback on the same bytes, its own flags, one core (oracle/_ref)
+    Parity: the legacy program's printed messages == the CPU twin program's (oracle/_ref/acarsdec_cpu_rtl), and the batched
+    API's records, printed the same way, == both."""
+    import re
+    import tempfile
+    import numpy as np
+    from acarsdec_amd import decoder as D, synth as S, _capi as K
+    M, ncb = RTL8["decim"], RTL8["callbacks"]
+    gpu_exe = os.path.join(ROOT, "acarsdec_amd", "lib", "acarsdec_gpu_rtl")
+    cpu_exe = os.path.join(ROOT, "oracle", "_ref", "acarsdec_cpu_rtl")
+    out = {"workload": RTL8["tag"] + "; %d callbacks of 1024 outputs from host memory, rtlMult=%d" % (ncb, M), "budget_ms_per_callback": 81.92,
+           "decim": M, "callbacks": ncb}
+    strip = lambda txt: [l for l in re.sub(r"\d\d/\d\d/\d{4} \d\d:\d\d:\d\d\.\d{3} ", "", txt).splitlines() if l.startswith("#")]
+    per_ch = lambda lines: {k: [l for l in lines if l.split()[0] == k] for k in sorted(set(l.split()[0] for l in lines))}
+    with tempfile.TemporaryDirectory() as td:
+        for nch in (8, 16):
+            rng = np.random.default_rng(0x0881 + nch)
+            freqs = rtl8_freqs(nch)
+            fr = [D.parse_freq_mhz(f) for f in freqs]
+            fc, _ = D.choose_fc(fr, M)
+            env = np.zeros((nch, ncb * 1024))
+            for c in range(nch):
+                a_, _ = S.channel_audio(rng, env.shape[1], gap=(3125, 12500), text_len=(20, 120))
+                env[c] = CARRIER * (1.0 + DEPTH * a_)
+            iq = S.iq_u8_from_envelopes(env, M, [f - fc for f in fr], phases=list(rng.uniform(0, 2 * np.pi, nch)), scale=1.0 / nch, noise=0.004, rng=rng)
+            path = os.path.join(td, "rtl%d.iq" % nch)
+            iq.tofile(path)
+            e = {"channels": nch}
+            envp = dict(os.environ, ACARSDEC_IQ_FILE=path, ACARSDEC_AMD_STATS="1")
+            lines = {}
+            for name, exe in (("cpu", cpu_exe), ("legacy", gpu_exe)):
+                if not os.path.exists(exe):
+                    continue
+                r = subprocess.run([exe, "-o", "1", "-r", "0"] + freqs, env=envp, capture_output=True, timeout=300)
+                if r.returncode != 0:
+                    e[name + "_error"] = _short(r.stderr.decode("latin-1"), 200)
+                    continue
+                lines[name] = per_ch(strip(r.stdout.decode("latin-1")))
+                if name == "legacy":
+                    m = re.search(r"first call ([0-9.]+) ms.*others ([0-9.]+) ms per call", r.stderr.decode("latin-1"))
+                    if m:
+                        e["legacy_first_call_ms"], e["legacy_ms_per_callback"] = float(m.group(1)), float(m.group(2))
+            # the batched API, nstreams = 1: one host buffer per callback, messages collected one call behind
+            dec = D.Decoder(nch, decim=M, nstreams=1, max_blocks=1, repair=True, bitlog=False, max_lag=1)
+            dec.init_rtl(freqs)
+            blk = 1024 * M * 2
+            bufs = [np.ascontiguousarray(iq[b * blk:(b + 1) * blk]).reshape(1, -1) for b in range(ncb)]
+
+            def run_batched(sink):
+                for b in bufs:
+                    dec.in_callback(b)
+                    while True:
+                        n_, fb, more = dec.collect_msgs_raw(1, 256)
+                        if sink is not None:
+                            sink += [K.Msg.from_buffer_copy(fb[i]) for i in range(n_)]
+                        if not more:
+                            break
+                last = dec.drain_msgs(256)
+                if sink is not None:
+                    sink += last
+            run_batched(None)                       # warm-up (first launches), then from reset
+            dec.reset()
+            msgs = []
+            t0 = time.perf_counter()
+            run_batched(msgs)
+            e["batched_ms_per_callback"] = round((time.perf_counter() - t0) / ncb * 1e3, 4)
+            dec.close()
+            got = per_ch([rtl8_oneline(int(m.chn), m.lvl, int(m.err), m.addr, m.fid, m.mode, m.label, m.no, bytes(m.txt[: m.txt_len])) for m in msgs])
+            lines["batched"] = got
+            # the reference's in_callback on one host core (its own flags)
+            for variant in ("_fast", "_v3", ""):
+                if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libacarsref%s.so" % variant)):
+                    continue
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--rtl8-cpu-child", variant, str(nch), path], capture_output=True, text=True, timeout=300)
+                if r.returncode == 0 and r.stdout.strip():
+                    e["cpu_reference_ms_per_callback"] = round(json.loads(r.stdout.strip().splitlines()[-1])["ms_per_callback"], 4)
+                    break
+            e["messages"] = sum(len(v) for v in lines.get("batched", {}).values())
+            e["parity"] = {"legacy_program_equals_cpu_program": (lines["legacy"] == lines["cpu"]) if ("legacy" in lines and "cpu" in lines) else None,
+                           "batched_equals_cpu_program": (lines["batched"] == lines["cpu"]) if "cpu" in lines else None,
+                           "batched_equals_legacy_program": (lines["batched"] == lines["legacy"]) if "legacy" in lines else None}
+            if any(v is False for v in e["parity"].values()):
+                raise SystemExit("bench[rtl%d]: printed messages differ: %r" % (nch, {k: {c: len(v) for c, v in l.items()} for k, l in lines.items()}))
+            out["ch%d" % nch] = e
+    return out
+
+
 def _short(s, n):
     s = str(s)
     return s if len(s) <= n else s[: n - 3] + "..."
@@ -1054,7 +1206,8 @@ def compact_line(full):
                 "msgs": ms.get("records"), "msgs_exact": ms.get("exact"), "dm_within_1e5_rel": p.get("dm_within_1e5_rel"),
                 "exact_order_identical": (bool(ex.get("dm_bit_identical_to_oracle") and ex.get("blocks_identical_end_to_end")) if ex else None),
                 "end_to_end_differing": (p.get("end_to_end") or {}).get("blocks_differing"), "allowed": (p.get("end_to_end") or {}).get("allowed"),
-                "ref_builds_differing": refs.get("ref_fast_vs_ref_o2_blocks_differing")}
+                "ref_builds_differing": refs.get("ref_fast_vs_ref_o2_blocks_differing"),
+                "gpu_vs_ref_ofast": refs.get("gpu_vs_ref_ofast_blocks_differing")}
 
     def parity_ok(p):
         if not p:
@@ -1062,7 +1215,7 @@ def compact_line(full):
         e = p.get("end_to_end") or {}
         ms = p.get("msgs")
         return bool(p.get("blocks_exact_given_gpu_dm") and p.get("dm_within_1e5_rel") and (ms is None or ms.get("exact"))
-                    and e.get("blocks_differing", 0) <= e.get("allowed", 0))
+                    and e.get("blocks_differing", 0) <= e.get("allowed", 0) and not e.get("gpu_vs_ref_ofast"))
     cfg = full.get("config", {})
     rf = full.get("roofline", {})
     line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -1086,11 +1239,21 @@ def compact_line(full):
             if "error" in a:
                 line["also"][name] = {"error": _short(a["error"], 120)}
                 continue
+            if name == "rtl8":                       # BASELINE configs[1]: ms per 81.92 ms callback, legacy view / batched API / CPU reference
+                line["also"][name] = {"budget_ms": a.get("budget_ms_per_callback")}
+                for k in ("ch8", "ch16"):
+                    c_ = a.get(k) or {}
+                    pv = [v for v in (c_.get("parity") or {}).values() if v is not None]
+                    line["also"][name][k] = {"legacy_ms": c_.get("legacy_ms_per_callback"), "batched_ms": c_.get("batched_ms_per_callback"),
+                                             "cpu_ref_ms": c_.get("cpu_reference_ms_per_callback"), "msgs": c_.get("messages"),
+                                             "parity_ok": (all(pv) if pv else None)}
+                continue
             ar = a.get("roofline", {})
             e = {"value": a.get("value"), "ms_per_step": a.get("ms_per_step"), "channels": a.get("config", {}).get("channels_per_gpu"),
                  "whole_job_frac": a.get("whole_job_frac_of_hbm"), "roofline_frac": ar.get("frac"), "traffic": ar.get("traffic"),
                  "bytes_per_launch": ar.get("bytes_per_launch"), "parity_ok": parity_ok(a.get("parity")),
-                 "blocks": (a.get("parity") or {}).get("blocks"), "e2e_differing": ((a.get("parity") or {}).get("end_to_end") or {}).get("blocks_differing")}
+                 "blocks": (a.get("parity") or {}).get("blocks"), "e2e_differing": ((a.get("parity") or {}).get("end_to_end") or {}).get("blocks_differing"),
+                 "gpu_vs_ref_ofast": ((a.get("parity") or {}).get("end_to_end") or {}).get("gpu_vs_ref_ofast")}
             if a.get("config", {}).get("placement"):
                 e["placement_ms_per_call"] = a["config"]["placement"].get("ms_per_call")
             if "hostfed" in a:
@@ -1174,7 +1337,11 @@ def main():
                          "and the reductions through it on device tensors instead of the world == 1 short-cuts")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-child", nargs=4, default=None)
+    ap.add_argument("--rtl8-cpu-child", nargs=3, default=None)
     args = ap.parse_args()
+    if args.rtl8_cpu_child:
+        rtl8_cpu_child(*args.rtl8_cpu_child)
+        return
     if args.cpu_child:
         v, M, b, s = args.cpu_child
         cpu_baseline_child(v, int(M), int(b), float(s))
@@ -1218,7 +1385,8 @@ def main():
     J.L = K.load()
 
     def fir_kernel_name(M, nout):
-        v = int(os.environ.get("ACG_FIR_VARIANT", "5"))
+        # (the product library knows variant 5 and its fallback only: ACG_FIR_VARIANT means something to the lab build alone)
+        v = int(os.environ.get("ACG_FIR_VARIANT", "5")) if J.L.acg_is_lab_build() else 5
         if (v in (7, 8) or 70 <= v <= 73) and M == 200 and nout % 128 == 0:
             return "fir_u8_coltap_kernel"
         if (v in (5, 7, 8) or 50 <= v <= 55 or 70 <= v <= 73) and M in (160, 192, 200) and nout % 128 == 0:
@@ -1244,10 +1412,11 @@ def main():
     elif overridden or args.format != "u8" or args.share > 1:
         also = []
     else:
-        also = ["wide", "stress", "shard2048", "cs16", "f32", "hostfed"] if world == 1 else ["shard2048"]
+        also = ["wide", "stress", "shard2048", "cs16", "f32", "rtl8", "hostfed"] if world == 1 else ["shard2048"]
         also = [a for a in also if a != args.config]
     with_hostfed = "hostfed" in also
-    also = [a for a in also if a != "hostfed"]
+    with_rtl8 = "rtl8" in also and world == 1
+    also = [a for a in also if a not in ("hostfed", "rtl8")]
     cases = [(args.config, case)] + [(a, dict(CASES[a])) for a in also]
     # with several ranks sharing one GPU (gloo rehearsal) keep the footprint small
     def case_bps(i, c):
@@ -1277,6 +1446,14 @@ def main():
             for r in res:
                 r["roofline"]["pure_reader_GBs_measured_this_run"] = round(gbs.value, 1)
                 r["roofline"]["frac_of_pure_reader"] = round(r["roofline"]["achieved"] / gbs.value, 4)
+        rtl8 = None
+        if with_rtl8:
+            try:
+                rtl8 = run_rtl8(J, args)
+            except SystemExit:
+                raise
+            except Exception as ex:                   # (a missing demo binary or reference build must not take the line with it)
+                rtl8 = {"error": _short(repr(ex), 300)}
         hostfed = None
         if with_hostfed:
             # the hostfed case in a child process with a timeout, after this process has let go of its input buffer
@@ -1322,6 +1499,8 @@ def main():
                     out["also"][name]["per_gpu"] = r["per_gpu"]
         if hostfed is not None:
             out.setdefault("also", {})["hostfed"] = hostfed
+        if rtl8 is not None:
+            out.setdefault("also", {})["rtl8"] = rtl8
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = run_cpu_baseline(case["decim"])
             out["cpu_baseline"]["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)

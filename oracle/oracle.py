@@ -474,18 +474,30 @@ def _ref_blocks_child(variant, path_in, path_out):
     thread does not exist in the child -- ADVICE r03)."""
     import pickle
     z = np.load(path_in)
-    rows, taps, M = z["rows"], z["taps"], int(z["M"])
-    os.dup2(os.open(os.devnull, os.O_WRONLY), 2)          # initRtl narrates on stderr
+    rows, taps, M, front = z["rows"], z["taps"], int(z["M"]), str(z["front"])
+    os.dup2(os.open(os.devnull, os.O_WRONLY), 2)          # init* narrates on stderr
     blk = 1024 * M * 2
     ref = Ref(variant)
+    if front != "rtl":
+        getattr(ref.L, "ref_set_oscillator" if front == "soapy" else "ref_set_wf").argtypes = [C.c_int, C.c_void_p, C.c_int]
     grab = lambda fr: [(int(f.len), int(f.err), bytes(f.crc), bytes(f.txt[: max(0, f.len)])) for f in fr]
     raw, out = [], []
     for c in range(rows.shape[0]):
-        ref.init_rtl(["131.725"], M)                      # one channel; its state is re-initialised by every init
-        ref.set_wf(0, taps[c])
+        t = np.ascontiguousarray(taps[c], dtype=np.float32)
         r = np.ascontiguousarray(rows[c]).reshape(-1)
-        for b in range(r.size // blk):
-            ref.in_callback(r[b * blk:(b + 1) * blk])
+        if front == "rtl":
+            ref.init_rtl(["131.725"], M)                  # one channel; its state is re-initialised by every init
+            ref.set_wf(0, t)
+            for b in range(r.size // blk):
+                ref.in_callback(r[b * blk:(b + 1) * blk])
+        elif front == "soapy":                            # CS16 through the reader loop of soapy.c:220-254, 1000-sample reads
+            ref.init_soapy(["131.725"], M)
+            assert ref.L.ref_set_oscillator(0, t.ctypes.data, t.shape[0]) == 0
+            ref.soapy_feed(r.view(np.int16), 1000)
+        else:                                             # real f32 through rx_callback (air.c:291-341), ragged transfers
+            ref.init_air(["131.725"], INTRATE * M)
+            assert ref.L.ref_set_wf(0, t.ctypes.data, t.shape[0]) == 0
+            ref.air_feed(r.view(np.float32), 50000)
         ref.drain()                                       # blk_thread's pass over what decodeAcars queued (acars.c:93-215)
         raw.append(grab(ref.raw_frames()))
         out.append(grab(ref.out_frames()))
@@ -493,12 +505,14 @@ def _ref_blocks_child(variant, path_in, path_out):
         pickle.dump(dict(raw=raw, out=out), w)
 
 
-def ref_blocks(variant, rows, M, taps, timeout_s=600):
+def ref_blocks(variant, rows, M, taps, timeout_s=600, front="rtl"):
     """The UNMODIFIED reference build `variant` ("" = -O2 IEEE, "_fast" = the reference's own -Ofast -march=native,
-    "_v3") run over rows[c] (u8 I/Q of whole callbacks) with channel c's tap table taps[c], one channel per pass, through
-    its own in_callback -> demodMSK -> decodeAcars -> blk_thread.  Returns {"raw": [...], "out": [...]}: per channel the
-    blocks as decodeAcars queued them and as outputmsg() received them, each (len, err, crc, txt) -- or None when the build
-    is missing or cannot run on this host.  Runs in a child interpreter; rows and taps travel through a temporary file."""
+    "_v3"; front="soapy" / "air": "_soapy" / "_air" and their "_fast" twins) run over rows[c] (whole callbacks of u8 I/Q;
+    CS16 samples; real f32 samples) with channel c's tap table taps[c], one channel per pass, through its own front end
+    (rtl.c in_callback / soapy.c's reader loop / air.c rx_callback) -> demodMSK -> decodeAcars -> blk_thread.  Returns
+    {"raw": [...], "out": [...]}: per channel the blocks as decodeAcars queued them and as outputmsg() received them, each
+    (len, err, crc, txt) -- or None when the build is missing or cannot run on this host.  Runs in a child interpreter; rows
+    and taps travel through a temporary file."""
     import pickle
     import sys
     import tempfile
@@ -510,7 +524,7 @@ def ref_blocks(variant, rows, M, taps, timeout_s=600):
         for c, t in enumerate(taps):
             t = np.ascontiguousarray(t, dtype=np.float32).reshape(-1, 2)
             tp[c, : t.shape[0]] = t
-        np.savez(pin, rows=np.stack([np.ascontiguousarray(r).reshape(-1) for r in rows]), taps=tp, M=M)
+        np.savez(pin, rows=np.stack([np.ascontiguousarray(r).reshape(-1).view(np.uint8) for r in rows]), taps=tp, M=M, front=front)
         code = "import sys; sys.path.insert(0, %r); from oracle import oracle as O; O._ref_blocks_child(%r, %r, %r)" % (
             os.path.dirname(HERE), variant, pin, pout)
         try:

@@ -375,6 +375,17 @@ int ref_get_oscillator(int n, float *out, int M)
 	}
 	return (int)channel[n].Fr;
 }
+/* Overwrites the oscillator table initSoapy built for channel n (soapy.c:163-166) with the caller's, like ref_set_wf on the
+ * rtl.c path: the reference's reader loop on the very table another implementation was given.  Harness only. */
+int ref_set_oscillator(int n, const float *taps, int ntaps)
+{
+	int i;
+	if (n < 0 || (unsigned int)n >= nbch || ntaps < 0 || ntaps > rateMult)
+		return -1;
+	for (i = 0; i < rateMult; i++)
+		channel[n].oscillator[i] = i < ntaps ? taps[2 * i] + taps[2 * i + 1] * I : 0;
+	return 0;
+}
 #endif /* WITH_SOAPY */
 
 #ifdef WITH_SDRPLAY
@@ -505,6 +516,16 @@ int ref_get_wf(int n, float *out, int M)
 	return channel[n].Fr;
 }
 unsigned int ref_air_get_mult(void) { return ref_air_mult(); }
+/* Overwrites the tap table initAirspy built for channel n (air.c:278-285) with the caller's.  Harness only. */
+int ref_set_wf(int n, const float *taps, int ntaps)
+{
+	int i, M = (int)ref_air_mult();
+	if (n < 0 || (unsigned int)n >= nbch || ntaps < 0 || ntaps > M)
+		return -1;
+	for (i = 0; i < M; i++)
+		channel[n].wf[i] = i < ntaps ? taps[2 * i] + taps[2 * i + 1] * I : 0;
+	return 0;
+}
 #endif /* WITH_AIR */
 
 /* sound-file path (soundfile.c:30-56): nch channels of 12.5 kHz real samples */

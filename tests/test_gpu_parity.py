@@ -633,7 +633,7 @@ def test_message_drain_keeps_what_does_not_fit_and_records_are_fully_defined(D, 
     assert len(d4.drain_frames(5)) == 0
     d4.close()
     for m in got:                                               # text beyond txt_len and the reserved fields are zero
-        assert bytes(m.txt[m.txt_len:]) == bytes(242 - m.txt_len) and m.reserved0 == 0.0 and m.reserved1 == 0
+        assert bytes(m.txt[m.txt_len:]) == bytes(242 - m.txt_len) and m.reserved1 == 0 and m.reserved3 == 0 and 0 <= m.soh_sample < m.end_sample
     dec.close()
     dec2.close()
 

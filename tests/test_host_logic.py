@@ -374,14 +374,23 @@ def test_bench_compact_line_stays_under_4k_at_the_full_case_shape():
     for extra in ("shard2048", "hostfed"):
         d["also"][extra] = json.loads(json.dumps(d["also"]["wide"]))
     d["also"]["hostfed"]["hostfed"] = {"h2d_GBs": 55.12, "frac_of_h2d": 0.931, "realtime_10000ch": True, "value_needed_for_realtime": 25000}
+    # round 5: BASELINE configs[1] (ms per callback, legacy view / batched API / CPU reference) and the gate's -Ofast leg per case
+    ch = {"channels": 16, "legacy_first_call_ms": 412.345, "legacy_ms_per_callback": 0.9123, "batched_ms_per_callback": 0.4123,
+          "cpu_reference_ms_per_callback": 12.3456, "messages": 123, "parity": {"legacy_program_equals_cpu_program": True,
+          "batched_equals_cpu_program": True, "batched_equals_legacy_program": True}}
+    d["also"]["rtl8"] = {"workload": "w" * 200, "budget_ms_per_callback": 81.92, "decim": 160, "callbacks": 32, "ch8": dict(ch), "ch16": dict(ch)}
+    for a in [v for k, v in d["also"].items() if k != "rtl8"] + [d]:
+        a["parity"].setdefault("end_to_end", {})["gpu_vs_ref_ofast"] = 0
+        (a["parity"].get("reference_builds") or {}).update(gpu_vs_ref_ofast_blocks_differing=0)
     d["multi_gpu"] = bench.MULTI_GPU_NOTE
     d["per_gpu"] = [1364179.5] * 8
     d["config"].update(delivered="acg_msg records: " + "x" * 300, contexts="one context from acg_create " + "y" * 100)
-    for a in list(d["also"].values()) + [d]:
+    for a in [v for k, v in d["also"].items() if k != "rtl8"] + [d]:
         a["config"]["placement"] = {"ms_per_call": [5.255, 4.527, 4.521, 5.313]}
         a["parity"]["msgs"] = {"records": 762, "exact": True, "delivered": 12000}
-    for a in d["also"].values():
-        a["per_gpu"] = [3047963.0] * 8
+    for k_, a in d["also"].items():
+        if k_ != "rtl8":
+            a["per_gpu"] = [3047963.0] * 8
     line = json.dumps(bench.compact_line(d), separators=(",", ":"))
     assert len(line) < 4096, len(line)
     c = json.loads(line)
@@ -393,8 +402,11 @@ def test_bench_compact_line_stays_under_4k_at_the_full_case_shape():
         assert k in c["roofline"], k
     assert c["cpu_baseline"]["kind"] == "reference" and c["cpu_baseline"]["cores"] == 1 and c["cpu_baseline"]["all_cores"]["processes"] == 64
     assert c["parity"]["exact_given_gpu_dm"] is True and c["parity"]["msgs_exact"] is True and c["parity"]["ref_builds_differing"] == 1
-    assert set(c["also"]) == {"wide", "stress", "cs16", "f32", "shard2048", "hostfed"}
-    assert all(a["parity_ok"] is True and 0 < a["roofline_frac"] < 1 for a in c["also"].values())
+    assert set(c["also"]) == {"wide", "stress", "cs16", "f32", "shard2048", "hostfed", "rtl8"}
+    assert all(a["parity_ok"] is True and 0 < a["roofline_frac"] < 1 and a["gpu_vs_ref_ofast"] == 0 for k_, a in c["also"].items() if k_ != "rtl8")
+    r8 = c["also"]["rtl8"]
+    assert r8["budget_ms"] == 81.92 and r8["ch8"]["parity_ok"] is True and r8["ch16"]["legacy_ms"] == 0.9123 and r8["ch16"]["cpu_ref_ms"] == 12.3456
+    assert c["parity"]["gpu_vs_ref_ofast"] == 0
 
 
 def test_crc_is_the_xor_of_the_syndromes_of_the_set_bits():
