@@ -61,7 +61,10 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
     // dm samples per refill block = how far ahead of its use a block is requested (64 samples = 12 bit periods ~ 10 us:
     // with 32, a demodulator whose dm comes from HBM beside the streaming down-converter -- calls too large for the
     // last-level cache -- waited for its refills: 1024 channels, 36 callbacks per call: 1.04 us per bit instead of 0.89)
-    constexpr int WB = LPC >= 4 ? 64 : 32;
+#ifndef ACG_MSK_WB
+#define ACG_MSK_WB 64
+#endif
+    constexpr int WB = LPC >= 4 ? ACG_MSK_WB : 32;
     constexpr int SPB = WB / LPC;                  // dm samples per lane per refill
     constexpr int WSTR = 2 * WB + 4;               // rows stay 16-byte aligned (b128 refill stores); 4 mod 32 banks apart
     // inb[] of the wave's channels, every sample stored twice (k and k+FLEN) so that the 11 taps of

@@ -81,15 +81,33 @@ def test_bench_also_cases_in_one_line():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     d = last_json(r.stdout)
-    assert set(d["also"]) == {"wide", "stress", "shard2048", "cs16", "f32", "hostfed"}
+    assert set(d["also"]) == {"wide", "stress", "shard2048", "cs16", "f32", "hostfed", "rtl8"}
     hf = d["also"].pop("hostfed")
+    # BASELINE configs[1]: one dongle's 8 (and 16) channels on one 2.0 Msps stream, a callback at a time from host memory --
+    # the legacy view (the reference program on compat_msk.c), the batched API with nstreams = 1, the CPU reference; ms per
+    # callback against the 81.92 ms a callback's signal lasts, and the three printed outputs identical
+    r8 = d["also"].pop("rtl8")
+    assert r8["budget_ms_per_callback"] == 81.92
+    for k in ("ch8", "ch16"):
+        e = r8[k]
+        assert e["messages"] > 0 and e["parity"]["batched_equals_cpu_program"] in (True, None)
+        assert 0 < e["batched_ms_per_callback"] < 81.92
+        if e["parity"]["legacy_program_equals_cpu_program"] is not None:       # the demo binaries travelled
+            assert e["parity"]["legacy_program_equals_cpu_program"] is True and e["parity"]["batched_equals_legacy_program"] is True
+            assert 0 < e["legacy_ms_per_callback"] < 10.0 and e["cpu_reference_ms_per_callback"] > 0
     # the host-fed case: the same records as the _dev entry point on the same bytes, the oracle on the gate channels, and a
     # rate that is a fraction (<= 1, within timer noise) of what a bare host-to-device copy reaches on this box
     assert hf["parity"]["same_records_as_dev_entry_point"] is True and hf["parity"]["blocks_exact_given_gpu_dm"] is True and hf["parity"]["blocks"] > 0
     assert hf["hostfed"]["h2d_GBs_measured"] > 1 and 0 < hf["hostfed"]["frac_of_h2d"] < 1.1 and hf["value"] > 0
     assert hf["config"]["channels_per_gpu"] == 320 and hf["hostfed"]["realtime_needs"] == 320 * 2.5
     c = compact_json(r.stdout)
-    assert set(c["also"]) == set(d["also"]) | {"hostfed"} and all(a["parity_ok"] is True for a in c["also"].values())
+    assert set(c["also"]) == set(d["also"]) | {"hostfed", "rtl8"} and all(a["parity_ok"] is True for k_, a in c["also"].items() if k_ != "rtl8")
+    assert c["also"]["rtl8"]["ch8"]["parity_ok"] is True and c["also"]["rtl8"]["ch16"]["batched_ms"] > 0
+    # every format's gate has its reference-builds leg now (rtl.c / soapy.c / air.c from oracle/_ref) where the builds travelled
+    for name in ("cs16", "f32"):
+        rb = d["also"][name]["parity"]["reference_builds"]
+        if rb is not None:
+            assert rb["oracle_vs_ref_o2_blocks_differing"] == 0 and rb["gpu_vs_ref_ofast_blocks_differing"] == 0
     assert c["also"]["hostfed"]["hostfed"]["realtime"] in (True, False)
     assert c["also"]["shard2048"]["channels"] == 192 and "u8" not in d["also"]["cs16"]["config"]["arithmetic"]
     for name, a in d["also"].items():
