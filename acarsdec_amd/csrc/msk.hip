@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
     L.phi = st->phi; L.df = st->df; L.lvlsum = st->lvlsum;
     L.clk = st->clk; L.bitcount = st->bitcount; L.S = st->S; L.idx = st->idx;
     L.nbits = st->nbits; L.astate = st->astate; L.blen = st->blen; L.berr = st->berr;
-    L.outbits = st->outbits; L.crc0 = st->crc0; L.nbit_total = st->nbit_total; L.soh = st->soh32;
+    L.outbits = st->outbits; L.crc0 = st->crc0; L.nbit_total = st->nbit_total;
     const long long samp0 = st->nsamp_total;
     if (leader) {
 #pragma unroll
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
                 txt[plain ? L.blen : 255] = (unsigned char)r;          // byte 255 of the 256-byte text buffer is scratch (blen <= 241)
                 L.blen += plain ? 1 : 0;
                 L.nbits = hunt ? 1 : (plain ? 8 : L.nbits);
-                if (ev & !hunt & !plain) decode_acars(L, a, ch, txt, samp0 + n - 1, leader);
+                if (ev & !hunt & !plain) decode_acars(L, a, ch, txt, samp0 + n - 1, leader, &st->soh32);
             }
             L.nbit_total++;
             L.S++;
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
         st->phi = p; st->df = L.df; st->lvlsum = L.lvlsum;
         st->clk = L.clk; st->bitcount = L.bitcount; st->S = L.S; st->idx = idx;
         st->nbits = L.nbits; st->astate = L.astate; st->blen = L.blen; st->berr = L.berr;
-        st->outbits = L.outbits; st->crc0 = L.crc0; st->nbit_total = L.nbit_total; st->soh32 = L.soh;
+        st->outbits = L.outbits; st->crc0 = L.crc0; st->nbit_total = L.nbit_total;
         st->nsamp_total = samp0 + len;
 #pragma unroll
         for (int j = 0; j < FLEN; ++j) {

@@ -62,7 +62,7 @@ struct alignas(8) HState {
     int bitcount;
     unsigned int S;
     int nbits, astate, blen, berr;
-    unsigned int outbits, crc0, soh;
+    unsigned int outbits, crc0;
     int nb;
 };
 
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(128 * PAIRS) void msk_demod2_kernel(const MskArgs a
         {
             const HState& h = P.hst[slot];
             L.phi = p; L.df = df; L.lvlsum = h.lvlsum; L.clk = h.clk; L.bitcount = h.bitcount; L.S = h.S; L.idx = idx;
-            L.nbits = h.nbits; L.astate = h.astate; L.blen = h.blen; L.berr = h.berr; L.outbits = h.outbits; L.crc0 = h.crc0; L.soh = h.soh;
+            L.nbits = h.nbits; L.astate = h.astate; L.blen = h.blen; L.berr = h.berr; L.outbits = h.outbits; L.crc0 = h.crc0;
             L.nbit_total = h.nbit_total;
         }
         int nb = P.hst[slot].nb;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(128 * PAIRS) void msk_demod2_kernel(const MskArgs a
                     L.outbits = (L.outbits >> 1) & 0x7fu;                  // putbit, msk.c:53-63
                     if (sv > 0) L.outbits |= 0x80u;
                     L.nbits--;
-                    if (L.nbits <= 0) decode_acars(L, a, ch, txt, samp0 + n - 1, leader);
+                    if (L.nbits <= 0) decode_acars(L, a, ch, txt, samp0 + n - 1, leader, &st->soh32);
                     L.nbit_total++;
                     L.S++;
                     L.df = (double)0.52f * L.df + (1.0 - (double)0.52f) * (double)38e-4f * d.dphi;   // msk.c:130
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(128 * PAIRS) void msk_demod2_kernel(const MskArgs a
             st->phi = p; st->df = L.df; st->lvlsum = L.lvlsum;
             st->clk = L.clk; st->bitcount = L.bitcount; st->S = L.S; st->idx = idx;
             st->nbits = L.nbits; st->astate = L.astate; st->blen = L.blen; st->berr = L.berr;
-            st->outbits = L.outbits; st->crc0 = L.crc0; st->nbit_total = L.nbit_total; st->soh32 = L.soh;
+            st->outbits = L.outbits; st->crc0 = L.crc0; st->nbit_total = L.nbit_total;
             st->nsamp_total = samp0 + len;
 #pragma unroll
             for (int j = 0; j < FLEN; ++j) {
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(128 * PAIRS) void msk_demod2_kernel(const MskArgs a
         L.phi = 0; L.df = st->df; L.lvlsum = st->lvlsum;
         L.clk = st->clk; L.bitcount = st->bitcount; L.S = st->S; L.idx = 0;
         L.nbits = st->nbits; L.astate = st->astate; L.blen = st->blen; L.berr = st->berr;
-        L.outbits = st->outbits; L.crc0 = st->crc0; L.nbit_total = st->nbit_total; L.soh = st->soh32;
+        L.outbits = st->outbits; L.crc0 = st->crc0; L.nbit_total = st->nbit_total;
         float2* bits = a.bits ? a.bits + (size_t)chc * a.bit_cap : (float2*)(txt + 248);     // (no bit log: scratch slot, see msk.hip)
         const int bit_cap = a.bits ? a.bit_cap : 1;
         int nb = (a.bit_append && active) ? a.nbits_out[ch] : 0;
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(128 * PAIRS) void msk_demod2_kernel(const MskArgs a
                     txt[plain ? L.blen : 255] = (unsigned char)r;
                     L.blen += plain ? 1 : 0;
                     L.nbits = hunt ? 1 : (plain ? 8 : L.nbits);
-                    if (ev & !hunt & !plain) decode_acars(L, a, ch, txt, samp0 + prev_end - 1, leader);
+                    if (ev & !hunt & !plain) decode_acars(L, a, ch, txt, samp0 + prev_end - 1, leader, &st->soh32);
                 }
                 L.nbit_total++;
                 L.S++;
@@ -531,14 +531,14 @@ __global__ __launch_bounds__(128 * PAIRS) void msk_demod2_kernel(const MskArgs a
             L.outbits = (L.outbits >> 1) & 0x7fu;
             if (sv > 0) L.outbits |= 0x80u;
             L.nbits--;
-            if (L.nbits <= 0) decode_acars(L, a, ch, txt, samp0 + prev_end - 1, leader);
+            if (L.nbits <= 0) decode_acars(L, a, ch, txt, samp0 + prev_end - 1, leader, &st->soh32);
             L.nbit_total++;
             L.S++;
         }
         if (leader) {
             HState& h = P.hst[slot];
             h.lvlsum = L.lvlsum; h.nbit_total = L.nbit_total; h.clk = L.clk; h.bitcount = L.bitcount; h.S = L.S;
-            h.nbits = L.nbits; h.astate = L.astate; h.blen = L.blen; h.berr = L.berr; h.outbits = L.outbits; h.crc0 = L.crc0; h.soh = L.soh;
+            h.nbits = L.nbits; h.astate = L.astate; h.blen = L.blen; h.berr = L.berr; h.outbits = L.outbits; h.crc0 = L.crc0;
             h.nb = nb;
         }
         __syncthreads();                                                   // T1

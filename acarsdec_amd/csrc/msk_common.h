@@ -29,7 +29,6 @@ struct Lane {
     unsigned int S, idx;
     int nbits, astate, blen, berr;
     unsigned int outbits, crc0;
-    unsigned int soh;           // low 32 bits of the 12.5 kHz sample index at which the block's SOH byte completed
     long long nbit_total;
 };
 
@@ -40,8 +39,12 @@ __device__ __forceinline__ void reset_acars(Lane& L)          // acars.c:239-244
     L.nbits = 1;
 }
 
+// soh_slot = &AcgChan::soh32 of the channel: the SOH stamp lives in the channel's state record in HBM, written and read by the
+// group leader on these rare paths only.  (As a field of Lane it was one more value alive across the per-bit loop: the
+// register allocator of this kernel's recipe started spilling -- ten scratch accesses in the loop, the demodulator alone 0.750
+// -> 0.779 us per bit and 38 % slower beside the down-converter at 4096 channels; round 5, GPU calls 2-4.)
 __device__ __forceinline__ void put_frame(Lane& L, const MskArgs& a, int ch, unsigned char crc1,
-                                          const unsigned char* txt, long long sample_index, bool leader)
+                                          const unsigned char* txt, long long sample_index, bool leader, unsigned int* soh_slot)
 {
     // acars.c:350-369: queue the block.  lvl = 10*log10(MskLvlSum/MskBitCount) is taken on the host
     // from the two operands (same libm call as the reference).
@@ -62,7 +65,7 @@ __device__ __forceinline__ void put_frame(Lane& L, const MskArgs& a, int ch, uns
         f->pad[0] = 0;
         // where the reference stamps the block's time: at its SOH (acars.c:290 gettimeofday(&blk->tv)), as a distance back from
         // the closing bit (a block is < 2^16 samples long: the 32-bit difference is exact across the index's wrap)
-        f->soh_back = (int)((unsigned int)sample_index - L.soh);
+        f->soh_back = (int)((unsigned int)sample_index - *soh_slot);
         const uint4* s = (const uint4*)txt;
         uint4* d = (uint4*)f->txt;
         const int nv = (L.blen + 15) >> 4;
@@ -73,7 +76,7 @@ __device__ __forceinline__ void put_frame(Lane& L, const MskArgs& a, int ch, uns
 }
 
 __device__ __forceinline__ void decode_acars(Lane& L, const MskArgs& a, int ch, unsigned char* txt,
-                                             long long sample_index, bool leader)
+                                             long long sample_index, bool leader, unsigned int* soh_slot)
 {
     const unsigned int r = L.outbits & 0xffu;
     switch (L.astate) {
@@ -95,7 +98,7 @@ __device__ __forceinline__ void decode_acars(Lane& L, const MskArgs& a, int ch, 
             L.nbits = 8;
             L.lvlsum = 0;
             L.bitcount = 0;
-            L.soh = (unsigned int)sample_index;                    // acars.c:290: the block's time stamp is taken here
+            if (leader) *soh_slot = (unsigned int)sample_index;    // acars.c:290: the block's time stamp is taken here
             return;
         }
         reset_acars(L);
@@ -113,7 +116,7 @@ __device__ __forceinline__ void decode_acars(Lane& L, const MskArgs& a, int ch, 
             L.crc0 = txt[L.blen];
             const unsigned char c1 = txt[L.blen + 1];
             L.astate = CRC2;
-            put_frame(L, a, ch, c1, txt, sample_index, leader);
+            put_frame(L, a, ch, c1, txt, sample_index, leader, soh_slot);
             return;
         }
         if (L.blen > 240) { reset_acars(L); return; }
@@ -125,7 +128,7 @@ __device__ __forceinline__ void decode_acars(Lane& L, const MskArgs& a, int ch, 
         L.nbits = 8;
         return;
     case CRC2:                                                 // acars.c:348-369
-        put_frame(L, a, ch, (unsigned char)r, txt, sample_index, leader);
+        put_frame(L, a, ch, (unsigned char)r, txt, sample_index, leader, soh_slot);
         return;
     default:                                                   // END, acars.c:370-373
         reset_acars(L);
