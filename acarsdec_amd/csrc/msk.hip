@@ -53,8 +53,18 @@
 // POLY (run-time flag ACG_F_PRECISE_MIXER, a verification mode like ACG_F_EXACT_FIR): the mixer's sin/cos as the < 1 ulp
 // Cody-Waite + fdlibm-kernel evaluation instead of the 128-entry table + rotation (<= 2.1 ulp).  What the loop keeps are the
 // float-rounded products, and those are the same for both (tests); the flag lets a maintainer see that on his own input.
+// A/B builds only (profiles/probe/build_ab.py; VERDICT r04 item 7, results in profiles/LEDGER.md round 5):
+//   ACG_MSK_AB_EU       the register budget of one wave per SIMD (the kernel never runs more): amdgpu_waves_per_eu(1, 1)
+//   ACG_MSK_AB_COUNTED  a counted inner loop of K bit periods between two looks at the window (K * 6 + 8 <= WB samples: the
+//                       reads of K periods stay inside the two blocks the window holds), no refill test and no wave-wide
+//                       `any lane left` test per period
+#ifdef ACG_MSK_AB_EU
+#define MSK_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(1, 1)))
+#else
+#define MSK_KERNEL_ATTR
+#endif
 template <int LPC, int WPG, bool VEC, bool POLY = false>
-__global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
+__global__ __launch_bounds__(64 * WPG) MSK_KERNEL_ATTR void msk_demod_kernel(const MskArgs a)
 {
     constexpr int CPW = 64 / LPC;                  // channels per wave
     constexpr int SPL = (6 + LPC - 1) / LPC;       // mixer samples per lane per bit period
@@ -197,6 +207,9 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
             refill_at += WB;
             fetch_block(pend_blk);
         }
+#ifdef ACG_MSK_AB_COUNTED
+        for (int period_ = 0; period_ < (WB - 8) / 6; ++period_) {
+#endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // this period's mixer inputs: lane g takes samples n+g, n+g+LPC, ... (issued now, used in B)
@@ -457,6 +470,9 @@ __global__ __launch_bounds__(64 * WPG) void msk_demod_kernel(const MskArgs a)
 #endif
             STAMP(6);                                                      // C4: loop filter
         }
+#ifdef ACG_MSK_AB_COUNTED
+        }
+#endif
     }
 #ifdef ACG_MSK_STAMP
     if (a.stamp && tid == 0) {

@@ -63,9 +63,9 @@ def test_bench_line_contract():
     assert par["end_to_end"]["blocks_differing"] <= par["end_to_end"]["allowed"]
     if par["reference_builds"] is not None:           # oracle/_ref travelled: the reference's two builds on the same bytes
         assert par["reference_builds"]["oracle_vs_ref_o2_blocks_differing"] == 0
-            # no slack: what the reference's own builds differ by, and nothing at all against the reference as shipped (-Ofast)
-            assert par["end_to_end"]["allowed"] == par["reference_builds"]["ref_fast_vs_ref_o2_blocks_differing"]
-            assert par["reference_builds"]["gpu_vs_ref_ofast_blocks_differing"] == 0 and par["end_to_end"]["gpu_vs_ref_ofast"] == 0
+        # no slack: what the reference's own builds differ by, and nothing at all against the reference as shipped (-Ofast)
+        assert par["end_to_end"]["allowed"] == par["reference_builds"]["ref_fast_vs_ref_o2_blocks_differing"]
+        assert par["reference_builds"]["gpu_vs_ref_ofast_blocks_differing"] == 0 and par["end_to_end"]["gpu_vs_ref_ofast"] == 0
     assert d["sustain"]["passes_per_step"] == 1 and d["burst"]["value"] > 0
     assert abs(d["value"] - 256 * 8 * 1024 * 200 * 4 / (d["ms_per_step"] * 4e-3) / 1e6) < 1e-3 * d["value"]
     assert d["time_dominant_kernel"] in ("msk_demod_kernel", d["roofline"]["kernel"]) and 0 < d["whole_job_frac_of_hbm"] < 1
