@@ -54,10 +54,9 @@
 // Cody-Waite + fdlibm-kernel evaluation instead of the 128-entry table + rotation (<= 2.1 ulp).  What the loop keeps are the
 // float-rounded products, and those are the same for both (tests); the flag lets a maintainer see that on his own input.
 // A/B builds only (profiles/probe/build_ab.py; VERDICT r04 item 7, results in profiles/LEDGER.md round 5):
-//   ACG_MSK_AB_EU       the register budget of one wave per SIMD (the kernel never runs more): amdgpu_waves_per_eu(1, 1)
-//   ACG_MSK_AB_COUNTED  a counted inner loop of K bit periods between two looks at the window (K * 6 + 8 <= WB samples: the
-//                       reads of K periods stay inside the two blocks the window holds), no refill test and no wave-wide
-//                       `any lane left` test per period
+//   ACG_MSK_AB_EU         the register budget of one wave per SIMD (the kernel never runs more): amdgpu_waves_per_eu(1, 1) -- the same
+//                         instruction stream in higher registers, nothing alone, -6 % at 4096 channels beside the down-converter
+//   ACG_MSK_AB_UNCOUNTED  round 4's loop: the window test and the wave-wide `any lane left` test before EVERY bit period
 #ifdef ACG_MSK_AB_EU
 #define MSK_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(1, 1)))
 #else
@@ -207,8 +206,16 @@ __global__ __launch_bounds__(64 * WPG) MSK_KERNEL_ATTR void msk_demod_kernel(con
             refill_at += WB;
             fetch_block(pend_blk);
         }
-#ifdef ACG_MSK_AB_COUNTED
-        for (int period_ = 0; period_ < (WB - 8) / 6; ++period_) {
+        // ---- K bit periods between two looks at the window and at `is any lane left` (round 5: 0.762 -> 0.725 us per bit alone,
+        // +6 % on the headline).  A period consumes <= 6 samples and reads <= 8 ahead of its start, the window holds two blocks of
+        // WB samples: with 6 K <= WB - 1 the reads of K periods that start in the older block end inside the newer one, and after
+        // a refill (n at most 6 K into the newer block) inside the block just stored (12 K <= 2 WB - 1).  The loop counter and
+        // its branch are scalar; the per-period `v_cmp -> vcc -> branch` round trip of the old loop is gone.  Lanes past their
+        // len idle through the remaining periods (cnt = 0: no sample, no bit, the mixer writes its scratch row).
+#ifndef ACG_MSK_AB_UNCOUNTED
+        constexpr int PERIODS = (WB - 8) / 6;          // 9 (WB 64), 4 (WB 32)
+        static_assert(6 * PERIODS <= WB - 1 && 12 * PERIODS <= 2 * WB - 1, "the counted periods must stay inside the dm window");
+        for (int period_ = 0; period_ < PERIODS; ++period_) {
 #endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -470,7 +477,7 @@ __global__ __launch_bounds__(64 * WPG) MSK_KERNEL_ATTR void msk_demod_kernel(con
 #endif
             STAMP(6);                                                      // C4: loop filter
         }
-#ifdef ACG_MSK_AB_COUNTED
+#ifndef ACG_MSK_AB_UNCOUNTED
         }
 #endif
     }
