@@ -251,6 +251,20 @@ def make_taps(D, fmt_name, offs, M, ntaps):
     return taps
 
 
+def lookup_traffic(kernel, nch, M, ntaps, blocks_per_launch):
+    """HBM bytes of one launch of this shape from the committed PMC passes (profiles/pmc_traffic.json: separate rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE runs of the same command; rocprofv3 cannot run inside the timed process): (bytes, source) or (None, None)"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            for e in json.load(f)["entries"]:
+                if (e["channels"], e["decim"], e["ntaps"]) == (nch, M, ntaps) and abs(e["blocks_per_launch"] - blocks_per_launch) < 1e-9 \
+                        and e["kernel"] == kernel:
+                    return e["traffic_bytes"], e.get("source", "profiles/pmc_traffic.json")
+    except Exception:
+        pass
+    return None, None
+
+
 def _probe_ab(args, J, step, drain, steps, nch, nout, M):
     """measurement aid (--ab): the same decoder, buffers and placement, timed again under each value of a per-launch switch in
     turn (acg_tune: ACG_FIR_VARIANT, ACG_MSK_LPC_LIVE, ...), two rounds -- not part of the reported value"""
@@ -787,15 +801,7 @@ def run_case(J, name, case, args, steps, warmup, headline):
         kname = ("fir_fmt_direct_kernel<%d, %d, %d>" % ((fid,) + shape)) if shape else "fir_fmt_kernel<%d>" % fid
     # HBM traffic of this launch shape from the committed PMC passes (rocprofv3 cannot run inside the timed
     # process): looked up by the full kernel signature and launch shape, not measured in this run -- the source is named next to the number
-    traffic, traffic_src = None, None
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            for e in json.load(f)["entries"]:
-                if share == 1 and (e["channels"], e["decim"], e["ntaps"]) == (nch, M, ntaps) \
-                        and abs(e["blocks_per_launch"] - nblk / lps) < 1e-9 and e["kernel"] == kname:
-                    traffic, traffic_src = e["traffic_bytes"], e.get("source", "profiles/pmc_traffic.json")
-    except Exception:
-        pass
+    traffic, traffic_src = lookup_traffic(kname, nch, M, ntaps, nblk / lps) if share == 1 else (None, None)
     whole = step_bytes * steps / dt / 1e9                            # per GPU
     out = {
         "value": round(value, 1),
@@ -1034,7 +1040,10 @@ def run_hostfed(J, args, steps, warmup):
         "hostfed": {"input_GBs": round(in_gbs, 2), "h2d_GBs_measured": round(h2d, 2), "frac_of_h2d": round(in_gbs / h2d, 4),
                     "realtime_needs": need, "realtime": bool(value >= need), "pin_and_fill_s": round(pin_s, 2)},
         "roofline": {"bound": "hbm", "kernel": J.fir_kernel_name(M, cb * 1024), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "bytes_per_launch": int(fir_bytes * ncalls / max(1, tim["fir_launches"])),
+                     "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": lookup_traffic(J.fir_kernel_name(M, cb * 1024), nch, M, ntaps, cb * ncalls / max(1, tim["fir_launches"]))[0],
+                     "bytes_per_launch": int(fir_bytes * ncalls / max(1, tim["fir_launches"])),
+                     "launches_per_pass": max(1, tim["fir_launches"] // max(1, steps * reps)),
                      "avg_launch_ms": round(fir_avg_ms, 4), "launches_per_step": tim["fir_launches"] // steps,
                      "note": "the kernel's own launches (event-timed) while the NEXT call's host-to-device copy runs beside them; the job is bound by the link, not by this kernel"},
         "parity": parity,
@@ -1335,6 +1344,11 @@ def main():
     ap.add_argument("--rccl-selftest", action="store_true",
                     help="with --gpus 1: initialise torch.distributed (nccl = RCCL) with world size 1 and send the channel scatter, the barriers "
                          "and the reductions through it on device tensors instead of the world == 1 short-cuts")
+    ap.add_argument("--cooldown", type=float, default=3.0,
+                    help="idle seconds between two cases of one invocation.  The cases that saturate HBM hold the chip at its 1400 W cap "
+                         "(shader clock 1.64 GHz); a case that starts right behind one inherits that state for its first seconds, and "
+                         "the demodulator-bound cases follow the shader clock (round 5: 2048 channels 0.57 of HBM right behind the "
+                         "4096-channel case, 0.60-0.63 from an idle chip).  Every case is still timed for >= --sustain seconds.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-child", nargs=4, default=None)
     ap.add_argument("--rtl8-cpu-child", nargs=3, default=None)
@@ -1412,7 +1426,9 @@ def main():
     elif overridden or args.format != "u8" or args.share > 1:
         also = []
     else:
-        also = ["wide", "stress", "shard2048", "cs16", "f32", "rtl8", "hostfed"] if world == 1 else ["shard2048"]
+        # (order: the two cases whose step the demodulator sets -- they follow the shader clock -- before the cases that saturate
+        #  HBM and run the chip into its power cap: see --cooldown)
+        also = ["shard2048", "wide", "stress", "cs16", "f32", "rtl8", "hostfed"] if world == 1 else ["shard2048"]
         also = [a for a in also if a != args.config]
     with_hostfed = "hostfed" in also
     with_rtl8 = "rtl8" in also and world == 1
@@ -1433,7 +1449,12 @@ def main():
 
     res = []
     for i, (name, c) in enumerate(cases):
+        if i and args.cooldown > 0:
+            torch.cuda.synchronize()
+            time.sleep(args.cooldown)
         res.append(run_case(J, name, c, args, args.steps, args.warmup, headline=(i == 0)))
+        if res[-1] is not None:
+            res[-1]["config"]["cooldown_before_s"] = args.cooldown if i else 0.0
 
     if rank == 0:
         head = res[0]
