@@ -324,11 +324,14 @@ extern "C" int acg_launch_blk_repair(AcgFrameRec* frames, unsigned int cap, cons
                                      unsigned int* done_upto, unsigned int* done_ctr, const unsigned short* synd,
                                      const unsigned short* crctab, int nch, void* stream)
 {
-    // a wave per block, the waves looping over the call's blocks (about one per channel per call of 8 callbacks): one wave per 8
-    // channels, 128 ... 1024 waves -- enough that the pass keeps up with the calls at every width (64 waves did not at 2048
-    // channels), small enough not to crowd the demodulator's CUs at 1024 (1024 waves, most of them finding nothing, did)
-    int wgs = nch / (8 * BLK_WAVES);
-    wgs = wgs < 32 ? 32 : wgs > 256 ? 256 : wgs;
+    // a wave per block, the waves looping over the call's blocks (0.6 - 1 per channel per call of 8 callbacks): one wave per 2
+    // channels, 128 ... 2048 waves.  With the searches done 64 candidates at a time a block costs its two or three dependent
+    // memory round trips (a few microseconds each beside the streaming down-converter) and nothing else, so what sets the
+    // pass is how many blocks a wave takes one after the other: at one wave per 8 channels (round 4's grid, sized for waves
+    // that could sit on a SIMD for a millisecond) the pass took 90 - 105 us and 3.4 - 4.2 % of the GPU time
+    // (profiles/r05_*_stats_call8.txt); an empty pass is 25 us (table to LDS, the mark from host memory).
+    int wgs = nch / (2 * BLK_WAVES);
+    wgs = wgs < 32 ? 32 : wgs > 512 ? 512 : wgs;
     hipLaunchKernelGGL(blk_repair_kernel, dim3(wgs), dim3(64 * BLK_WAVES), 0, (hipStream_t)stream, frames, cap, upto, done_upto, done_ctr, synd, crctab);
     return (int)hipGetLastError();
 }

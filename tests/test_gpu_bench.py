@@ -60,8 +60,9 @@ def test_bench_line_contract():
     assert par["channels_checked"] == 64 and "bit_exact" not in par
     # the exact-order mode closes the argument: same GPU demodulator, dm bit-identical to the oracle -> end to end identical
     assert par["exact_order_mode"]["dm_bit_identical_to_oracle"] is True and par["exact_order_mode"]["blocks_identical_end_to_end"] is True
-    assert par["end_to_end"]["blocks_differing"] <= par["end_to_end"]["allowed"]
-    if par["reference_builds"] is not None:           # oracle/_ref travelled: the reference's two builds on the same bytes
+    assert (par["end_to_end"]["allowed"] is None) == (par["reference_builds"] is None)     # (without the builds: reported, not gated)
+    if par["reference_builds"] is not None:
+        assert par["end_to_end"]["blocks_differing"] <= par["end_to_end"]["allowed"]           # oracle/_ref travelled: the reference's two builds on the same bytes
         assert par["reference_builds"]["oracle_vs_ref_o2_blocks_differing"] == 0
         # no slack: what the reference's own builds differ by, and nothing at all against the reference as shipped (-Ofast)
         assert par["end_to_end"]["allowed"] == par["reference_builds"]["ref_fast_vs_ref_o2_blocks_differing"]
