@@ -73,21 +73,40 @@ __global__ __launch_bounds__(64 * BLK_WAVES) void blk_repair_kernel(AcgFrameRec*
     const unsigned int lo = (hi - from > cap) ? hi - cap : from;
     const int lane = threadIdx.x & 63;
     const unsigned int wave = blockIdx.x * BLK_WAVES + (threadIdx.x >> 6), nwaves = gridDim.x * BLK_WAVES;
+    // Everything a block needs from memory is requested at once -- its length, all 256 bytes of its text row (what lies beyond
+    // len is masked below, the row is always there) and the two CRC bytes: ONE round trip per block instead of three dependent
+    // ones (length -> text -> CRC bytes), each a few microseconds beside the streaming down-converter -- and the request for the
+    // wave's NEXT block is in flight while it works on this one.
+    unsigned int nraw[4] = {0, 0, 0, 0}, ncrcb = 0;
+    int nlen = 0;
+    auto request = [&](unsigned int q_) {
+        const AcgFrameRec* g_ = frames + (q_ & (cap - 1));                  // (cap is a power of two)
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) nraw[s_] = g_->txt[lane + 64 * s_];
+        ncrcb = g_->crc[lane & 1];
+        nlen = g_->len;
+    };
+    if (lo + wave - lo < hi - lo) request(lo + wave);
     for (unsigned int q = lo + wave; q - lo < hi - lo; q += nwaves) {      // (q is wave-uniform: no divergence around the ballots)
-        AcgFrameRec* f = frames + (q & (cap - 1));                          // (cap is a power of two)
-        const int len = f->len;
+        AcgFrameRec* f = frames + (q & (cap - 1));
+        unsigned char* txt = f->txt;
+        unsigned int raw[4];
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) raw[s_] = nraw[s_];
+        const unsigned int crcb = ncrcb;
+        const int len = nlen;
+        if (q + nwaves - lo < hi - lo) request(q + nwaves);
         if (len < 13) {                                                    // acars.c:124
             if (lane == 0) f->status = 2;
             continue;
         }
-        unsigned char* txt = f->txt;
         unsigned int c[4];
         bool have[4];
 #pragma unroll
         for (int s_ = 0; s_ < 4; ++s_) {
             const int i = lane + 64 * s_;
             have[s_] = i < len;                                            // (len <= 250)
-            c[s_] = have[s_] ? txt[i] : 0u;
+            c[s_] = have[s_] ? raw[s_] : 0u;
         }
         if (lane == 12) c[0] = (c[0] & (ETX | STX)) | (ETX & STX);         // acars.c:132-133
         // parity errors (acars.c:136-144) and the CRC over text + the two CRC bytes (acars.c:159-165)
@@ -98,7 +117,7 @@ __global__ __launch_bounds__(64 * BLK_WAVES) void blk_repair_kernel(AcgFrameRec*
             bad[s_] = __ballot(have[s_] && (__popc(c[s_]) & 1) == 0);
             if (have[s_]) x ^= synd_of_bits(synd, c[s_], 8 * (len - (lane + 64 * s_) + 1));
         }
-        if (lane < 2) x ^= synd_of_bits(synd, f->crc[lane], 8 * (1 - lane));
+        if (lane < 2) x ^= synd_of_bits(synd, crcb, 8 * (1 - lane));
 #pragma unroll
         for (int off = 32; off; off >>= 1) x ^= (unsigned int)__shfl_xor((int)x, off);
         const unsigned short crc = (unsigned short)x;
@@ -324,14 +343,13 @@ extern "C" int acg_launch_blk_repair(AcgFrameRec* frames, unsigned int cap, cons
                                      unsigned int* done_upto, unsigned int* done_ctr, const unsigned short* synd,
                                      const unsigned short* crctab, int nch, void* stream)
 {
-    // a wave per block, the waves looping over the call's blocks (0.6 - 1 per channel per call of 8 callbacks): one wave per 2
-    // channels, 128 ... 2048 waves.  With the searches done 64 candidates at a time a block costs its two or three dependent
-    // memory round trips (a few microseconds each beside the streaming down-converter) and nothing else, so what sets the
-    // pass is how many blocks a wave takes one after the other: at one wave per 8 channels (round 4's grid, sized for waves
-    // that could sit on a SIMD for a millisecond) the pass took 90 - 105 us and 3.4 - 4.2 % of the GPU time
-    // (profiles/r05_*_stats_call8.txt); an empty pass is 25 us (table to LDS, the mark from host memory).
-    int wgs = nch / (2 * BLK_WAVES);
-    wgs = wgs < 32 ? 32 : wgs > 512 ? 512 : wgs;
+    // a wave per block, the waves looping over the call's blocks (0.6 - 1 per channel per call of 8 callbacks): one wave per 8
+    // channels, 128 ... 1024 waves -- enough that the pass keeps up with the calls at every width, small enough not to crowd
+    // the CUs: round 5 tried one wave per 2 channels and the pass got SLOWER (88 -> 97 us at 1024 channels, 105 -> 141 us at
+    // 2048, 111 -> 201 us at 4096: profiles/r05_*_stats_call9_wave_per_2_channels.txt) -- what a pass costs is workgroups finding
+    // a place beside the down-converter and filling their table, not the handful of blocks a wave takes one after the other.
+    int wgs = nch / (8 * BLK_WAVES);
+    wgs = wgs < 32 ? 32 : wgs > 256 ? 256 : wgs;
     hipLaunchKernelGGL(blk_repair_kernel, dim3(wgs), dim3(64 * BLK_WAVES), 0, (hipStream_t)stream, frames, cap, upto, done_upto, done_ctr, synd, crctab);
     return (int)hipGetLastError();
 }
