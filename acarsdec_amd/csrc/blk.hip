@@ -61,10 +61,18 @@ __global__ __launch_bounds__(64 * BLK_WAVES) void blk_repair_kernel(AcgFrameRec*
     //  streaming down-converter and a block took ~50 us per wave: the pass fell behind the calls at 2048 channels, call 9)
     (void)crctab_g;
     __shared__ unsigned short synd[NSYND];
-    for (int i = threadIdx.x; i < NSYND; i += 64 * BLK_WAVES) synd[i] = synd_g[i];
-    __syncthreads();
+    // The pass's fixed cost is a chain of memory round trips beside a down-converter that saturates HBM (a few microseconds
+    // each): the marks, the table, the first block.  They are requested in that order WITHOUT waiting in between: the two marks
+    // first, the table's rows while those are in flight, the wave's first block as soon as the marks say which one it is, and
+    // only then the barrier behind which the table is needed.
     const unsigned int mark = __hip_atomic_load(upto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const unsigned int from = *done_upto;
+    unsigned short trow[(NSYND + 64 * BLK_WAVES - 1) / (64 * BLK_WAVES)];
+#pragma unroll
+    for (int k = 0; k < (NSYND + 64 * BLK_WAVES - 1) / (64 * BLK_WAVES); ++k) {
+        const int i = threadIdx.x + k * 64 * BLK_WAVES;
+        trow[k] = i < NSYND ? synd_g[i] : (unsigned short)0;
+    }
     // A mark at or BEHIND what has been processed means nothing to do (the counters are monotonic and wrap: a signed
     // difference).  It cannot move the pass backwards: re-processing blocks whose parity has already been stripped would
     // fail their parity check and drop valid messages (a pass that reads a mark word which a later call
@@ -75,8 +83,7 @@ __global__ __launch_bounds__(64 * BLK_WAVES) void blk_repair_kernel(AcgFrameRec*
     const unsigned int wave = blockIdx.x * BLK_WAVES + (threadIdx.x >> 6), nwaves = gridDim.x * BLK_WAVES;
     // Everything a block needs from memory is requested at once -- its length, all 256 bytes of its text row (what lies beyond
     // len is masked below, the row is always there) and the two CRC bytes: ONE round trip per block instead of three dependent
-    // ones (length -> text -> CRC bytes), each a few microseconds beside the streaming down-converter -- and the request for the
-    // wave's NEXT block is in flight while it works on this one.
+    // ones (length -> text -> CRC bytes) -- and the request for the wave's NEXT block is in flight while it works on this one.
     unsigned int nraw[4] = {0, 0, 0, 0}, ncrcb = 0;
     int nlen = 0;
     auto request = [&](unsigned int q_) {
@@ -86,7 +93,13 @@ __global__ __launch_bounds__(64 * BLK_WAVES) void blk_repair_kernel(AcgFrameRec*
         ncrcb = g_->crc[lane & 1];
         nlen = g_->len;
     };
-    if (lo + wave - lo < hi - lo) request(lo + wave);
+    if (wave < hi - lo) request(lo + wave);
+#pragma unroll
+    for (int k = 0; k < (NSYND + 64 * BLK_WAVES - 1) / (64 * BLK_WAVES); ++k) {
+        const int i = threadIdx.x + k * 64 * BLK_WAVES;
+        if (i < NSYND) synd[i] = trow[k];
+    }
+    __syncthreads();
     for (unsigned int q = lo + wave; q - lo < hi - lo; q += nwaves) {      // (q is wave-uniform: no divergence around the ballots)
         AcgFrameRec* f = frames + (q & (cap - 1));
         unsigned char* txt = f->txt;

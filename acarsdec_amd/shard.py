@@ -4,9 +4,10 @@ Channels are independent units: a channel's down-converter and demodulator state
 another channel's, so the multi-GPU path is a pure partition -- rank r owns channels
 {c : c mod world == r} (BASELINE.json configs[3]: "sharded round-robin"), generates/receives its
 own input and keeps its own state.  There is NO data-path collective.  torch.distributed (RCCL on
-GPUs, gloo in the CPU tests) carries only the trivial exchanges: the scatter of per-channel
-configuration from rank 0, the barrier around the timed region and the reduction/gather of
-counts, timings and decoded blocks.
+GPUs, gloo in the CPU tests) carries only the trivial exchanges: the per-channel configuration from
+rank 0 (ONE BROADCAST of the whole table, 32 B per channel, from which every rank keeps its own rows --
+not an ncclSend/Recv scatter: 0.5 MB at 16 384 channels is not worth one), the barrier around the
+timed region and the reduction/gather of counts, timings and decoded blocks.
 """
 import numpy as np
 
@@ -26,8 +27,8 @@ def local_index(channel, world):
 
 def scatter_channel_config(cfg_rows, world, rank, dist=None, src=0, device=None, force=False):
     """Rank `src` holds one config row per GLOBAL channel (e.g. [offset_hz, phase, track, id]); every
-    rank ends up with the rows of the channels it owns.  The table is tiny (32 B per channel), so it
-    is sent with the most basic collective -- one broadcast -- and sliced locally; the same code
+    rank ends up with the rows of the channels it owns.  The name says what the caller gets; the transport is a BROADCAST:
+    the table is tiny (32 B per channel), so it is sent whole with the most basic collective and sliced locally; the same code
     runs over gloo (CPU tests) and RCCL (device tensors).  cfg_rows may be None on other ranks.
     force: go through the collective even with world == 1 (bench.py --rccl-selftest: the RCCL path on a one-GPU box)."""
     if dist is None or (world == 1 and not force):

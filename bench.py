@@ -25,7 +25,7 @@ printed on an EARLIER line prefixed "# bench_detail: " and written to bench_deta
 Multi-GPU: `python bench.py --gpus N` launches N ranks itself (torch.distributed.run, one rank per GPU,
 backend nccl = RCCL); started under torchrun it uses the ranks it is given.  Channels are independent
 (SURVEY 8e): rank r owns channels c = r (mod N), generates its input locally and keeps its own state;
-there is no data-path collective.  RCCL carries the scatter of the per-channel configuration, the
+there is no data-path collective.  RCCL carries the broadcast of the per-channel configuration table (32 B per channel; every rank keeps its rows), the
 barriers around the timed region and the reductions of time and counts (scaling: weak).
 """
 import argparse
@@ -1064,7 +1064,7 @@ def run_hostfed(J, args, steps, warmup):
 
 
 MULTI_GPU_NOTE = ("no N>1 run has been measured by the builder (1-GPU boxes only): --gpus N shards channel c to rank c mod N "
-                  "(weak scaling, no data-path collective; RCCL carries the 32 B/channel config scatter, barriers and reductions)")
+                  "(weak scaling, no data-path collective; RCCL carries the 32 B/channel config-table broadcast, barriers and reductions)")
 
 
 # ------------------------------------------------------------------------------------------ BASELINE configs[1]: the rtl.c shape
