@@ -449,6 +449,15 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
                 HIPCHK(c, hipEventCreateWithFlags(&c->fir_in, hipEventDisableTiming));
                 HIPCHK(c, hipEventCreateWithFlags(&c->fir_out, hipEventDisableTiming));
                 c->fir_ncu = total - ncu;
+                // The block repair's stream on the DOWN-CONVERTER's side of the partition (ACG_POST_MASK=0: no mask, round 4's
+                // shape).  Without a mask its workgroups go where the most resources are free -- the demodulator's CUs, one wave
+                // per SIMD -- and there a wave at normal priority gets the fifth of the issue slots the demodulator's waves
+                // (s_setprio 3, issue-bound) leave over, while taking cycles from the stage that sets the step.  The
+                // down-converter's waves wait for memory most of the time.  (Round 4 masked this stream TOGETHER with the
+                // result-copy stream and lost 6-10 %: that was the copies turning into blit kernels; this stream carries one
+                // kernel and event waits, no copies.)
+                if ((cfg->flags & ACG_F_REPAIR) && acg_tune_get("ACG_POST_MASK", 1))
+                    HIPCHK(c, hipExtStreamCreateWithCUMask(&c->post_stream, (uint32_t)mask_words, fm.data()));
             } else {
                 // a stream of its own priority class gets a hardware queue of its own
                 int lo = 0, hi = 0;
@@ -509,7 +518,7 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
             HIPCHK(c, hipMemcpy(c->d_crctab, tabs.data(), tabs.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
             HIPCHK(c, hipMalloc(&c->d_rep_upto, 2 * sizeof(unsigned int)));       // {blocks through the pass, workgroups finished}
             HIPCHK(c, hipMemset(c->d_rep_upto, 0, 2 * sizeof(unsigned int)));
-            HIPCHK(c, hipStreamCreateWithFlags(&c->post_stream, hipStreamNonBlocking));
+            if (!c->post_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->post_stream, hipStreamNonBlocking));
             for (auto& e : c->msk_end) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         }
         float h[136] = {0};
