@@ -449,14 +449,14 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
                 HIPCHK(c, hipEventCreateWithFlags(&c->fir_in, hipEventDisableTiming));
                 HIPCHK(c, hipEventCreateWithFlags(&c->fir_out, hipEventDisableTiming));
                 c->fir_ncu = total - ncu;
-                // The block repair's stream on the DOWN-CONVERTER's side of the partition (ACG_POST_MASK=0: no mask, round 4's
-                // shape).  Without a mask its workgroups go where the most resources are free -- the demodulator's CUs, one wave
-                // per SIMD -- and there a wave at normal priority gets the fifth of the issue slots the demodulator's waves
-                // (s_setprio 3, issue-bound) leave over, while taking cycles from the stage that sets the step.  The
-                // down-converter's waves wait for memory most of the time.  (Round 4 masked this stream TOGETHER with the
-                // result-copy stream and lost 6-10 %: that was the copies turning into blit kernels; this stream carries one
-                // kernel and event waits, no copies.)
-                if ((cfg->flags & ACG_F_REPAIR) && acg_tune_get("ACG_POST_MASK", 1))
+                // Measurement switch ACG_POST_MASK=1: the block repair's stream on the DOWN-CONVERTER's side of the partition.
+                // Without a mask its workgroups go where the most resources are free -- the demodulator's CUs, one wave per SIMD
+                // -- and get the fifth of the issue slots the demodulator's waves (s_setprio 3, issue-bound) leave over: the pass
+                // takes 78 / 97 us (1024 / 2048 channels) instead of 47 / 68 us with the mask, 3.8 / 3.1 % of the GPU time
+                // instead of 2.3 / 2.2 %.  But the WHOLE JOB is faster without it -- 1.422 M against 1.418 M at 1024 channels,
+                // 0.611 against 0.591 of HBM at 2048, two alternating runs each on one box (profiles/r05_post_mask_ab.txt) -- and
+                // the whole job is what a host gets: no mask.
+                if ((cfg->flags & ACG_F_REPAIR) && acg_tune_get("ACG_POST_MASK", 0))
                     HIPCHK(c, hipExtStreamCreateWithCUMask(&c->post_stream, (uint32_t)mask_words, fm.data()));
             } else {
                 // a stream of its own priority class gets a hardware queue of its own
