@@ -253,3 +253,21 @@ def test_compat_rtl_program_with_16_channels_equals_its_cpu_twin(S, tmp_path):
     assert stats and int(stats.group(1)) == nblk
     # a callback carries 81.92 ms of signal (rtl.c:49,213): the legacy view must stay far inside that budget
     assert float(stats.group(2)) < 20.0, stats.group(0)
+
+
+def test_host_entry_points_do_not_share_a_carried_window(D, S):
+    """acg_feed_samples_host keeps the samples of an incomplete window at the head of the two staging buffers that
+    acg_process_iq_u8_host uses as well.  While a partial window is carried, the u8 entry point refuses (ACG_ESTATE) instead of
+    overwriting it; after acg_reset (which drops the carry) it works again."""
+    from acarsdec_amd import _capi as K
+    M = 160
+    dec = D.Decoder(2, decim=M, nstreams=2, max_blocks=1, bitlog=False)
+    x = (np.arange(2 * (M + 37) * 2, dtype=np.int16) % 97).reshape(2, -1)          # one window and 37 samples per stream
+    assert dec.L.acg_feed_samples_host(dec.ctx, K.FMT_CS16, x.ctypes.data, None, M + 37, M + 37) == K.OK
+    iq = np.zeros((2, 1024 * M * 2), dtype=np.uint8)
+    assert dec.L.acg_process_iq_u8_host(dec.ctx, iq.ctypes.data, iq.shape[1], 1) == K.ESTATE
+    assert b"partial window" in dec.L.acg_last_error(dec.ctx)
+    dec.reset()
+    assert dec.L.acg_process_iq_u8_host(dec.ctx, iq.ctypes.data, iq.shape[1], 1) == K.OK
+    assert dec.drain_frames() == []
+    dec.close()
