@@ -57,6 +57,16 @@
 //   ACG_MSK_AB_EU         the register budget of one wave per SIMD (the kernel never runs more): amdgpu_waves_per_eu(1, 1) -- the same
 //                         instruction stream in higher registers, nothing alone, -6 % at 4096 channels beside the down-converter
 //   ACG_MSK_AB_UNCOUNTED  round 4's loop: the window test and the wave-wide `any lane left` test before EVERY bit period
+//   ACG_MSK_AB_EXPECT     branch weights on the three branches of the per-bit path (quick period: likely; bit fired: likely; framing
+//                         state machine beyond its two fast paths: unlikely), so that the block placement keeps the common path
+//                         fall-through
+#ifdef ACG_MSK_AB_EXPECT
+#define MSK_LIKELY(x) __builtin_expect(!!(x), 1)
+#define MSK_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#else
+#define MSK_LIKELY(x) (x)
+#define MSK_UNLIKELY(x) (x)
+#endif
 #ifdef ACG_MSK_AB_EU
 #define MSK_KERNEL_ATTR __attribute__((amdgpu_waves_per_eu(1, 1)))
 #else
@@ -251,7 +261,7 @@ __global__ __launch_bounds__(64 * WPG) MSK_KERNEL_ATTR void msk_demod_kernel(con
         // (six samples left in the buffer: the last few samples of a call go through the one-sample pass, so that the
         //  fifth step below needs no end-of-buffer predicate on the serial phase / clock chains: 3.5 % per bit)
         const bool quick = (s > 0) && !((double)c4 >= thr) && (n + 6 <= len);
-        if (n < len && quick) {
+        if (MSK_LIKELY(n < len && quick)) {
 #ifdef ACG_MSK_AB_PICK_EXEC
                 // A/B build only: the per-lane phase pick as an EXEC-masked 64-bit move (1 VALU + 2 SALU) instead of the two
                 // v_cndmask_b32 the compiler makes of the select
@@ -392,7 +402,7 @@ __global__ __launch_bounds__(64 * WPG) MSK_KERNEL_ATTR void msk_demod_kernel(con
         __builtin_amdgcn_wave_barrier();
         STAMP(2);                                                          // B
         // ---- C: bit decision (replicated; side effects by the group leader only)
-        if (fired) {
+        if (MSK_LIKELY(fired)) {
 #ifdef ACG_MSK_STAMP
             ++stamp_bits;
 #endif
@@ -463,7 +473,7 @@ __global__ __launch_bounds__(64 * WPG) MSK_KERNEL_ATTR void msk_demod_kernel(con
                 txt[plain ? L.blen : 255] = (unsigned char)r;          // byte 255 of the 256-byte text buffer is scratch (blen <= 241)
                 L.blen += plain ? 1 : 0;
                 L.nbits = hunt ? 1 : (plain ? 8 : L.nbits);
-                if (ev & !hunt & !plain) decode_acars(L, a, ch, txt, samp0 + n - 1, leader, &st->soh32);
+                if (MSK_UNLIKELY(ev & !hunt & !plain)) decode_acars(L, a, ch, txt, samp0 + n - 1, leader, &st->soh32);
             }
             L.nbit_total++;
             L.S++;
