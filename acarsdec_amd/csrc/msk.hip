@@ -202,9 +202,6 @@ __global__ __launch_bounds__(64 * WPG) MSK_KERNEL_ATTR void msk_demod_kernel(con
 #endif
 
     while (__any(n < len)) {
-#ifdef ACG_MSK_STAMP
-        ++stamp_iters;
-#endif
         // ---- window upkeep (rare: once per 32 samples per channel)
         // (measured and left out: looking at the refill condition only every 8th pass, so that the channels of a wave
         //  refill together -- 8 instructions fewer per pass, 0.8 % SLOWER; dropping the per-bit counters that can be derived
@@ -226,6 +223,9 @@ __global__ __launch_bounds__(64 * WPG) MSK_KERNEL_ATTR void msk_demod_kernel(con
         constexpr int PERIODS = (WB - 8) / 6;          // 9 (WB 64), 4 (WB 32)
         static_assert(6 * PERIODS <= WB - 1 && 12 * PERIODS <= 2 * WB - 1, "the counted periods must stay inside the dm window");
         for (int period_ = 0; period_ < PERIODS; ++period_) {
+#endif
+#ifdef ACG_MSK_STAMP
+        ++stamp_iters;                                                     // (periods, not looks at the window)
 #endif
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
