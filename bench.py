@@ -265,6 +265,44 @@ def lookup_traffic(kernel, nch, M, ntaps, blocks_per_launch):
     return None, None
 
 
+def live_traffic(case_name, kernel, nch, blocks_per_launch, timeout_s=170):
+    """HBM bytes of ONE launch of `kernel` measured in THIS invocation: two child runs of this script under rocprofv3
+    (--kernel-trace --pmc FETCH_SIZE, then --pmc WRITE_SIZE: separate passes, never combined with another trace domain, as
+    MI355X_MICROARCH.md's HBM section prescribes), a short burst of the same launch shape each; traffic = 2 x FETCH_SIZE x 1024
+    + WRITE_SIZE x 1024 (gfx950: FETCH_SIZE counts wide coalesced reads at half their bytes; profiles/pmc_traffic.json _about).
+    Returns (bytes, source text) or (None, reason): any failure leaves the committed look-up in place."""
+    import shutil
+    import sqlite3
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    vals = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            with tempfile.TemporaryDirectory(dir="/tmp") as td:
+                cmd = [prof, "--kernel-trace", "--pmc", ctr, "-d", td, "--", sys.executable, os.path.abspath(__file__), "--config", case_name,
+                       "--also", "none", "--blocks", str(int(2 * blocks_per_launch)), "--channels", str(nch), "--steps", "3", "--warmup", "1", "--sustain", "0",
+                       "--no-cpu-baseline", "--no-ref-leg", "--check-channels", "8", "--no-live-traffic", "--detail-file", os.path.join(td, "detail.json")]
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+                dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(td) for f in fs if f.endswith(".db")]
+                if r.returncode != 0 or not dbs:
+                    return None, "rocprofv3 --pmc %s child failed (%d)" % (ctr, r.returncode)
+                con = sqlite3.connect(dbs[0])
+                rows = con.execute("select k.name, count(*), avg(p.counter_value) from pmc_events p join kernels k on k.dispatch_id = p.dispatch_id "
+                                   "where p.counter_name = ? group by k.name", (ctr,)).fetchall()
+                con.close()
+                hit = [(n, c, v) for n, c, v in rows if n.replace("void ", "").startswith(kernel.split("(")[0])]
+                if not hit:
+                    return None, "kernel %s not in the %s pass" % (kernel, ctr)
+                vals[ctr] = (hit[0][2], hit[0][1])
+    except Exception as ex:                      # (timeouts included: the line must not depend on a profiler)
+        return None, "live PMC pass failed: %r" % (ex,)
+    traffic = int(round(2 * vals["FETCH_SIZE"][0] * 1024 + vals["WRITE_SIZE"][0] * 1024))
+    return traffic, ("measured in this invocation: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate child runs of this script at "
+                     "the same launch shape, %d / %d launches): 2 x FETCH_SIZE + WRITE_SIZE" % (vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1]))
+
+
 def _probe_ab(args, J, step, drain, steps, nch, nout, M):
     """measurement aid (--ab): the same decoder, buffers and placement, timed again under each value of a per-launch switch in
     turn (acg_tune: ACG_FIR_VARIANT, ACG_MSK_LPC_LIVE, ...), two rounds -- not part of the reported value"""
@@ -1257,7 +1295,7 @@ def compact_line(full):
                       "delivered": _short(cfg.get("delivered", ""), 60), "contexts": _short(cfg.get("contexts", ""), 60)}
     if cfg.get("placement"):
         line["config"]["placement_ms_per_call"] = cfg["placement"].get("ms_per_call")
-    line["roofline"] = {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_launch", "avg_launch_ms",
+    line["roofline"] = {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_live", "bytes_per_launch", "avg_launch_ms",
                                                 "launches_per_step", "pure_reader_GBs_measured_this_run")}
     for k in ("whole_job_frac_of_hbm", "time_dominant_kernel", "timed_region_s", "per_gpu"):
         if k in full:
@@ -1370,6 +1408,9 @@ def main():
                          "(shader clock 1.64 GHz); a case that starts right behind one inherits that state for its first seconds, and "
                          "the demodulator-bound cases follow the shader clock (round 5: 2048 channels 0.57 of HBM right behind the "
                          "4096-channel case, 0.60-0.63 from an idle chip).  Every case is still timed for >= --sustain seconds.")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic of the headline launch shape in this invocation (two short child runs under "
+                         "rocprofv3 --pmc, ~25 s each); the committed PMC passes of profiles/pmc_traffic.json are looked up instead")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-child", nargs=4, default=None)
     ap.add_argument("--rtl8-cpu-child", nargs=3, default=None)
@@ -1512,6 +1553,19 @@ def main():
                     {"error": "child exited with %d: %s" % (r_.returncode, (r_.stderr or r_.stdout)[-300:])}
             except subprocess.TimeoutExpired:
                 hostfed = {"error": "hostfed child did not finish within 240 s"}
+        # roofline.traffic of the headline's launch shape, measured here and now (the committed passes stay as the fall-back)
+        if world == 1 and not args.no_live_traffic and not overridden and args.format == "u8" and args.share == 1:
+            if "iq_all" in J.__dict__:
+                del J.iq_all
+                torch.cuda.empty_cache()
+            rf_ = head["roofline"]
+            lt, src = live_traffic(args.config, rf_["kernel"], head["config"]["channels_per_gpu"],
+                                   head["config"]["blocks_per_pass"] / max(1, rf_.get("launches_per_pass") or 1))
+            rf_["traffic_committed_passes"] = rf_.get("traffic")
+            if lt is not None:
+                rf_["traffic"], rf_["traffic_source"], rf_["traffic_live"] = lt, src, True
+            else:
+                rf_["traffic_live"], rf_["traffic_live_note"] = False, src
         out = {
             "metric": "acars_channels_x_input_msps",
             "value": head["value"],

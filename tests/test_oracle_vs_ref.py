@@ -432,3 +432,42 @@ def test_reference_callback_front_end_programs_decode_the_golden_recording(fe, t
     assert r.returncode == 0 and len(msgs) == 7, out + r.stderr.decode("latin-1")[-500:]
     for tail in ("PH-BXR KL1681 E 5V S53A", "LN-DYY DY083J 2 Q0 S46A", "F-GTAE AF7728 G H1 D65C", "G-DBCK BA031T E Q0 S63A"):
         assert tail in out, tail
+
+
+def test_rtl8_one_line_format_equals_the_reference_program(tmp_path):
+    """bench.py's rtl8 case (BASELINE configs[1]) compares three printed outputs: the CPU reference program's, the GPU legacy
+    program's, and the batched API's records printed by bench.rtl8_oneline().  That formatter must be printoneline()
+    (output.c:327-346) minus the date: here the oracle's messages for an 8-channel dongle, printed by it, against what the
+    UNMODIFIED reference program (oracle/_ref/acarsdec_cpu_rtl: rtl.c + msk.c + acars.c + output.c) prints on the same I/Q file."""
+    import re
+    import subprocess
+    import bench
+    from acarsdec_amd import decoder as D, synth as S
+    exe = os.path.join(ROOT, "oracle", "_ref", "acarsdec_cpu_rtl")
+    if not os.path.exists(exe):
+        pytest.skip("needs the reference program (oracle/_ref, built where /root/reference exists)")
+    M, ncb, nch = 160, 10, 8
+    rng = np.random.default_rng(0x0881 + nch)
+    freqs = bench.rtl8_freqs(nch)
+    fr = [D.parse_freq_mhz(f) for f in freqs]
+    fc, _ = D.choose_fc(fr, M)
+    env = np.zeros((nch, ncb * 1024))
+    for c in range(nch):
+        a_, _ = S.channel_audio(rng, env.shape[1], gap=(3125, 12500), text_len=(20, 120))
+        env[c] = 0.5 * (1 + 0.5 * a_)
+    iq = S.iq_u8_from_envelopes(env, M, [f - fc for f in fr], phases=list(rng.uniform(0, 6.28, nch)), scale=1.0 / nch, noise=0.004, rng=rng)
+    path = tmp_path / "x.iq"
+    iq.tofile(str(path))
+    r = subprocess.run([exe, "-o", "1", "-r", "0"] + freqs, env=dict(os.environ, ACARSDEC_IQ_FILE=str(path)), capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode("latin-1")[-500:]
+    want = [l for l in re.sub(r"\d\d/\d\d/\d{4} \d\d:\d\d:\d\d\.\d{3} ", "", r.stdout.decode("latin-1")).splitlines() if l.startswith("#")]
+    mine = []
+    for c in range(nch):
+        ch = O.Channel(c, max_frames=256)
+        ch.demod(O.fir_u8(iq, M, D.rtl_taps(fr[c], fc, M)))
+        for f in ch.frames:
+            o = O.blk_process(f)
+            if o is not None:
+                m = O.msg_split(o)
+                mine.append(bench.rtl8_oneline(c, m.lvl, int(m.err), m.addr, m.fid, m.mode, m.label, m.no, bytes(m.txt[: m.txt_len])))
+    assert sorted(mine) == sorted(want) and len(want) >= 5
