@@ -265,7 +265,7 @@ def lookup_traffic(kernel, nch, M, ntaps, blocks_per_launch):
     return None, None
 
 
-def live_traffic(case_name, kernel, nch, blocks_per_launch, timeout_s=170):
+def live_traffic(case_name, kernel, nch, blocks_per_launch, timeout_s=100):
     """HBM bytes of ONE launch of `kernel` measured in THIS invocation: two child runs of this script under rocprofv3
     (--kernel-trace --pmc FETCH_SIZE, then --pmc WRITE_SIZE: separate passes, never combined with another trace domain, as
     MI355X_MICROARCH.md's HBM section prescribes), a short burst of the same launch shape each; traffic = 2 x FETCH_SIZE x 1024
