@@ -277,6 +277,9 @@ def live_traffic(case_name, kernel, nch, blocks_per_launch, timeout_s=100):
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(prof):
         return None, "rocprofv3 not found"
+    # (this process may itself be running under a profiler -- `rocprofv3 --stats -- python bench.py ...`: no profiler inside a profiler)
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process runs under a profiler: no nested PMC pass"
     vals = {}
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
