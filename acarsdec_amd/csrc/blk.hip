@@ -60,6 +60,9 @@ __global__ __launch_bounds__(64 * BLK_WAVES) void blk_repair_kernel(AcgFrameRec*
     // (the table in LDS: read where it lies -- 3.9 KB that stay in L2 -- every look-up is a ~1.5 us round trip beside the
     //  streaming down-converter and a block took ~50 us per wave: the pass fell behind the calls at 2048 channels, call 9)
     (void)crctab_g;
+#ifdef ACG_BLK_AB_PRIO
+    __builtin_amdgcn_s_setprio(3);          // A/B build only: see profiles/LEDGER.md round 5
+#endif
     __shared__ unsigned short synd[NSYND];
     // The pass's fixed cost is a chain of memory round trips beside a down-converter that saturates HBM (a few microseconds
     // each): the marks, the table, the first block.  They are requested in that order WITHOUT waiting in between: the two marks
