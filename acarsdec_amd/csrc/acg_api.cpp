@@ -184,6 +184,10 @@ struct acg_ctx {
     int ngroups = 0;                // 0: every stream feeds one channel (plain kernel)
     float* d_gtaps = nullptr;       // taps regrouped for the shared-stream kernel (lazily rebuilt)
     bool gtaps_dirty = true;
+    void* d_mm_img = nullptr;       // matrix-pipe shared-stream kernel (fir_mm.hip): tap digits per group, MmChan per channel
+    void* d_mm_chan = nullptr;
+    size_t mm_img_bytes = 0;
+    bool mm_dirty = true;
     float* d_dm = nullptr;          // dm buffer of the newest call (one of the two halves of d_dm_all)
     float* d_dm_all = nullptr;      // two dm buffers: the down-converter of call i+1 fills one while the demodulator of call i reads the other
     int dm_par = 0;
@@ -278,7 +282,7 @@ extern "C" int acg_device_count(void)
 static void free_all(acg_ctx* c)
 {
     if (!c) return;
-    hipFree(c->d_taps); hipFree(c->d_stream_of); hipFree(c->d_groups); hipFree(c->d_group_ch); hipFree(c->d_gtaps); hipFree(c->d_dm_all); hipFree(c->d_st);
+    hipFree(c->d_taps); hipFree(c->d_stream_of); hipFree(c->d_groups); hipFree(c->d_group_ch); hipFree(c->d_gtaps); hipFree(c->d_mm_img); hipFree(c->d_mm_chan); hipFree(c->d_dm_all); hipFree(c->d_st);
     hipFree(c->d_h); hipFree(c->d_sctab); hipFree(c->d_txt); hipFree(c->d_frames); hipFree(c->d_frame_count);
     hipFree(c->d_stamp);
     hipFree(c->d_msgs); std::free(c->h_msgs);
@@ -331,6 +335,7 @@ static int upload_stream_map(acg_ctx* c, const int* so)
     }
     c->ngroups = 0;
     c->gtaps_dirty = true;
+    c->mm_dirty = true;
     if (!shared || !c->tile_path) return ACG_OK;
     std::vector<int> fill(cnt.begin(), cnt.end() - 1);
     for (int i = 0; i < nch; ++i) ord[(size_t)fill[(size_t)so[i]]++] = i;          // stable: ascending channel id per stream
@@ -342,6 +347,16 @@ static int upload_stream_map(acg_ctx* c, const int* so)
     HIPCHK(c, hipMemcpy(c->d_groups, groups.data(), groups.size() * sizeof(int4), hipMemcpyHostToDevice));
     c->ngroups = (int)groups.size();
     if (!acg_tune_get("ACG_FIR_SHARED", 1)) c->ngroups = 0;
+    // the matrix-pipe kernel's tap digits: 2 KiB per group and 32-byte k-step (26 KiB per group at rtlMult 200)
+    const size_t need = acg_fir_mm_image_bytes(c->cfg.decim, c->ngroups);
+    if (need > c->mm_img_bytes) {
+        hipFree(c->d_mm_img);
+        c->d_mm_img = nullptr;
+        c->mm_img_bytes = 0;
+        HIPCHK(c, hipMalloc(&c->d_mm_img, need));
+        c->mm_img_bytes = need;
+    }
+    if (need && !c->d_mm_chan) HIPCHK(c, hipMalloc(&c->d_mm_chan, (size_t)nch * sizeof(MmChan)));
     return ACG_OK;
 }
 
@@ -593,6 +608,7 @@ extern "C" int acg_set_taps(acg_ctx* ctx, int ch0, int n, const float* taps)
     HIPCHK(ctx, hipMemcpy2D(ctx->d_taps + (size_t)ch0 * ctx->ntaps_pad * 2, dst_pitch, taps, src_pitch,
                             src_pitch, (size_t)n, hipMemcpyHostToDevice));
     ctx->gtaps_dirty = true;
+    ctx->mm_dirty = true;
     return ACG_OK;
 }
 
@@ -705,6 +721,21 @@ static int launch_fir(acg_ctx* c, const uint8_t* iq_dev, size_t pitch, int nbloc
         a.group_ch = c->d_group_ch;
         a.ngroups = c->ngroups;
         a.gtaps = c->d_gtaps;
+        a.mm_img = c->d_mm_img;
+        a.mm_chan = c->d_mm_chan;
+        // several channels per stream: the contraction goes to the matrix pipe (fir_mm.hip) where it takes the shape
+        // (rtlMult 160 / 192 / 200, whole tiles), else to the vector-pipe kernel below
+        const bool mm = c->ngroups > 0 && acg_tune_get("ACG_FIR_MM", 1) && acg_fir_mm_takes(&a);
+        if (mm) {
+            if (c->mm_dirty) {
+                if ((e = acg_launch_fir_mm_prep(&a, s)) != 0) {
+                    c->err = std::string("tap digit launch: ") + hipGetErrorString((hipError_t)e);
+                    return ACG_EHIP;
+                }
+                c->mm_dirty = false;
+            }
+            e = acg_launch_fir_mm(&a, s);
+        } else {
         if (c->ngroups > 0 && c->gtaps_dirty) {          // taps or the stream map changed (both synchronise the device)
             if ((e = acg_launch_regroup_taps(&a, s)) != 0) {
                 c->err = std::string("tap regroup launch: ") + hipGetErrorString((hipError_t)e);
@@ -713,6 +744,7 @@ static int launch_fir(acg_ctx* c, const uint8_t* iq_dev, size_t pitch, int nbloc
             c->gtaps_dirty = false;
         }
         e = c->ngroups > 0 ? acg_launch_fir_shared(&a, s) : acg_launch_fir(&a, s);
+        }
     } else {
         a.nseg = 1;
         e = acg_launch_fir_generic(&a, s);

@@ -105,6 +105,15 @@ struct FirArgs {
     int high_prio;              // wave-private kernel: raise the wave priority (the demodulator shares its CUs and has slack)
     int run_pairs;              // wave-private kernel: two-tile bodies per dispensed run (set by the launcher)
     int shares_cus;             // demodulator workgroups run on the same CUs (no CU partition): leave them LDS
+    const void* mm_img;         // matrix-pipe shared-stream kernel (fir_mm.hip): the groups' A-operand images (tap digits)
+    const void* mm_chan;        // ... and MmChan[nch]
+};
+
+// fir_mm.hip: what a channel's tap table contributes besides its digits
+struct MmChan {
+    double scale;               // 2^(e - 30): value of one unit of the 31-bit fixed-point taps
+    double dc_re, dc_im;        // (128 - 127.37f) (1 + j) sum w
+    double up;                  // 2^(30 - e), 0 for an all-zero table
 };
 
 // Run dispenser of one launch in flight: words [0], [1] = {tickets, finished} of the workgroup-granular
@@ -148,6 +157,10 @@ int acg_launch_fir(const FirArgs* a, void* stream);
 int acg_launch_fir_generic(const FirArgs* a, void* stream);
 int acg_launch_fir_shared(const FirArgs* a, void* stream);
 int acg_launch_regroup_taps(const FirArgs* a, void* stream);          // channels grouped by stream (a->groups)
+size_t acg_fir_mm_image_bytes(int decim, int ngroups);               // fir_mm.hip; 0: the matrix kernel does not take this decimation
+int acg_fir_mm_takes(const FirArgs* a);
+int acg_launch_fir_mm_prep(const FirArgs* a, void* stream);
+int acg_launch_fir_mm(const FirArgs* a, void* stream);
 int acg_launch_fir_fmt(const FirArgs* a, int fmt, void* stream);     // fmt: 1 CS16, 2 split int16 planes, 3 real f32
 size_t acg_fir_lds_bytes(const FirArgs* a);
 int acg_launch_msk(const MskArgs* a, int lanes_per_channel, void* stream);

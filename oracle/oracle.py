@@ -479,7 +479,7 @@ def _ref_blocks_child(variant, path_in, path_out):
     blk = 1024 * M * 2
     ref = Ref(variant)
     if front != "rtl":
-        getattr(ref.L, "ref_set_oscillator" if front == "soapy" else "ref_set_wf").argtypes = [C.c_int, C.c_void_p, C.c_int]
+        getattr(ref.L, "ref_set_oscillator" if front in ("soapy", "sdrplay") else "ref_set_wf").argtypes = [C.c_int, C.c_void_p, C.c_int]
     grab = lambda fr: [(int(f.len), int(f.err), bytes(f.crc), bytes(f.txt[: max(0, f.len)])) for f in fr]
     raw, out = [], []
     for c in range(rows.shape[0]):
@@ -494,6 +494,11 @@ def _ref_blocks_child(variant, path_in, path_out):
             ref.init_soapy(["131.725"], M)
             assert ref.L.ref_set_oscillator(0, t.ctypes.data, t.shape[0]) == 0
             ref.soapy_feed(r.view(np.int16), 1000)
+        elif front == "sdrplay":                          # int16 I and Q planes through myStreamCallback (sdrplay.c:202-237), ragged callbacks
+            ref.init_sdrplay(["131.725"])
+            assert ref.L.ref_set_oscillator(0, t.ctypes.data, t.shape[0]) == 0
+            h = r.view(np.int16)
+            ref.sdrplay_feed(h[: h.size // 2], h[h.size // 2:], 1008)
         else:                                             # real f32 through rx_callback (air.c:291-341), ragged transfers
             ref.init_air(["131.725"], INTRATE * M)
             assert ref.L.ref_set_wf(0, t.ctypes.data, t.shape[0]) == 0
@@ -507,8 +512,8 @@ def _ref_blocks_child(variant, path_in, path_out):
 
 def ref_blocks(variant, rows, M, taps, timeout_s=600, front="rtl"):
     """The UNMODIFIED reference build `variant` ("" = -O2 IEEE, "_fast" = the reference's own -Ofast -march=native,
-    "_v3"; front="soapy" / "air": "_soapy" / "_air" and their "_fast" twins) run over rows[c] (whole callbacks of u8 I/Q;
-    CS16 samples; real f32 samples) with channel c's tap table taps[c], one channel per pass, through its own front end
+    "_v3"; front="soapy" / "air" / "sdrplay": "_soapy" / "_air" / "_sdrplay" and their "_fast" twins) run over rows[c] (whole
+    callbacks of u8 I/Q; CS16 samples; real f32 samples; an int16 I plane followed by the Q plane) with channel c's tap table taps[c], one channel per pass, through its own front end
     (rtl.c in_callback / soapy.c's reader loop / air.c rx_callback) -> demodMSK -> decodeAcars -> blk_thread.  Returns
     {"raw": [...], "out": [...]}: per channel the blocks as decodeAcars queued them and as outputmsg() received them, each
     (len, err, crc, txt) -- or None when the build is missing or cannot run on this host.  Runs in a child interpreter; rows

@@ -114,7 +114,10 @@ def test_fir_shared_stream_and_stream_map(D, O):
 def test_fir_shared_stream_kernel_ragged_groups(D, O, M, tune):
     """the shared-stream down-converter (one tile load + one u8->f32 conversion for all channels of a
     stream, groups of <= 8): streams feeding 1, 3, 8, 11 and 16 channels in scrambled channel order;
-    dm within tolerance of the oracle AND bit-identical to the one-channel-per-unit kernel."""
+    dm within tolerance of the oracle AND bit-identical to the one-channel-per-unit kernel.  (Round 6: this vector-pipe kernel
+    is the fallback for rtlMult values the matrix-pipe kernel does not take -- fir_mm.hip, tests/test_gpu_round6.py -- and is
+    selected here with ACG_FIR_MM=0.)"""
+    tune("ACG_FIR_MM", "0")
     rng = np.random.default_rng(77 + M)
     sizes = [1, 3, 8, 11, 16, 1]
     smap = np.repeat(np.arange(len(sizes)), sizes)
