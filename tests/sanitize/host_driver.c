@@ -20,7 +20,9 @@ void acg_host_crc_tables_n(unsigned short *crc, unsigned short *synd, int nk);
 STUB(acg_launch_fir) STUB(acg_launch_fir_generic) STUB(acg_launch_fir_shared) STUB(acg_launch_regroup_taps)
 STUB(acg_launch_fir_fmt) STUB(acg_launch_msk) STUB(acg_launch_msk2) STUB(acg_launch_blk_repair) STUB(acg_launch_sincos_selftest)
 STUB(acg_launch_div2_selftest) STUB(acg_launch_msg_split) STUB(acg_launch_synth_iq) STUB(acg_launch_fill_random) STUB(acg_launch_read_probe)
+STUB(acg_fir_mm_takes) STUB(acg_launch_fir_mm_prep) STUB(acg_launch_fir_mm)
 size_t acg_fir_lds_bytes() { return 0; }
+size_t acg_fir_mm_image_bytes() { return 0; }
 
 static int fails;
 #define CHECK(c) do { if (!(c)) { fprintf(stderr, "CHECK failed line %d: %s\n", __LINE__, #c); ++fails; } } while (0)
