@@ -25,7 +25,7 @@ class ChanState(C.Structure):
     _fields_ = [("MskPhi", C.c_double), ("MskDf", C.c_double), ("MskLvlSum", C.c_double),
                 ("MskClk", C.c_float), ("MskBitCount", C.c_int), ("MskS", C.c_uint), ("idx", C.c_uint),
                 ("inb", C.c_float * (2 * FLEN)), ("outbits", C.c_int), ("nbits", C.c_int),
-                ("Acarsstate", C.c_int), ("blk_len", C.c_int), ("blk_err", C.c_int)]
+                ("Acarsstate", C.c_int), ("blk_len", C.c_int), ("blk_err", C.c_int), ("soh_back", C.c_int)]
 
 
 class Frame(C.Structure):

@@ -397,10 +397,21 @@ extern "C" int acg_create(acg_ctx** out, const acg_config* cfg)
         // wrap-safe as unsigned / signed 32-bit differences, and fetch's two-piece copy stays contiguous.  (Round 4 indexed
         // count % cap with cap = per_call * calls: at the wrap the slot sequence jumped and live records aliased -- 3 h away at
         // bench rates, VERDICT r04 weak 6.  tests/test_gpu_round5.py presets the counters to 2^32 - k through the lab hook.)
-        unsigned int cap2 = 1;
-        while ((unsigned long long)cap2 < per_call * calls) cap2 <<= 1;
-        c->frame_cap = cap2;
-        c->lag_max = (int)calls - 1;
+        // The rounding is kept INSIDE the budget where the host left the lag to the library (rounding the 512 MiB
+        // worst case up could allocate close to 1 GiB): the largest power of two within 512 MiB, as many calls as fit into it
+        // (at least two).  A host that names max_lag gets the smallest power of two that holds max_lag + 1 calls -- up to twice
+        // that worst case (include/acarsdec_amd.h, acg_config.max_lag) -- and lag_max says what the ring it got really holds.
+        unsigned long long cap2 = 1;
+        if (cfg->max_lag > 0) {
+            while (cap2 < per_call * calls) cap2 <<= 1;
+        } else {
+            while (cap2 * 2 * sizeof(AcgFrameRec) <= (512ull << 20)) cap2 <<= 1;
+            while (cap2 / 2 >= per_call * (acg_ctx::NCALL - 1)) cap2 >>= 1;          // (no larger than seven calls need)
+            while (cap2 < per_call * 2) cap2 <<= 1;                                   // (very wide contexts: two calls, whatever they cost)
+        }
+        if (cap2 > 0x80000000ull) { delete c; return ACG_EINVAL; }
+        c->frame_cap = (unsigned int)cap2;
+        c->lag_max = (int)std::min<unsigned long long>(acg_ctx::NCALL - 2, cap2 / per_call - 1);
     }
     c->exact_fir = (cfg->flags & ACG_F_EXACT_FIR) != 0;
     // MSK kernel shape: the chip has 1024 SIMDs; give every channel as many lanes as keeps the
@@ -577,6 +588,7 @@ extern "C" int acg_reset(acg_ctx* ctx)
     HIPCHK(ctx, hipDeviceSynchronize());
     ctx->consumed = 0;
     ctx->call_seq = 0;
+    ctx->last_guard = nullptr;
     ctx->feed_fill = 0;
     ctx->feed_cur = 0;
     ctx->stage_seq = 0;
@@ -854,6 +866,7 @@ extern "C" int acg_fir_only_dev(acg_ctx* ctx, const uint8_t* iq_dev, size_t pitc
 // get a repair pass that reads a later call's mark).  The event has normally completed long ago: one query.
 static int begin_call(acg_ctx* ctx)
 {
+    ctx->last_guard = nullptr;          // only ever a guard recorded in THIS call (a call that failed after guard_record leaves one behind: ADVICE r05)
     if (ctx->call_seq >= (unsigned long long)acg_ctx::NCALL)
         HIPCHK(ctx, hipEventSynchronize(ctx->call_done[ctx->call_seq % acg_ctx::NCALL]));
     return ACG_OK;
@@ -1373,6 +1386,9 @@ static void state_from_dev(const AcgChan& d, acg_chan_state* st)
     std::memcpy(st->inb, d.inb, sizeof(d.inb));
     st->outbits = (int)d.outbits; st->nbits = d.nbits; st->Acarsstate = d.astate;
     st->blk_len = d.blen; st->blk_err = d.berr;
+    // the SOH stamp as a distance (the sample counter is the slot's own, the distance travels): ADVICE r05
+    const unsigned int back = (unsigned int)d.nsamp_total - d.soh32;
+    st->soh_back = (d.astate >= 3 && d.astate <= 5 && back < 65536u) ? (int)back : 0;
 }
 
 // channels ch0 .. ch0+n-1 in one transfer (the legacy view moves all channels of a dongle per callback)
@@ -1396,8 +1412,8 @@ extern "C" int acg_set_state_n(acg_ctx* ctx, int ch0, int n, const acg_chan_stat
         if (st[i].idx >= ACG_FLEN) return fail(ctx, ACG_EINVAL, "idx out of range");
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
     HIPCHK(ctx, hipDeviceSynchronize());
-    // read-modify-write: the bookkeeping that is not part of channel_t (bit / sample counters, the held CRC byte, the SOH
-    // stamp) stays as the device has it
+    // read-modify-write: the bookkeeping that is not part of channel_t (bit / sample counters, the held CRC byte) stays as the
+    // device has it; the SOH stamp is re-based on this slot's sample counter from the distance the caller brings
     std::vector<AcgChan> dv((size_t)n);
     HIPCHK(ctx, hipMemcpy(dv.data(), ctx->d_st + ch0, (size_t)n * sizeof(AcgChan), hipMemcpyDeviceToHost));
     for (int i = 0; i < n; ++i) {
@@ -1408,6 +1424,7 @@ extern "C" int acg_set_state_n(acg_ctx* ctx, int ch0, int n, const acg_chan_stat
         std::memcpy(d.inb, t.inb, sizeof(d.inb));
         d.outbits = (unsigned int)t.outbits & 0xffu; d.nbits = t.nbits; d.astate = t.Acarsstate;
         d.blen = t.blk_len; d.berr = t.blk_err;
+        d.soh32 = (unsigned int)d.nsamp_total - (unsigned int)(t.soh_back > 0 && t.soh_back < 65536 ? t.soh_back : 0);
     }
     HIPCHK(ctx, hipMemcpy(ctx->d_st + ch0, dv.data(), (size_t)n * sizeof(AcgChan), hipMemcpyHostToDevice));
     return ACG_OK;

@@ -40,7 +40,8 @@
 #define FLEN ((INTRATE / 1200) + 1)
 
 static int g_keep_dm;
-static double g_secs, g_first;       /* g_first: the first call (context creation, first launches) */
+static double g_secs, g_first;       /* g_first: the first call (round 5: context creation + first launches; now an ordinary call) */
+static double g_prepare;             /* context creation + one throw-away call, paid inside initMsk() of the last channel */
 static unsigned long g_calls;
 
 void acarsdec_amd_compat_keep_dm(int on) { g_keep_dm = on; }
@@ -63,9 +64,9 @@ static void print_stats(void)
 {
 	if (g_calls)
 		fprintf(stderr, "acarsdec_amd compat: %lu calls, %.6f s inside the legacy entry points, %.4f ms per call "
-			"(first call %.3f ms: context creation; the others %.4f ms per call)\n",
+			"(first call %.3f ms; the others %.4f ms per call; context made at initMsk() time in %.1f ms)\n",
 			g_calls, g_secs, 1e3 * g_secs / (double)g_calls, 1e3 * g_first,
-			g_calls > 1 ? 1e3 * (g_secs - g_first) / (double)(g_calls - 1) : 0.0);
+			g_calls > 1 ? 1e3 * (g_secs - g_first) / (double)(g_calls - 1) : 0.0, 1e3 * g_prepare);
 }
 static void account(double t0)
 {
@@ -96,6 +97,8 @@ static void die(const char *what, acg_ctx *c, int rc)
 	exit(1);
 }
 
+static int compat_prepare(void);
+
 int initMsk(channel_t *ch)
 {
 	/* msk.c:34-42: same observable effect on channel_t */
@@ -106,6 +109,12 @@ int initMsk(channel_t *ch)
 	ch->inb = calloc(FLEN, sizeof(float complex));
 	if (ch->inb == NULL)
 		return -1;
+	/* The last channel (acarsdec.c:445-454 runs this loop after the front end's init has filled wf / oscillator): make the GPU
+	 * context NOW, not inside the first callback -- a live radio's first transfer period (81.92 ms on rtl.c, shorter on
+	 * airspy / SDRplay) does not hold a context creation (0.14-0.27 s).  A failure is the reference's own error
+	 * path: main() prints "Unable to init internal decoders" and exits with this value (acarsdec.c:456-459). */
+	if (nbch > 0 && ch == &channel[nbch - 1])
+		return compat_prepare();
 	return 0;
 }
 
@@ -158,7 +167,8 @@ static void download_all(acg_ctx *c, shadow_t *sh, channel_t *const *chs, int n)
 	sh->valid = 1;
 	for (k = 0; k < n; k++) {
 		channel_t *ch = chs[k];
-		const acg_chan_state *st = &sh->st[k];
+		acg_chan_state *st = &sh->st[k];
+		st->soh_back = 0;                 /* (not a channel_t field: pack() cannot know it, and this view stamps blk->tv itself) */
 		ch->MskPhi = st->MskPhi; ch->MskDf = st->MskDf; ch->MskClk = st->MskClk;
 		ch->MskS = st->MskS; ch->idx = st->idx;
 		for (i = 0; i < FLEN; i++)
@@ -194,6 +204,89 @@ static void discard_device_blocks(acg_ctx *g)
 		die("drain_frames", g, rc);
 }
 
+/* nbch channels of one stream, their tap tables from the front end's own init */
+static acg_ctx *make_front_ctx(int mult, int max_blocks, float complex *const *tables)
+{
+	acg_config cfg;
+	acg_ctx *c = NULL;
+	float *taps = malloc(sizeof(float) * 2 * (size_t)mult * nbch);
+	unsigned int n;
+	int k, rc;
+	if (taps == NULL)
+		return NULL;
+	memset(&cfg, 0, sizeof(cfg));
+	cfg.nch = (int)nbch; cfg.nstreams = 1; cfg.decim = mult; cfg.ntaps = mult;
+	cfg.max_blocks = max_blocks; cfg.flags = ACG_F_BITLOG; cfg.max_lag = 1;        /* drained after every call */
+	if ((rc = acg_create(&c, &cfg)) != ACG_OK) {
+		fprintf(stderr, "acarsdec_amd: acg_create: %s\n", acg_strerror(rc));
+		free(taps);
+		return NULL;
+	}
+	for (n = 0; n < nbch; n++)
+		for (k = 0; k < mult; k++) {
+			taps[2 * ((size_t)n * mult + k)] = crealf(tables[n][k]);
+			taps[2 * ((size_t)n * mult + k) + 1] = cimagf(tables[n][k]);
+		}
+	rc = acg_set_taps(c, 0, (int)nbch, taps);
+	free(taps);
+	if (rc != ACG_OK) {
+		fprintf(stderr, "acarsdec_amd: set_taps: %s (%s)\n", acg_strerror(rc), acg_last_error(c));
+		acg_destroy(c);
+		return NULL;
+	}
+	return c;
+}
+
+static acg_ctx *make_msk_ctx(int blocks)
+{
+	acg_config cfg;
+	acg_ctx *c = NULL;
+	int rc;
+	memset(&cfg, 0, sizeof(cfg));
+	cfg.nch = 1; cfg.nstreams = 1; cfg.decim = 8; cfg.ntaps = 8;
+	cfg.max_blocks = blocks;
+	cfg.flags = ACG_F_BITLOG;
+	cfg.max_lag = 1;                              /* drained after every call */
+	if ((rc = acg_create(&c, &cfg)) != ACG_OK) {
+		fprintf(stderr, "acarsdec_amd: acg_create: %s\n", acg_strerror(rc));
+		return NULL;
+	}
+	return c;
+}
+
+static void null_sink(void *user, int slot, float vo, float lvl) { (void)user; (void)slot; (void)vo; (void)lvl; }
+
+/* One throw-away call through every entry point the real calls use (kernels get loaded, staging buffers pinned), then the
+ * context goes back to the state acg_create left it in.  fmt < 0: the 12.5 kHz path of demodMSK(). */
+static int warm_up(acg_ctx *c, int fmt, int mult, int nchan)
+{
+	const size_t ns = (size_t)ACG_BLOCK * (size_t)(mult > 0 ? mult : 1);
+	acg_chan_state *st = malloc(sizeof(acg_chan_state) * (size_t)nchan);
+	void *buf = calloc(ns, fmt == 0 ? 2 : 4);
+	void *buf2 = fmt == ACG_FMT_S16_SPLIT ? calloc(ns, 2) : NULL;
+	acg_frame f[8];
+	int rc = ACG_OK, n = 0;
+	if (st == NULL || buf == NULL || (fmt == ACG_FMT_S16_SPLIT && buf2 == NULL))
+		rc = ACG_ENOMEM;
+	else if (fmt < 0)
+		rc = acg_process_dm_host(c, (const float *)buf, ns, ACG_BLOCK);
+	else if (fmt == 0) {
+		memset(buf, 127, ns * 2);
+		rc = acg_process_iq_u8_host(c, buf, ns * 2, 1);
+	} else
+		rc = acg_feed_samples_host(c, fmt, buf, buf2, 0, ns);
+	if (rc == ACG_OK) rc = acg_replay_bits(c, null_sink, NULL);
+	if (rc == ACG_OK) rc = acg_get_state_n(c, 0, nchan, st);
+	if (rc == ACG_OK) {
+		do { rc = acg_drain_frames(c, f, 8, &n); } while (rc == ACG_EAGAIN);
+	}
+	if (rc == ACG_OK) rc = acg_reset(c);
+	if (rc != ACG_OK)
+		fprintf(stderr, "acarsdec_amd: warm-up call: %s (%s)\n", acg_strerror(rc), acg_last_error(c));
+	free(st); free(buf); free(buf2);
+	return rc;
+}
+
 void demodMSK(channel_t *ch, int len)
 {
 	int rc;
@@ -202,20 +295,14 @@ void demodMSK(channel_t *ch, int len)
 
 	if (len <= 0)
 		return;
-	if (g_msk == NULL || (len + ACG_BLOCK - 1) / ACG_BLOCK > g_msk_blocks) {
-		acg_config cfg;
+	if (g_msk == NULL || (len + ACG_BLOCK - 1) / ACG_BLOCK > g_msk_blocks) {       /* (made by initMsk(); here: a longer call than foreseen) */
 		if (g_msk)
 			acg_destroy(g_msk);
-		memset(&cfg, 0, sizeof(cfg));
 		g_msk_blocks = (len + ACG_BLOCK - 1) / ACG_BLOCK;
 		if (g_msk_blocks < 4)
 			g_msk_blocks = 4;                     /* soundfile.c:27 MAXNBFRAMES 4096 */
-		cfg.nch = 1; cfg.nstreams = 1; cfg.decim = 8; cfg.ntaps = 8;
-		cfg.max_blocks = g_msk_blocks;
-		cfg.flags = ACG_F_BITLOG;
-		cfg.max_lag = 1;                              /* drained after every call */
-		if ((rc = acg_create(&g_msk, &cfg)) != ACG_OK)
-			die("acg_create", NULL, rc);
+		if ((g_msk = make_msk_ctx(g_msk_blocks)) == NULL)
+			exit(1);
 		g_msk_sh.valid = 0;
 	}
 	one[0] = ch;
@@ -245,23 +332,11 @@ void acarsdec_amd_in_callback(unsigned char *rtlinbuff, uint32_t nread, void *ct
 		fprintf(stderr, "warning: partial read\n");
 		return;
 	}
-	if (g_rtl == NULL) {
-		acg_config cfg;
-		float *taps = malloc(sizeof(float) * 2 * (size_t)rtlMult * nbch);
-		int k;
-		memset(&cfg, 0, sizeof(cfg));
-		cfg.nch = (int)nbch; cfg.nstreams = 1; cfg.decim = rtlMult; cfg.ntaps = rtlMult;
-		cfg.max_blocks = 1; cfg.flags = ACG_F_BITLOG; cfg.max_lag = 1;
-		if ((rc = acg_create(&g_rtl, &cfg)) != ACG_OK)
-			die("acg_create", NULL, rc);
-		for (n = 0; n < nbch; n++)                           /* wf from initRtl, rtl.c:283-286 */
-			for (k = 0; k < rtlMult; k++) {
-				taps[2 * ((size_t)n * rtlMult + k)] = crealf(channel[n].wf[k]);
-				taps[2 * ((size_t)n * rtlMult + k) + 1] = cimagf(channel[n].wf[k]);
-			}
-		if ((rc = acg_set_taps(g_rtl, 0, (int)nbch, taps)) != ACG_OK)
-			die("set_taps", g_rtl, rc);
-		free(taps);
+	if (g_rtl == NULL) {                                         /* (normally made by initMsk(): a host that skipped it lands here) */
+		float complex *tab[MAXNBCHANNELS];
+		for (n = 0; n < nbch; n++) tab[n] = channel[n].wf;       /* wf from initRtl, rtl.c:283-286 */
+		if ((g_rtl = make_front_ctx(rtlMult, 1, tab)) == NULL)
+			exit(1);
 	}
 	for (n = 0; n < nbch; n++)
 		chs[n] = &channel[n];
@@ -304,24 +379,12 @@ void acarsdec_amd_soapy_samples(const int16_t *iq, int nsamples)
 
 	if (nsamples <= 0)
 		return;
-	if (g_soapy == NULL) {
-		acg_config cfg;
-		float *taps = malloc(sizeof(float) * 2 * (size_t)rateMult * nbch);
-		int k;
-		memset(&cfg, 0, sizeof(cfg));
-		cfg.nch = (int)nbch; cfg.nstreams = 1; cfg.decim = rateMult; cfg.ntaps = rateMult;
-		cfg.max_blocks = 2;                                  /* a read is at most SOAPYOUTBUFSZ windows (soapy.c:59) + the carry */
-		cfg.flags = ACG_F_BITLOG; cfg.max_lag = 1;
-		if ((rc = acg_create(&g_soapy, &cfg)) != ACG_OK)
-			die("acg_create", NULL, rc);
-		for (n = 0; n < nbch; n++)                           /* oscillator[] from initSoapy, soapy.c:131-137 */
-			for (k = 0; k < rateMult; k++) {
-				taps[2 * ((size_t)n * rateMult + k)] = crealf(channel[n].oscillator[k]);
-				taps[2 * ((size_t)n * rateMult + k) + 1] = cimagf(channel[n].oscillator[k]);
-			}
-		if ((rc = acg_set_taps(g_soapy, 0, (int)nbch, taps)) != ACG_OK)
-			die("set_taps", g_soapy, rc);
-		free(taps);
+	if (g_soapy == NULL) {                                       /* (normally made by initMsk()) */
+		float complex *tab[MAXNBCHANNELS];
+		for (n = 0; n < nbch; n++) tab[n] = channel[n].oscillator;   /* oscillator[] from initSoapy, soapy.c:131-137 */
+		/* a read is at most SOAPYOUTBUFSZ windows (soapy.c:59) + the carry: two blocks */
+		if ((g_soapy = make_front_ctx(rateMult, 2, tab)) == NULL)
+			exit(1);
 	}
 	if ((g_soapy_carry + (size_t)nsamples) / (size_t)rateMult == 0) {        /* no window completes: nothing to demodulate yet */
 		if ((rc = acg_feed_samples_host(g_soapy, ACG_FMT_CS16, iq, NULL, 0, (size_t)nsamples)) != ACG_OK)
@@ -347,6 +410,7 @@ void acarsdec_amd_soapy_samples(const int16_t *iq, int nsamples)
 #if defined(WITH_AIR) || defined(WITH_SDRPLAY)
 /* the front ends whose DSP sits in a vendor callback: samples of any count per call, the partial window carried on the device */
 static acg_ctx *g_fe;
+static int g_fe_mult;
 static size_t g_fe_carry;
 
 static void fe_samples(int fmt, const void *p0, const void *p1, int nsamples, int mult, float complex *const *tables)
@@ -358,23 +422,15 @@ static void fe_samples(int fmt, const void *p0, const void *p1, int nsamples, in
 
 	if (nsamples <= 0)
 		return;
-	if (g_fe == NULL) {
-		acg_config cfg;
-		float *taps = malloc(sizeof(float) * 2 * (size_t)mult * nbch);
-		int k;
-		memset(&cfg, 0, sizeof(cfg));
-		cfg.nch = (int)nbch; cfg.nstreams = 1; cfg.decim = mult; cfg.ntaps = mult;
-		cfg.max_blocks = 2; cfg.flags = ACG_F_BITLOG; cfg.max_lag = 1;
-		if ((rc = acg_create(&g_fe, &cfg)) != ACG_OK)
-			die("acg_create", NULL, rc);
-		for (n = 0; n < nbch; n++)
-			for (k = 0; k < mult; k++) {
-				taps[2 * ((size_t)n * mult + k)] = crealf(tables[n][k]);
-				taps[2 * ((size_t)n * mult + k) + 1] = cimagf(tables[n][k]);
-			}
-		if ((rc = acg_set_taps(g_fe, 0, (int)nbch, taps)) != ACG_OK)
-			die("set_taps", g_fe, rc);
-		free(taps);
+	if (g_fe != NULL && g_fe_mult != mult) {                     /* initMsk() guessed another window length: start over */
+		acg_destroy(g_fe);
+		g_fe = NULL;
+		g_front_sh.valid = 0;
+	}
+	if (g_fe == NULL) {                                          /* (normally made by initMsk()) */
+		if ((g_fe = make_front_ctx(mult, 2, tables)) == NULL)
+			exit(1);
+		g_fe_mult = mult;
 	}
 	if ((g_fe_carry + (size_t)nsamples) / (size_t)mult == 0) {               /* no window completes: nothing to demodulate yet */
 		if ((rc = acg_feed_samples_host(g_fe, fmt, p0, p1, 0, (size_t)nsamples)) != ACG_OK)
@@ -427,3 +483,62 @@ void acarsdec_amd_sdrplay_samples(const int16_t *xi, const int16_t *xq, int nsam
 }
 #endif
 
+
+/* The context of whichever front end this build serves, made when initMsk() sees the last channel (above).  The front end's
+ * own init has run (acarsdec.c:420-437 before the loop at :445): its tap tables exist, or -- sound-file / ALSA input -- they
+ * do not, and demodMSK()'s 1-channel context is what will be used. */
+static int compat_prepare(void)
+{
+	const double t0 = now_s();
+	float complex *tab[MAXNBCHANNELS];
+	unsigned int n;
+	int rc = ACG_OK, made = 0;
+	(void)tab; (void)n;
+#if defined(WITH_RTL)
+	if (g_rtl == NULL && rtlMult > 0 && channel[0].wf != NULL) {
+		for (n = 0; n < nbch; n++) tab[n] = channel[n].wf;
+		if ((g_rtl = make_front_ctx(rtlMult, 1, tab)) == NULL)
+			return -1;
+		rc = warm_up(g_rtl, 0, rtlMult, (int)nbch);
+		made = 1;
+	}
+#elif defined(WITH_SOAPY)
+	if (g_soapy == NULL && rateMult > 0 && channel[0].oscillator != NULL) {
+		for (n = 0; n < nbch; n++) tab[n] = channel[n].oscillator;
+		if ((g_soapy = make_front_ctx(rateMult, 2, tab)) == NULL)
+			return -1;
+		rc = warm_up(g_soapy, ACG_FMT_CS16, rateMult, (int)nbch);
+		made = 1;
+	}
+#elif defined(WITH_SDRPLAY)
+	if (g_fe == NULL && channel[0].oscillator != NULL) {
+		for (n = 0; n < nbch; n++) tab[n] = channel[n].oscillator;
+		if ((g_fe = make_front_ctx(160, 2, tab)) == NULL)              /* SDRPLAY_MULT, sdrplay.c:40 */
+			return -1;
+		g_fe_mult = 160;
+		rc = warm_up(g_fe, ACG_FMT_S16_SPLIT, 160, (int)nbch);
+		made = 1;
+	}
+#elif defined(WITH_AIR)
+	if (g_fe == NULL && channel[0].wf != NULL && crealf(channel[0].wf[0]) > 0) {
+		/* AIRMULT is static in air.c; wf[0] = cexpf(0) / AIRMULT (air.c:279-280) says what it is */
+		const int mult = (int)(1.0f / crealf(channel[0].wf[0]) + 0.5f);
+		if (mult >= 8 && mult <= 1024 && mult % 4 == 0) {
+			for (n = 0; n < nbch; n++) tab[n] = channel[n].wf;
+			if ((g_fe = make_front_ctx(mult, 2, tab)) == NULL)
+				return -1;
+			g_fe_mult = mult;
+			rc = warm_up(g_fe, ACG_FMT_F32_REAL, mult, (int)nbch);
+			made = 1;
+		}
+	}
+#endif
+	if (!made && g_msk == NULL) {                                    /* soundfile.c / alsa.c feed demodMSK() directly */
+		g_msk_blocks = 4;                                            /* soundfile.c:27 MAXNBFRAMES 4096 */
+		if ((g_msk = make_msk_ctx(g_msk_blocks)) == NULL)
+			return -1;
+		rc = warm_up(g_msk, -1, 0, 1);
+	}
+	g_prepare = now_s() - t0;
+	return rc == ACG_OK ? 0 : -1;
+}

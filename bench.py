@@ -57,6 +57,44 @@ from benchlib.rtl8 import rtl8_cpu_child, run_rtl8                              
 from benchlib.traffic import live_traffic                                                # noqa: E402
 
 
+def dry_run_main(J, args, dist, local):
+    """--dry-run: the launch path of main() below without a device (see benchlib/dryrun.py); same cases, same line"""
+    from benchlib.dryrun import run_case_dry
+    world, rank = J.world, J.rank
+    J.backend, J.local, J.dev, J.cdev, J.dist, J.coll, J.L = "gloo", local, None, None, dist, None, None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        J.coll = dist
+    also = ["shard2048"] if args.also is None else ([] if args.also in ("", "none") else args.also.split(","))
+    cases = [(args.config, dict(CASES[args.config]))] + [(a, dict(CASES[a])) for a in also if a != args.config]
+    if args.channels:
+        cases[0][1]["channels"] = args.channels
+    res = [run_case_dry(J, name, c, args, args.steps, args.warmup, headline=(i == 0)) for i, (name, c) in enumerate(cases)]
+    final_line = None
+    if rank == 0:
+        head = res[0]
+        out = {"metric": "acars_channels_x_input_msps", "value": head["value"], "unit": "channel*Msamples/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "dry_run": True}
+        for k in ("data", "config", "roofline", "whole_job_frac_of_hbm", "time_dominant_kernel", "timed_region_s", "sustain", "parity", "per_gpu"):
+            if k in head:
+                out[k] = head[k]
+        if len(res) > 1:
+            out["also"] = {name: r for (name, _), r in zip(cases[1:], res[1:])}
+        out["multi_gpu"] = MULTI_GPU_NOTE
+        print("# bench_detail: " + json.dumps(out), flush=True)
+        line = compact_line(out)
+        line["dry_run"] = True
+        final_line = json.dumps(line, separators=(",", ":"))
+        assert len(final_line) < 4096, len(final_line)
+    if J.coll is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(final_line, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,6 +141,10 @@ def main():
     ap.add_argument("--sustain", type=float, default=5.0,
                     help="seconds the timed region of every case should last at least: a step becomes as many passes over the resident "
                          "batch as that takes (0 = one pass per step, the short burst of rounds 1-2)")
+    ap.add_argument("--sustain-hbm", type=float, default=20.0,
+                    help="seconds the timed region of the cases that saturate HBM (benchlib.cases.SUSTAIN_HBM: wide, stress, cs16, f32) lasts at "
+                         "least: at the power cap their rate sinks with the shader clock for tens of seconds, the first 5 s are reported "
+                         "beside it as burst5s")
     ap.add_argument("--no-ref-leg", action="store_true", help="skip the gate's reference -O2 vs -Ofast leg (oracle/_ref on the host cores)")
     ap.add_argument("--rccl-selftest", action="store_true",
                     help="with --gpus 1: initialise torch.distributed (nccl = RCCL) with world size 1 and send the channel scatter, the barriers "
@@ -115,6 +157,10 @@ def main():
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not measure roofline.traffic of the headline launch shape in this invocation (two short child runs under "
                          "rocprofv3 --pmc, ~25 s each); the committed PMC passes of profiles/pmc_traffic.json are looked up instead")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rehearse the N-rank launch path without a GPU (benchlib/dryrun.py): real launcher, real scatter / barriers / "
+                         "reductions over gloo, real timed region and result line, a stub that sleeps in place of the decoder.  The line "
+                         "says \"dry_run\": true and measures nothing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-child", nargs=4, default=None)
     ap.add_argument("--rtl8-cpu-child", nargs=3, default=None)
@@ -140,6 +186,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run_main(J, args, dist, local)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
     J.backend = os.environ.get("ACG_BENCH_BACKEND", "nccl")    # "gloo": rehearsal without RCCL (several ranks on one GPU)
@@ -194,7 +242,8 @@ def main():
     else:
         # (order: the two cases whose step the demodulator sets -- they follow the shader clock -- before the cases that saturate
         #  HBM and run the chip into its power cap: see --cooldown)
-        also = ["shard2048", "wide", "stress", "cs16", "f32", "rtl8", "hostfed"] if world == 1 else ["shard2048"]
+        also = (["shard2048", "share8", "wide", "stress", "m160", "m192", "cs16", "f32", "split16", "rtl8", "hostfed"] if world == 1
+                else ["shard2048"])
         also = [a for a in also if a != args.config]
     with_hostfed = "hostfed" in also
     with_rtl8 = "rtl8" in also and world == 1
@@ -204,7 +253,7 @@ def main():
     def case_bps(i, c):
         f = c.get("format") or (args.format if i == 0 else "u8")
         return 2 if f == "u8" else 4
-    need = max(c["channels"] // (max(1, args.share) if i == 0 else 1) * c["blocks"] * 1024 * c["decim"] * case_bps(i, c)
+    need = max(c["channels"] // int(c.get("share") or (max(1, args.share) if i == 0 else 1)) * c["blocks"] * 1024 * c["decim"] * case_bps(i, c)
                for i, (_, c) in enumerate(cases))
     hostfed_need = (args.hostfed_channels or HOSTFED["channels"]) * HOSTFED["call_blocks"] * 1024 * HOSTFED["decim"] * 2 * 3
     if args.hostfed_child:    # two calls' worth on the device (the _dev reference of its gate) + one call of scratch
@@ -267,7 +316,7 @@ def main():
                                    head["config"]["blocks_per_pass"] / max(1, rf_.get("launches_per_pass") or 1))
             rf_["traffic_committed_passes"] = rf_.get("traffic")
             if lt is not None:
-                rf_["traffic"], rf_["traffic_source"], rf_["traffic_live"] = lt, src, True
+                rf_["traffic"], rf_["traffic_source"], rf_["traffic_live"], rf_["traffic_src"] = lt, src, True, "live"
             else:
                 rf_["traffic_live"], rf_["traffic_live_note"] = False, src
         out = {
@@ -284,7 +333,7 @@ def main():
             "dtype": "f32",
         }
         for k in ("data", "config", "roofline", "whole_job_frac_of_hbm", "whole_job_GBs_per_gpu", "time_dominant_kernel",
-                  "timed_region_s", "sustain", "burst", "kernels", "parity", "per_gpu", "valu", "ab_same_process", "placement_trials"):
+                  "timed_region_s", "sustain", "burst", "kernels", "parity", "per_gpu", "valu", "ab_same_process", "placement_trials", "roofline_msk"):
             if k in head:
                 out[k] = head[k]
         if out["time_dominant_kernel"] != out["roofline"]["kernel"]:
@@ -292,7 +341,7 @@ def main():
                                                  "serial recurrence, latency-bound), see whole_job_frac_of_hbm" % out["time_dominant_kernel"])
         if len(res) > 1:
             out["also"] = {name: {k: r[k] for k in ("value", "ms_per_step", "timed_region_s", "sustain", "burst", "whole_job_frac_of_hbm", "whole_job_GBs_per_gpu",
-                                                    "time_dominant_kernel", "roofline", "kernels", "parity", "config", "data", "hostfed") if k in r}
+                                                    "time_dominant_kernel", "roofline", "roofline_msk", "kernels", "parity", "config", "data", "hostfed") if k in r}
                            for (name, _), r in zip(cases[1:], res[1:])}
             for name, r in zip([n for n, _ in cases[1:]], res[1:]):
                 if "per_gpu" in r:

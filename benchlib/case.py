@@ -25,10 +25,10 @@ def run_case(J, name, case, args, steps, warmup, headline):
     fmt_name = case.get("format") or (args.format if headline else "u8")
     fmt = {"u8": 0, "cs16": K.FMT_CS16, "split16": K.FMT_S16_SPLIT, "f32": K.FMT_F32_REAL}[fmt_name]
     bps = 2 if fmt == 0 else 4
-    share = max(1, args.share) if headline else 1
+    share = int(case.get("share") or (max(1, args.share) if headline else 1))
     if share > 1:
         assert fmt == 0 and nch % share == 0, "--share needs the u8 format and a channel count divisible by it"
-        content = "random"
+        content = "shared+acars"
     if fmt != 0 and content != "format+acars":
         content = "format"
     nstreams = nch // share
@@ -45,6 +45,11 @@ def run_case(J, name, case, args, steps, warmup, headline):
         r0 = np.random.default_rng(0xACA25)
         off = r0.integers(-48, 49, size=nch_total) * 25000.0           # multiples of 12.5 kHz within +-1.2 MHz
         off[np.abs(off) < 25000] = 50000.0                              # >= 25 kHz from DC like chooseFc enforces
+        if share > 1:
+            # channels of one dongle: distinct carriers 150 kHz apart (75 kHz with more than 8), the whole comb shifted per dongle;
+            # all multiples of 12.5 kHz (rtl.c:245-247), within +-0.6 MHz
+            c_ = np.arange(nch_total)
+            off = (2 * (c_ % share) - share + 1) * (75000.0 if share <= 8 else 37500.0) + ((c_ // share) % 5 - 2) * 12500.0
         cfg_rows = np.stack([off, r0.uniform(0, 2 * np.pi, nch_total), np.zeros(nch_total),
                              np.arange(nch_total, dtype=np.float64)], axis=1)
     mine = shard.scatter_channel_config(cfg_rows, world, rank, J.coll, device=cdev, force=J.coll is not None)
@@ -89,9 +94,35 @@ def run_case(J, name, case, args, steps, warmup, headline):
         data_desc = ("uniform random bytes, seeded per stream (SURVEY 8d config 5: the value distribution is irrelevant to bandwidth); "
                      "the first %d channels (the ones the parity gate looks at) carry ACARS/MSK traffic as in the other cases, so "
                      "that the gate compares decoded blocks and not only magnitudes" % nacars)
+    elif content == "shared+acars":
+        # every dongle stream: uniform random bytes; the dongles of the gate's channels: the sum of their K channels' ACARS/MSK
+        # carriers (SURVEY App. C.1 with K carriers), AWGN at 20 dB SNR per channel, generated on the device
+        assert L.acg_fill_random_u8_dev(iq.data_ptr(), row, nstreams, row, 0xACA25 + rank, None) == 0
+        ngate = (min(nch, max(64, args.check_channels)) + share - 1) // share
+        sc_ = SCALE * 2.0 / share                                        # K carriers share the u8 range
+        sg_ = sc_ * CARRIER * (M / (2.0 * 10 ** (SNR_DB / 10.0))) ** 0.5
+        tt = torch.arange(nout * M, dtype=torch.float64, device=dev) * (2.0 * np.pi / (12500.0 * M))
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(0xACA25 + rank)
+        for s_ in range(ngate):
+            xi = sg_ * torch.randn(nout * M, device=dev, generator=gen)
+            xq = sg_ * torch.randn(nout * M, device=dev, generator=gen)
+            for k_ in range(share):
+                c = s_ * share + k_
+                a, _ = S.channel_audio(np.random.default_rng(0xACA25 + int(own[c])), nout, gap=(3125, 12500), text_len=(20, 220))
+                env = torch.from_numpy((sc_ * CARRIER * (1.0 + DEPTH * a)).astype(np.float32)).to(dev).repeat_interleave(M)
+                ph = torch.remainder(tt * float(offs[c]) + float(phases[c]), 2.0 * np.pi).to(torch.float32)
+                xi += env * torch.cos(ph)
+                xq += env * torch.sin(ph)
+            iq[s_, 0::2] = torch.round(127.37 + 127.5 * xi).clamp_(0, 255).to(torch.uint8)
+            iq[s_, 1::2] = torch.round(127.37 + 127.5 * xq).clamp_(0, 255).to(torch.uint8)
+        del tt, env, ph, xi, xq
+        data_desc = ("uniform random bytes, seeded per dongle stream; the first %d dongles (the ones the parity gate looks at) carry the sum of "
+                     "their %d channels' ACARS/MSK carriers (150 kHz apart, AM depth %.1f, %.0f dB SNR per channel), generated on the device"
+                     % (ngate, share, DEPTH, SNR_DB))
     elif content == "format+acars":
-        assert fmt in (K.FMT_CS16, K.FMT_F32_REAL)
-        if fmt == K.FMT_CS16:
+        assert fmt in (K.FMT_CS16, K.FMT_F32_REAL, K.FMT_S16_SPLIT)
+        if fmt in (K.FMT_CS16, K.FMT_S16_SPLIT):
             assert L.acg_fill_random_u8_dev(iq.data_ptr(), row, nstreams, row, 0xACA25 + rank, None) == 0
             iq.view(torch.int16).bitwise_and_(0x0FFF)
         else:
@@ -116,12 +147,17 @@ def run_case(J, name, case, args, steps, warmup, headline):
                 xq = env * torch.sin(ph) + sigma * torch.randn(nout * M, device=dev, generator=gen)
                 v16[c, 0::2] = torch.round(32767.0 * 0.9 * xi).clamp_(-32768, 32767).to(torch.int16)
                 v16[c, 1::2] = torch.round(32767.0 * 0.9 * xq).clamp_(-32768, 32767).to(torch.int16)
+            elif fmt == K.FMT_S16_SPLIT:        # the 12-bit ADC range of the RSP in an I plane followed by a Q plane (sdrplay.c:215-220)
+                xi = env * torch.cos(ph) + sigma * torch.randn(nout * M, device=dev, generator=gen)
+                xq = env * torch.sin(ph) + sigma * torch.randn(nout * M, device=dev, generator=gen)
+                v16[c, : nout * M] = torch.round(2047.0 * 0.9 * xi).clamp_(-2048, 2047).to(torch.int16)
+                v16[c, nout * M:] = torch.round(2047.0 * 0.9 * xq).clamp_(-2048, 2047).to(torch.int16)
             else:
                 v32[c] = 2.0 * env * torch.cos(ph) + sigma * torch.randn(nout * M, device=dev, generator=gen)
         del tt, env, ph
         data_desc = ("%s; the first %d channels (the ones the parity gate looks at) carry ACARS/MSK traffic "
                      "as in the u8 cases (AM depth %.1f, %.0f dB SNR in the channel), generated on the device"
-                     % ("uniform random 12-bit int16 samples" if fmt == K.FMT_CS16 else "gaussian float32 samples", nacars, DEPTH, SNR_DB))
+                     % ("gaussian float32 samples" if fmt == K.FMT_F32_REAL else "uniform random 12-bit int16 samples", nacars, DEPTH, SNR_DB))
     elif content == "random":
         assert L.acg_fill_random_u8_dev(iq.data_ptr(), row, nstreams, row, 0xACA25 + rank, None) == 0
         data_desc = "uniform random bytes, seeded per stream (SURVEY 8d config 5: the value distribution is irrelevant to bandwidth)"
@@ -214,191 +250,11 @@ def run_case(J, name, case, args, steps, warmup, headline):
             dist.barrier(device_ids=[J.local]) if J.backend == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- correctness gate on the first pass (state starts from reset): a subset of this rank's channels goes through
-    # the CPU checkers on the very bytes the GPU consumed.  SURVEY 8c's parity statement has two halves, and the gate
-    # checks each of them and then closes the argument between them:
-    #   (1) the 12.5 kHz magnitudes of EVERY call against the oracle's down-converter: |d dm| <= 1e-5 |dm| + 1e-6 full scale
-    #       (the streaming kernel re-associates the sum; so does the reference's own -Ofast build);
-    #   (2) the blocks against the oracle's demodulator + framing fed with the dm the GPU's demodulator consumed: BIT-EXACT
-    #       (`blocks_exact_given_gpu_dm`: the demodulator and the framing are exact);
-    #   (3) the same channels once more through the library in its exact-order mode (ACG_F_EXACT_FIR: rtl.c:335-353 in the
-    #       reference's own order of operations): dm BIT-IDENTICAL to the oracle's, blocks identical END TO END -- so the only
-    #       thing that can differ between the product path and the reference is the rounding of (1);
-    #   (4) end to end with the streaming kernel (oracle down-converter -> oracle demodulator): a 1e-7 difference in dm can
-    #       flip a soft decision that sits at |vo| < 1e-3 in a noise-only stretch, after which the two loops wander apart until
-    #       the next preamble and one of them may lock a block late.  How often the reference's own builds do that to each
-    #       other is MEASURED here: the same bytes and taps through the unmodified reference compiled -O2 (IEEE) and with its
-    #       own flags (-Ofast -march=native), both from oracle/_ref.  The streaming path may differ from the oracle in no more
-    #       blocks than those two builds differ from each other, plus one.
-    #   (5) the DELIVERED records: the pass once more from reset, collected as acg_msg (ACG_F_REPAIR + acg_collect_msgs), against
-    #       orc_blk_process + orc_msg_split of the oracle's blocks of (2): every field of every message, and no message of a
-    #       block that the reference's block thread drops (acars.c:124-207).
-    # With ACG_F_REPAIR (the default) "blocks" are what outputmsg() receives: checked / repaired, parity stripped, the dropped
-    # ones omitted -- on both sides (oracle: orc_blk_process; reference builds: what their blk_thread handed to outputmsg()).
-    def gate_first_pass():
-        """the first pass from reset through the CPU checkers (the comment above); returns the parity record (rank 0) or None;
-        raises SystemExit when the GPU output differs.  Nothing in here is timed."""
-        parity = None
-        first = []
-        ncheck = min(args.check_channels, nch) if rank == 0 else 0
-        dm_gpu = {c: [] for c in range(ncheck)}
-        step(lag=0, sink=first, dm_sink=dm_gpu if ncheck else None, frames=True)
-        msgs_first = []
-        if repair:
-            dec.reset()
-            step(lag=0, sink=msgs_first)
-        parity = None
-        if rank == 0:
-            from oracle import oracle as O
-
-            def processed(frames):
-                """the oracle's block thread on raw blocks: kept ones as OrcFrame (ACG_F_REPAIR), or the raw blocks themselves"""
-                if not repair:
-                    return list(frames)
-                return [b for b in (O.blk_process(f) for f in frames) if b is not None]
-            got = {}
-            got_end = {}
-            for f in first:
-                got.setdefault(int(f.chn), []).append(D.frame_tuple(f))
-                got_end.setdefault(int(f.chn), []).append(int(f.end_bit))
-            got_msgs = {}
-            for m_ in msgs_first:
-                got_msgs.setdefault(int(m_.chn), []).append(O.msg_tuple(m_))
-            ok, nblocks, dm_err, dm_ok = True, 0, 0.0, True
-            msgs_ok, nmsgs, nraw, first_bad_msg = True, 0, 0, None
-            e2e_blocks_off, e2e_channels_off = 0, []
-            first_bad = None
-            # absolute floor of the dm tolerance: 1e-6 of the largest term of the sum.  u8: |x - 127.37| / 127.5 <= 1; CS16:
-            # 4095 / 32768; split planes (random 12-bit samples, |D| / 4): 4095 / 4; real f32: ~0.5
-            dm_fullscale = {0: 1.0, K.FMT_CS16: 1.0, K.FMT_S16_SPLIT: 1024.0, K.FMT_F32_REAL: 1.0}[fmt]
-            host_rows = iq[:(ncheck + share - 1) // share].cpu().numpy()
-            dm_orc, e2e_want = [], []
-            for c in range(ncheck):
-                r = host_rows[c // share]
-                if fmt == 0:
-                    dm = O.fir_u8(r, M, taps[c], ntaps=ntaps)
-                elif fmt == K.FMT_CS16:
-                    dm = O.fir_cs16(r.view(np.int16), M, taps[c])
-                elif fmt == K.FMT_S16_SPLIT:
-                    h = r.view(np.int16)
-                    dm = O.fir_split16(h[: h.size // 2], h[h.size // 2:], M, taps[c])
-                else:
-                    dm = O.fir_f32r(r.view(np.float32), M, taps[c])
-                dm_orc.append(dm)
-                g = np.concatenate(dm_gpu[c])
-                e = np.abs(g - dm[: g.size])
-                dm_ok &= bool(g.size == dm.size and np.all(e <= 1e-5 * np.abs(dm) + 1e-6 * dm_fullscale))
-                dm_err = max(dm_err, float(e.max()))
-                ch = O.Channel(c)
-                ch.demod(g)                                         # (2): the oracle's demodulator on the GPU's dm
-                nraw += len(ch.frames)
-                kept = processed(ch.frames)
-                want = [O.frame_tuple(f) for f in kept]
-                nblocks += len(want)
-                mine = got.get(c, [])
-                if mine != want and first_bad is None:
-                    k_ = next((i for i in range(min(len(mine), len(want))) if mine[i] != want[i]), min(len(mine), len(want)))
-                    first_bad = dict(channel=c, gpu_blocks=len(mine), oracle_blocks=len(want), first_difference_at=k_,
-                                     gpu_end_bits=got_end.get(c, []), oracle_end_bits=[int(f.end_bit) for f in ch.frames],
-                                     gpu=repr(mine[k_])[:300] if k_ < len(mine) else None, oracle=repr(want[k_])[:300] if k_ < len(want) else None)
-                ok &= mine == want
-                if repair:                                          # (5): the delivered records, field for field
-                    want_m = [O.msg_tuple(O.msg_split(b)) for b in kept]
-                    nmsgs += len(want_m)
-                    mine_m = got_msgs.get(c, [])
-                    if mine_m != want_m and first_bad_msg is None:
-                        first_bad_msg = dict(channel=c, gpu_msgs=len(mine_m), oracle_msgs=len(want_m))
-                    msgs_ok &= mine_m == want_m
-                ch2 = O.Channel(c)
-                ch2.demod(dm)                                       # (4): oracle down-converter -> oracle demodulator
-                want2 = [O.frame_tuple(f) for f in processed(ch2.frames)]
-                e2e_want.append(want2)
-                if mine != want2:
-                    e2e_channels_off.append(c)
-                    e2e_blocks_off += len(set(mine) ^ set(want2))
-            # (3) the exact-order mode of the library on the same channels
-            exact = None
-            if fmt == 0 and share == 1 and ncheck:
-                dx = D.Decoder(ncheck, decim=M, ntaps=ntaps, nstreams=ncheck, max_blocks=cb, device=J.local, bitlog=False, exact_fir=True, repair=repair)
-                dx.set_taps(taps[:ncheck])
-                xfr, xdm_same = [], True
-                for k in range(ncall):
-                    dx.in_callback(iq[:ncheck, k * cb_bytes:(k + 1) * cb_bytes], nblocks=cb, pitch=row, stream=stream)
-                    for c in range(ncheck):
-                        xdm_same &= bool(np.array_equal(dx.dm(c, cb * 1024).view(np.uint32), dm_orc[c][k * cb * 1024:(k + 1) * cb * 1024].view(np.uint32)))
-                xgot = {}
-                for f in dx.drain_frames(maxfr):
-                    xgot.setdefault(int(f.chn), []).append(D.frame_tuple(f))
-                dx.close()
-                xoff = sum(len(set(xgot.get(c, [])) ^ set(e2e_want[c])) for c in range(ncheck))
-                xsame = all(xgot.get(c, []) == e2e_want[c] for c in range(ncheck))
-                exact = dict(dm_bit_identical_to_oracle=bool(xdm_same), blocks=sum(len(w) for w in e2e_want),
-                             blocks_differing_end_to_end=int(xoff), blocks_identical_end_to_end=bool(xsame),
-                             means="the library in ACG_F_EXACT_FIR mode (rtl.c:335-353 in the reference's order) -> the same GPU demodulator: "
-                                   "everything identical to oracle down-converter -> oracle demodulator, so the streaming path's only deviation is "
-                                   "the re-associated sum of its down-converter")
-            # (4b) the reference's own builds against each other on the same bytes and taps: rtl.c in_callback for u8, soapy.c's reader
-            # loop for CS16, air.c rx_callback for real f32 (oracle/_ref: the unmodified sources, -O2 and the reference's -Ofast)
-            refs = None
-            front = {0: "rtl", K.FMT_CS16: "soapy", K.FMT_F32_REAL: "air"}.get(fmt)
-            if front and share == 1 and ncheck and not args.no_ref_leg:
-                rows_ = [host_rows[c] for c in range(ncheck)]
-                wf_ = [taps[c] for c in range(ncheck)]
-                t_ref = time.perf_counter()
-                which = "out" if repair else "raw"
-                pick = lambda d: None if d is None else d[which]
-                if front == "rtl":
-                    b_o2 = pick(O.ref_blocks("", rows_, M, wf_))
-                    b_fast, fast_label = pick(O.ref_blocks("_fast", rows_, M, wf_)), "-Ofast -march=native"
-                    if b_fast is None:
-                        b_fast, fast_label = pick(O.ref_blocks("_v3", rows_, M, wf_)), "-Ofast -march=x86-64-v3"
-                else:
-                    b_o2 = pick(O.ref_blocks("_" + front, rows_, M, wf_, front=front))
-                    b_fast, fast_label = pick(O.ref_blocks("_%s_fast" % front, rows_, M, wf_, front=front)), "-Ofast -march=x86-64-v3"
-                if b_o2 is not None and b_fast is not None:
-                    strip = lambda lst: [t[1:] for t in lst]
-                    refs = dict(o2_blocks=sum(len(x) for x in b_o2), ofast_blocks=sum(len(x) for x in b_fast),
-                                ref_fast_vs_ref_o2_blocks_differing=sum(len(set(x) ^ set(y)) for x, y in zip(b_o2, b_fast)),
-                                oracle_vs_ref_o2_blocks_differing=sum(len(set(x) ^ set(strip(y))) for x, y in zip(b_o2, e2e_want)),
-                                gpu_vs_ref_o2_blocks_differing=sum(len(set(x) ^ set(strip(got.get(c, [])))) for c, x in enumerate(b_o2)),
-                                gpu_vs_ref_ofast_blocks_differing=sum(len(set(x) ^ set(strip(got.get(c, [])))) for c, x in enumerate(b_fast)),
-                                builds="oracle/_ref (-O2, IEEE) vs the reference's own flags (%s): unmodified %s + msk.c + "
-                                       "acars.c (%s) on the GPU's input bytes and tap tables, one channel per pass, each build in a child interpreter"
-                                       % (fast_label, {"rtl": "rtl.c in_callback", "soapy": "soapy.c reader loop", "air": "air.c rx_callback"}[front],
-                                          "blocks as its blk_thread hands them to outputmsg()" if repair else "blocks as decodeAcars queues them"),
-                                cpu_seconds=round(time.perf_counter() - t_ref, 1))
-            # What the streaming path may differ from the IEEE oracle by: exactly what the reference's own -O2 and -Ofast builds differ
-            # from each other on these bytes (MEASURED above; no slack on top of it -- VERDICT r04), and, where the -Ofast leg ran, NOT
-            # AT ALL from the reference as shipped (its -Ofast build).  Without a reference leg (split planes, shared streams,
-            # --no-ref-leg, oracle/_ref absent) that yardstick is missing: (4) is then reported, not enforced -- (1)-(3) are, and they
-            # already pin the only deviation of the streaming path to the rounding of (1).
-            allowed = refs["ref_fast_vs_ref_o2_blocks_differing"] if refs else None
-            parity = dict(channels_checked=ncheck, blocks=nblocks, blocks_exact_given_gpu_dm=bool(ok),
-                          blocks_are=("what outputmsg() receives: checked / repaired by the device (ACG_F_REPAIR, acars.c:93-215), parity stripped, "
-                                      "dropped blocks omitted" if repair else "as decodeAcars queues them (pre-repair, --raw-blocks)"),
-                          raw_blocks_before_repair=nraw,
-                          blocks_exact_given_gpu_dm_means="blocks identical to the oracle's demodulator + framing (+ block repair) fed with the dm the GPU's demodulator consumed",
-                          msgs=(dict(records=nmsgs, exact=bool(msgs_ok), delivered=len(msgs_first),
-                                     means="acg_msg records of acg_collect_msgs (a second pass from reset) == orc_msg_split(orc_blk_process(block)) field for field "
-                                           "(output.c:486-560)") if repair else None),
-                          dm_within_1e5_rel=bool(dm_ok), dm_max_abs_err=dm_err, dm_samples_per_channel=nout,
-                          exact_order_mode=exact,
-                          end_to_end=dict(blocks_differing=e2e_blocks_off, channels=e2e_channels_off, exact=bool(e2e_blocks_off == 0),
-                                          allowed=allowed, allowed_means="what the reference's -O2 and -Ofast builds differ by on this input (measured in this run); "
-                                                                         "and zero against the reference's -Ofast build",
-                                          gpu_vs_ref_ofast=(refs["gpu_vs_ref_ofast_blocks_differing"] if refs else None),
-                                          note="streaming down-converter -> GPU demodulator against oracle down-converter -> oracle demodulator; a differing "
-                                               "block = a razor-edge soft decision (|vo| < 1e-3 in noise) flipped by the 1e-7 re-association of dm"),
-                          reference_builds=refs,
-                          blocks_first_pass_all_channels=len(first))
-            bad = (not (ok and dm_ok and msgs_ok) or (allowed is not None and e2e_blocks_off > allowed) or
-                   (refs is not None and (refs["gpu_vs_ref_ofast_blocks_differing"] != 0 or refs["oracle_vs_ref_o2_blocks_differing"] != 0)) or
-                   (exact is not None and not (exact["dm_bit_identical_to_oracle"] and exact["blocks_identical_end_to_end"])))
-            if bad:
-                raise SystemExit("bench[%s]: GPU output differs from the oracle: %r; first mismatch: %r %r" % (name, parity, first_bad, first_bad_msg))
-        return parity
-
-    parity = gate_first_pass()
+    # ---- correctness gate on the first pass (state starts from reset): benchlib/gate.py
+    from types import SimpleNamespace
+    from . import gate
+    parity = gate.first_pass(SimpleNamespace(args=args, J=J, name=name, rank=rank, nch=nch, share=share, fmt=fmt, M=M, taps=taps, ntaps=ntaps, iq=iq, row=row,
+                                             nout=nout, cb=cb, ncall=ncall, cb_bytes=cb_bytes, stream=stream, maxfr=maxfr, repair=repair, dec=dec, step=step))
 
     # ---- timing.  A "pass" = the hot path once over the resident batch (the step of rounds 1-2).  `burst`: `steps` single
     # passes, timed as before (about half a second at the headline case: too short to be seen by an outside observer, and
@@ -406,56 +262,13 @@ def run_case(J, name, case, args, steps, warmup, headline):
     # passes, reps chosen from the burst rate so that `steps` steps take >= --sustain seconds; per-step times (host clock at
     # the step boundaries, no extra synchronisation: the host runs at most one call ahead of the device) give min / median /
     # max, the shader clock is read from sysfs while the device is still busy.
-    def timed_region():
-        """warm-up, the burst of `steps` single passes, then the reported region: `steps` steps of `reps` passes each, bracketed
-        by barrier + synchronize on both sides; everything a step does is inside step() / drain() above: the process call(s) of
-        the hot path and the collect of the delivered records.  Returns the raw clocks and counters; no probe, no switch."""
-        for _ in range(warmup):
-            step()
-        drain()                           # flush: the timed region starts with empty queues
-        warm = dec.timing()               # event sums of warm-up: the demodulator's launches are timed here only --
-        dec.set_timing(2)                 # in the timed region only the down-converter (roofline) is bracketed,
-                                          # event records on the demodulator stream sit on its serial launch chain
-        barrier()
-        t0 = time.perf_counter()
-        nfr_b = 0
-        for _ in range(steps):
-            nfr_b += step()
-        nfr_b += drain()
-        barrier()
-        dt_burst = time.perf_counter() - t0
-        tim_b = dec.timing()
-        dt_burst, _ = shard.reduce_timing(dt_burst, nfr_b, world, J.coll, cdev)
-        reps = 1
-        if args.sustain > 0:
-            reps = max(1, int(np.ceil(args.sustain / max(dt_burst, 1e-6))))
-            if world > 1 or J.coll is not None:           # every rank must use the same reps
-                reps = int(shard.reduce_timing(float(reps), 0.0, world, J.coll, cdev)[0])
-        clk0 = gpu_clock_mhz(J.local)
-        barrier()
-        t0 = time.perf_counter()
-        nfr = 0
-        marks = [t0]
-        clk_mid, tele_mid = None, None
-        for k_ in range(steps):
-            for _ in range(reps):
-                nfr += step()
-            marks.append(time.perf_counter())
-            if k_ == steps // 2:
-                clk_mid = gpu_clock_mhz(J.local)
-                tele_mid = gpu_telemetry(J.local)
-        clk1 = gpu_clock_mhz(J.local)              # the last call(s) are still running
-        nfr += drain()                             # the last call's results: all K steps fully delivered inside the timed region
-        barrier()
-        dt_local = time.perf_counter() - t0
-        tim = dec.timing()
-        step_ms = sorted((b - a) * 1e3 for a, b in zip(marks[:-1], marks[1:]))
-        dt, nfr_total = shard.reduce_timing(dt_local, nfr, world, J.coll, cdev)
-        per_rank = shard.gather_scalars(dt_local, world, J.coll, cdev)
-        return dict(warm=warm, tim_b=tim_b, dt_burst=dt_burst, reps=reps, clk0=clk0, clk_mid=clk_mid, clk1=clk1, tele_mid=tele_mid,
-                    dt_local=dt_local, tim=tim, step_ms=step_ms, dt=dt, nfr_total=nfr_total, per_rank=per_rank)
+    # the HBM-saturating cases are reported at >= --sustain-hbm seconds (their rate sinks with the shader clock at the power cap);
+    # the cases whose step the demodulator sets have a flat clock (step spread 0.35 %) and keep --sustain
+    from .cases import SUSTAIN_HBM
+    sustain_s = args.sustain_hbm if (name in SUSTAIN_HBM and args.sustain > 0 and not args.channels) else args.sustain
 
-    T = timed_region()
+    from .timing import timed_region
+    T = timed_region(step, drain, barrier, dec, steps, warmup, sustain_s, J, sync=torch.cuda.synchronize)
     warm, tim_b, dt_burst, reps, clk0, clk_mid, clk1, tele_mid = (T[k] for k in ('warm', 'tim_b', 'dt_burst', 'reps', 'clk0', 'clk_mid', 'clk1', 'tele_mid'))
     dt_local, tim, step_ms, dt, nfr_total, per_rank = (T[k] for k in ('dt_local', 'tim', 'step_ms', 'dt', 'nfr_total', 'per_rank'))
     # measurement aids (--ab, --decoders: same-process A/B of a per-launch switch, further decoders in the same process); not part
@@ -484,8 +297,9 @@ def run_case(J, name, case, args, steps, warmup, headline):
              "roofline_frac": round(fir_bytes / (tim_b["fir_ms"] / max(1, tim_b["fir_launches"]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
              "note": "`steps` single passes over the batch from a cold-ish device, as rounds 1-2 timed them; not the reported value"}
     msk_ms_step = warm["msk_ms"] / (warmup + (2 if repair else 1)) * reps      # (the gate's one or two passes are in the sum)
+    mm = share > 1 and M in (160, 192, 200) and (cb * 1024) % 64 == 0             # (mirrors acg_fir_mm_takes)
     if fmt == 0:
-        kname = "fir_u8_shared_kernel" if share > 1 else J.fir_kernel_name(M, nout)
+        kname = ("fir_u8_mm_kernel<%d>" % (M // 8) if mm else "fir_u8_shared_kernel") if share > 1 else J.fir_kernel_name(M, nout)
     else:
         # (mirrors acg_launch_fir_fmt: the wave-private kernel <FMT, 16-byte chunks per window (per plane), windows per tile> where it is
         #  instantiated for the window length, else round 1's workgroup-granular kernel)
@@ -495,14 +309,38 @@ def run_case(J, name, case, args, steps, warmup, headline):
         kname = ("fir_fmt_direct_kernel<%d, %d, %d>" % ((fid,) + shape)) if shape else "fir_fmt_kernel<%d>" % fid
     # HBM traffic of this launch shape from the committed PMC passes (rocprofv3 cannot run inside the timed
     # process): looked up by the full kernel signature and launch shape, not measured in this run -- the source is named next to the number
-    traffic, traffic_src = lookup_traffic(kname, nch, M, ntaps, nblk / lps) if share == 1 else (None, None)
+    traffic, traffic_src = lookup_traffic(kname, nch, M, ntaps, nblk / lps)
     whole = step_bytes * steps / dt / 1e9                            # per GPU
+    # the rate over the first ~5 s of the timed region (what rounds 1-5 reported as `value` for every case)
+    marks = T["marks"]
+    k5 = next((i for i in range(1, len(marks)) if marks[i] - marks[0] >= 5.0), len(marks) - 1)
+    burst5s = world * samples_per_step * k5 / (marks[k5] - marks[0]) / 1e6 if (sustain_s > 5.0 and k5 < len(marks) - 1) else None
+    tele3 = [T["tele0"], tele_mid, T["tele1"]]
+    # the demodulator's own bound (it sets the step of the <= 2048-channel cases): a serial recurrence per channel, ~325
+    # instructions per bit period issued from one wave per SIMD at >= 4 cycles each (profiles/r05_probe_msk_phase_stamps.txt)
+    msk_launches = max(1, warm["msk_launches"]) if "msk_launches" in warm else None
+    roofline_msk = None
+    if msk_launches and clk_mid:
+        us_bit = warm["msk_ms"] / msk_launches * 1e3 / ((nblk * (warmup + (2 if repair else 1)) * 1024 / msk_launches) * 2400.0 / 12500.0)
+        # (mirrors acg_create: lanes per channel by channel count; <= 2048 channels: the demodulator's own CU partition of 2.5 x its
+        #  one-wave-per-SIMD minimum, at most 80 CUs)
+        dec_lpc = 8 if nch <= 8192 else 4 if nch <= 16384 else 2 if nch <= 32768 else 1
+        msk_waves = nch * dec_lpc / 64.0
+        msk_cus = min(80, (5 * max(1, int((msk_waves + 3) // 4)) + 1) // 2) if nch <= 2048 else 256
+        waves_per_simd = max(1.0, msk_waves / (4.0 * msk_cus))
+        cyc = us_bit * clk_mid / waves_per_simd
+        roofline_msk = {"bound": "issue", "kernel": "msk_demod_kernel", "us_per_bit": round(us_bit, 4), "waves_per_simd": round(waves_per_simd, 2),
+                        "cycles_per_bit_per_wave": round(cyc, 0), "instr_per_bit": 325, "floor_cycles_per_bit": 1300,
+                        "frac": round(1300.0 / cyc, 3) if cyc > 0 else None,
+                        "note": "launch time / bit periods per channel, at the shader clock read mid-run; floor = 325 instructions x 4 issue cycles "
+                                "(one wave per SIMD cannot issue faster); the arithmetic is the reference's operation for operation"}
     out = {
         "value": round(value, 1),
         "ms_per_step": round(dt / steps * 1e3, 4),
         "timed_region_s": round(dt, 4),
         "sustain": {"passes_per_step": reps, "step_ms_min_median_max": [round(step_ms[0], 3), round(step_ms[len(step_ms) // 2], 3), round(step_ms[-1], 3)],
-                    "shader_clock_mhz_start_mid_end": [clk0, clk_mid, clk1], "telemetry_mid_run": tele_mid,
+                    "shader_clock_mhz_start_mid_end": [clk0, clk_mid, clk1], "telemetry_mid_run": tele_mid, "telemetry_start_mid_end": tele3,
+                    "sustain_s_asked": sustain_s, "burst5s": (round(burst5s, 1) if burst5s else None),
                     "note": "a step = passes_per_step passes over the resident batch (chosen from the burst rate so that the timed region lasts "
                             ">= --sustain seconds); step times from host time stamps at the step boundaries (the host runs at most one call ahead "
                             "of the device); clocks from sysfs while the device is busy (null where the box does not expose them)"},
@@ -547,6 +385,11 @@ def run_case(J, name, case, args, steps, warmup, headline):
                             "demodulator of i); the demodulator figure is taken during warm-up (its events are off in the timed region)"},
         "parity": parity,
     }
+    if roofline_msk:
+        out["roofline_msk"] = roofline_msk
+    import re
+    m_ = re.search(r"profiles/(r\d+)_", traffic_src or "")
+    out["roofline"]["traffic_src"] = ((m_.group(1) if m_ else "committed") if traffic else None)      # "live" where bench.py measured it in this run
     if ab:
         out["ab_same_process"] = ab
     if trials:
@@ -560,10 +403,24 @@ def run_case(J, name, case, args, steps, warmup, headline):
         out["config"]["collectives"] = "forced through torch.distributed/%s with world size 1 (--rccl-selftest)" % J.backend
     if share > 1:
         out["config"]["channels_per_stream"] = share
-        out["roofline"]["note"] = ("shared-stream mode: %d channels reuse each stream's bytes, the down-converter is VALU-bound "
-                                   "(8*K flop per 2 B); achieved counts each stream once and is NOT the HBM roofline figure" % share)
-        keff = min(share, 8)
-        ops = nch * nout * M * (2.0 + 3.0 / keff) * steps / (tim["fir_ms"] * 1e-3)
-        out["valu"] = {"kernel": "fir_u8_shared_kernel", "lane_ops_per_s": round(ops, 0), "peak": 256 * 4 * 16 * 2.4e9,
-                       "frac": round(ops / (256 * 4 * 16 * 2.4e9), 4), "lane_ops_per_channel_sample": round(2.0 + 3.0 / keff, 3)}
+        fir_s = tim["fir_ms"] * 1e-3 / max(1, tim["fir_launches"])             # seconds per launch
+        flops = 8.0 * nch * (nout / lps) * M / fir_s                            # rtl.c:349-351: 8 flop per channel-sample
+        if mm:
+            ks = (M // 8 + 1) // 2
+            groups = nstreams * ((share + 7) // 8)
+            mops = groups * (nout / lps / 32.0) * ks * 2 * 65536.0 / fir_s     # two v_mfma_i32_32x32x32_i8 per 32 windows x 32 bytes x group
+            out["roofline"]["note"] = ("rtl.c's shape: %d channels reuse each dongle stream's bytes (a [windows x 2M] x [2M x 2K] contraction); on the "
+                                       "matrix pipe (exact int8 digits, fir_mm.hip) it is HBM-bound again: achieved counts each stream ONCE.  Not the "
+                                       "figure of the one-stream-per-channel path" % share)
+            out["roofline"]["valu_equivalent"] = {"flop_per_s": round(flops, 0), "peak": 157.3e12, "frac": round(flops / 157.3e12, 4),
+                                                  "means": "8 flop x channel-samples/s of this kernel against the packed-f32 vector peak "
+                                                           "(MI355X_MICROARCH.md: 157.3 TFLOP/s): what a VALU kernel would have to sustain"}
+            out["roofline"]["mfma_i8"] = {"ops_per_s": round(mops, 0), "peak": 5.03e15, "frac": round(mops / 5.03e15, 4)}
+        else:
+            out["roofline"]["note"] = ("shared-stream mode: %d channels reuse each stream's bytes, the vector-pipe down-converter is VALU-bound "
+                                       "(8*K flop per 2 B); achieved counts each stream once and is NOT the HBM roofline figure" % share)
+            keff = min(share, 8)
+            ops = nch * nout * M * (2.0 + 3.0 / keff) * steps / (tim["fir_ms"] * 1e-3)
+            out["valu"] = {"kernel": "fir_u8_shared_kernel", "lane_ops_per_s": round(ops, 0), "peak": 256 * 4 * 16 * 2.4e9,
+                           "frac": round(ops / (256 * 4 * 16 * 2.4e9), 4), "lane_ops_per_channel_sample": round(2.0 + 3.0 / keff, 3)}
     return out

@@ -29,7 +29,20 @@ CASES = {
     "f32": dict(tag="air.c real-f32 front end (SURVEY 8f.2)", channels=4096, decim=200, ntaps=200, blocks=16, content="format+acars", format="f32"),
     # BASELINE.json configs[3] per-GPU share: 16384 channels over 8 GPUs
     "shard2048": dict(tag="BASELINE configs[3], per-GPU share", channels=2048, decim=200, ntaps=200, blocks=64, content="acars"),
+    # north_star: "from 2.0/2.5 Msps"; rtlMult 160 is the reference's default (acarsdec.c:57), 192 its other documented rate (rtl.c:35-37):
+    # fir_u8_direct_kernel<20> / <24>, one stream per channel
+    "m160": dict(tag="rtlMult 160 = 2.0 Msps, the reference's default (acarsdec.c:57)", channels=4096, decim=160, ntaps=160, blocks=16, content="random+acars"),
+    "m192": dict(tag="rtlMult 192 = 2.4 Msps (rtl.c:35-37)", channels=4096, decim=192, ntaps=192, blocks=16, content="random+acars"),
+    # the sdrplay.c front end's sample format (an int16 I plane and an int16 Q plane, sdrplay.c:215-236)
+    "split16": dict(tag="sdrplay.c split int16 planes (SURVEY 8f.2)", channels=4096, decim=160, ntaps=160, blocks=16, content="format+acars", format="split16"),
+    # rtl.c's OWN shape (rtl.c:344-354): one dongle stream feeds K channels -- 2048 dongles x 8 channels; the contraction runs on
+    # the matrix pipe (fir_mm.hip).  Never the HBM-roofline figure of the one-stream-per-channel path.
+    "share8": dict(tag="rtl.c's own shape: 2048 dongle streams x 8 channels each (rtl.c:344-354)", channels=16384, decim=200, ntaps=200, blocks=16,
+                   content="shared+acars", share=8),
 }
+# The cases that saturate HBM hold the chip at its power cap and their rate sinks with the shader clock for tens of seconds
+# (profiles/r05_soak.txt): their `value` is the >= 20 s figure (--sustain-hbm), the first 5 s are reported beside it (burst5s).
+SUSTAIN_HBM = ("wide", "stress", "cs16", "f32")
 # The reference's own interface: the input arrives in HOST memory that is only valid during the call (rtl.c:314-330,
 # soapy.c:220-254).  10 000 channels x 2.5 Msps is 50 GB/s -- PCIe Gen5 territory: this case says whether the ">= 10 000
 # concurrent channels" of the north star holds for inputs that come from a host (run_hostfed below; not a run_case shape).
@@ -55,9 +68,10 @@ def make_taps(D, fmt_name, offs, M, ntaps):
     for c in range(nch):
         o = int(offs[c])
         if o not in cache:
-            # the front end's own tap builder (rtl.c:283-286 / soapy.c:163-166 / air.c:278-285)
+            # the front end's own tap builder (rtl.c:283-286 / soapy.c:163-166 / air.c:278-285 / sdrplay.c:160-165)
             base = (D.rtl_taps(fc + o, fc, M) if fmt_name == "u8" else
-                    D.airspy_taps(fc - o, fc, M * 12500) if fmt_name == "f32" else D.soapy_taps(fc + o, fc, M))
+                    D.airspy_taps(fc - o, fc, M * 12500) if fmt_name == "f32" else
+                    D.sdrplay_taps(fc + o, fc) if (fmt_name == "split16" and M == 160) else D.soapy_taps(fc + o, fc, M))
             cache[o] = (base[:ntaps] * win[:, None]).astype(np.float32)
         taps[c] = cache[o]
     return taps

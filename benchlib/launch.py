@@ -23,7 +23,7 @@ def self_launch(args):
     import torch
     backend = os.environ.get("ACG_BENCH_BACKEND", "nccl")
     ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    if ndev < args.gpus and backend != "gloo":
+    if ndev < args.gpus and backend != "gloo" and not getattr(args, "dry_run", False):
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (ACG_BENCH_BACKEND=gloo rehearses the launch path "
                          "with several ranks per GPU)" % (args.gpus, ndev))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")

@@ -17,7 +17,9 @@
  *      initMsk()/demodMSK() with the reference's own signatures (acarsdec.h:190-191) on top of (1), so
  *      acars.c/output.c link unchanged.  See INTEGRATION.md.
  * Measurement and diagnostic entry points (tuning switches, probes, self tests, generators) are NOT product API: they are
- * declared in acarsdec_amd_lab.h.  The shared library exports exactly what these three headers declare.
+ * declared in acarsdec_amd_lab.h.  The shared library exports exactly what THIS header and acarsdec_amd_lab.h declare (a linker
+ * version script made from them); what acarsdec_amd_compat.h declares lives in compat_msk.c, which is compiled into the
+ * reference program, not into the library.
  */
 #ifndef ACARSDEC_AMD_H
 #define ACARSDEC_AMD_H
@@ -80,8 +82,10 @@ typedef struct {
 	int max_blocks;     /* capacity: 1024-output blocks per acg_process_* call */
 	uint32_t flags;
 	int max_lag;        /* most process calls acg_collect_* may stay behind (sizes the block queue: the worst case of
-	                       max_lag + 1 calls).  0 = as many as fit into 512 MiB, at most 6; a host that collects with
-	                       lag <= 1 after every call asks for 1 and gets the smallest queue */
+	                       max_lag + 1 calls, 304 B per block, rounded UP to a power of two -- so up to twice that worst
+	                       case is allocated; acg_max_lag() says what the queue really holds).  0 = as many calls as fit
+	                       into a power-of-two queue of at most 512 MiB, at most 6 (very wide contexts: two calls,
+	                       whatever they cost); a host that collects with lag <= 1 after every call asks for 1 */
 } acg_config;
 
 /* MSK + framing fields of channel_t (acarsdec.h:76-89) */
@@ -93,6 +97,11 @@ typedef struct {
 	float inb[2 * ACG_FLEN];      /* re,im interleaved (acarsdec.h:83) */
 	int outbits, nbits, Acarsstate;
 	int blk_len, blk_err;
+	int soh_back;                 /* not in channel_t: 12.5 kHz samples since the SOH byte of the block being assembled completed
+	                                 (where acars.c:290 stamps blk->tv; what soh_sample of that block will be measured from).
+	                                 Meaningful while Acarsstate is TXT / CRC1 / CRC2, else 0.  acg_set_state() re-bases it on the
+	                                 destination slot's own sample counter, so a channel moved mid-block keeps its time stamp;
+	                                 a host that leaves it 0 stamps the block at the moment of the move. */
 } acg_chan_state;
 
 /* A message block as decodeAcars() queues it (msgblk_t, acarsdec.h:48-57; acars.c:350-364):
@@ -229,7 +238,8 @@ int  acg_drain_frames(acg_ctx *ctx, acg_frame *out, int max_frames, int *nframes
 int  acg_collect_frames(acg_ctx *ctx, int lag, acg_frame *out, int max_frames, int *nframes);
 /* Largest lag this context accepts: its block queue is sized for the worst case (a 56-bit block every 291 samples on
  * every channel) of acg_max_lag() + 1 calls, so a host that collects after every call cannot be lapped.
- * acg_config.max_lag if that was given, else 6 unless that would take more than 512 MiB (then fewer, at least 1). */
+ * At least acg_config.max_lag if that was given (the power-of-two queue may hold more), else 6 unless that would take
+ * more than 512 MiB (then fewer, at least 1). */
 int  acg_max_lag(const acg_ctx *ctx);
 /* SURVEY 8f.4, the batch sink: like acg_drain_frames / acg_collect_frames, but every block is taken through
  * outputmsg()'s field split on the device and handed over as a fixed binary record.  Needs ACG_F_REPAIR (outputmsg()

@@ -475,6 +475,7 @@ def _ref_blocks_child(variant, path_in, path_out):
     import pickle
     z = np.load(path_in)
     rows, taps, M, front = z["rows"], z["taps"], int(z["M"]), str(z["front"])
+    row_of = z["row_of"]
     os.dup2(os.open(os.devnull, os.O_WRONLY), 2)          # init* narrates on stderr
     blk = 1024 * M * 2
     ref = Ref(variant)
@@ -482,9 +483,9 @@ def _ref_blocks_child(variant, path_in, path_out):
         getattr(ref.L, "ref_set_oscillator" if front in ("soapy", "sdrplay") else "ref_set_wf").argtypes = [C.c_int, C.c_void_p, C.c_int]
     grab = lambda fr: [(int(f.len), int(f.err), bytes(f.crc), bytes(f.txt[: max(0, f.len)])) for f in fr]
     raw, out = [], []
-    for c in range(rows.shape[0]):
+    for c in range(taps.shape[0]):
         t = np.ascontiguousarray(taps[c], dtype=np.float32)
-        r = np.ascontiguousarray(rows[c]).reshape(-1)
+        r = np.ascontiguousarray(rows[int(row_of[c])]).reshape(-1)
         if front == "rtl":
             ref.init_rtl(["131.725"], M)                  # one channel; its state is re-initialised by every init
             ref.set_wf(0, t)
@@ -510,14 +511,15 @@ def _ref_blocks_child(variant, path_in, path_out):
         pickle.dump(dict(raw=raw, out=out), w)
 
 
-def ref_blocks(variant, rows, M, taps, timeout_s=600, front="rtl"):
+def ref_blocks(variant, rows, M, taps, timeout_s=600, front="rtl", row_of=None):
     """The UNMODIFIED reference build `variant` ("" = -O2 IEEE, "_fast" = the reference's own -Ofast -march=native,
     "_v3"; front="soapy" / "air" / "sdrplay": "_soapy" / "_air" / "_sdrplay" and their "_fast" twins) run over rows[c] (whole
     callbacks of u8 I/Q; CS16 samples; real f32 samples; an int16 I plane followed by the Q plane) with channel c's tap table taps[c], one channel per pass, through its own front end
     (rtl.c in_callback / soapy.c's reader loop / air.c rx_callback) -> demodMSK -> decodeAcars -> blk_thread.  Returns
     {"raw": [...], "out": [...]}: per channel the blocks as decodeAcars queued them and as outputmsg() received them, each
     (len, err, crc, txt) -- or None when the build is missing or cannot run on this host.  Runs in a child interpreter; rows
-    and taps travel through a temporary file."""
+    and taps travel through a temporary file.  row_of[c] = the row channel c reads (default c: one row per channel; several
+    channels of one dongle name the same row)."""
     import pickle
     import sys
     import tempfile
@@ -529,7 +531,8 @@ def ref_blocks(variant, rows, M, taps, timeout_s=600, front="rtl"):
         for c, t in enumerate(taps):
             t = np.ascontiguousarray(t, dtype=np.float32).reshape(-1, 2)
             tp[c, : t.shape[0]] = t
-        np.savez(pin, rows=np.stack([np.ascontiguousarray(r).reshape(-1).view(np.uint8) for r in rows]), taps=tp, M=M, front=front)
+        np.savez(pin, rows=np.stack([np.ascontiguousarray(r).reshape(-1).view(np.uint8) for r in rows]), taps=tp, M=M, front=front,
+                 row_of=np.arange(len(taps)) if row_of is None else np.asarray(row_of, dtype=np.int64))
         code = "import sys; sys.path.insert(0, %r); from oracle import oracle as O; O._ref_blocks_child(%r, %r, %r)" % (
             os.path.dirname(HERE), variant, pin, pout)
         try:

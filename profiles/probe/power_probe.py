@@ -4,7 +4,7 @@ a pure streaming reader, and the down-converter alone -- default kernel, round 1
 import os, sys, time, threading, ctypes as C
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np, torch
-import bench
+from benchlib.telemetry import gpu_telemetry
 from acarsdec_amd import decoder as D, _capi as K
 L = K.load()
 nch, M, nblk = 16384, 200, 4
@@ -22,7 +22,7 @@ def run(tag, fn, seconds=2.5):
     samples, stop = [], threading.Event()
     def sampler():
         while not stop.is_set():
-            samples.append(bench.gpu_telemetry(0)); time.sleep(0.02)
+            samples.append(gpu_telemetry(0)); time.sleep(0.02)
     fn(); torch.cuda.synchronize()
     th = threading.Thread(target=sampler); th.start()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -40,9 +40,12 @@ def run(tag, fn, seconds=2.5):
         tag, n * bytes_ / e0.elapsed_time(e1) / 1e6, n * bytes_ / e0.elapsed_time(e1) / 8e9, sclk, pw, s[-1]["fclk"], s[-1]["mclk"], len(s)), flush=True)
 
 sink = torch.zeros(1, dtype=torch.int32, device="cuda")
-LI = C.CDLL(K.LIB_PATH)
-LI.acg_launch_read_probe.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]
-run("pure streaming reader (read_probe_kernel)", lambda: LI.acg_launch_read_probe(iq.data_ptr(), iq.numel(), sink.data_ptr(), 256, st.cuda_stream))
+# (the launcher acg_launch_read_probe is local to the library since round 5's version script: the exported lab entry point
+#  acg_probe_read_dev runs the same kernel, one repeat per call -- ADVICE r05)
+LI = K.load()
+LI.acg_probe_read_dev.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]
+_gbs = C.c_double(0)
+run("pure streaming reader (read_probe_kernel)", lambda: LI.acg_probe_read_dev(iq.data_ptr(), iq.numel(), 1, C.byref(_gbs)))
 for tag, var, extra in (("down-converter alone, default kernel (variant 5)", "5", None), ("..., register taps (variant 7)", "7", None),
                         ("..., default kernel without its arithmetic (variant 56: loads consumed, no cvt / FMA / tap reads)", "56", None),
                         ("..., round 1's workgroup kernel (variant 3)", "3", None), ("..., variant 3 without its arithmetic (loads + LDS staging only)", "3", "ACG_FIR_DEBUG_NOCOMPUTE")):

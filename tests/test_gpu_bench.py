@@ -80,11 +80,14 @@ def test_bench_also_cases_in_one_line():
             "bench.CASES['wide'].update(channels=512, blocks=2); bench.CASES['stress'].update(channels=256, blocks=2); "
             "bench.CASES['cs16'].update(channels=256, blocks=2); bench.CASES['f32'].update(channels=256, blocks=2); "
             "bench.CASES['shard2048'].update(channels=192, blocks=4); "
-            "sys.argv = ['bench.py', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--sustain', '0.5', '--hostfed-channels', '320']; bench.main()")
+            "bench.CASES['m160'].update(channels=256, blocks=4); bench.CASES['m192'].update(channels=256, blocks=4); "
+            "bench.CASES['split16'].update(channels=256, blocks=4); bench.CASES['share8'].update(channels=512, blocks=4); "
+            "sys.argv = ['bench.py', '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--sustain', '0.5', '--sustain-hbm', '0.5', "
+            "'--hostfed-channels', '320']; bench.main()")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
     d = last_json(r.stdout)
-    assert set(d["also"]) == {"wide", "stress", "shard2048", "cs16", "f32", "hostfed", "rtl8"}
+    assert set(d["also"]) == {"wide", "stress", "shard2048", "cs16", "f32", "hostfed", "rtl8", "m160", "m192", "split16", "share8"}
     hf = d["also"].pop("hostfed")
     # BASELINE configs[1]: one dongle's 8 (and 16) channels on one 2.0 Msps stream, a callback at a time from host memory --
     # the legacy view (the reference program on compat_msk.c), the batched API with nstreams = 1, the CPU reference; ms per
@@ -107,22 +110,31 @@ def test_bench_also_cases_in_one_line():
     assert set(c["also"]) == set(d["also"]) | {"hostfed", "rtl8"} and all(a["parity_ok"] is True for k_, a in c["also"].items() if k_ != "rtl8")
     assert c["also"]["rtl8"]["ch8"]["parity_ok"] is True and c["also"]["rtl8"]["ch16"]["batched_ms"] > 0
     # every format's gate has its reference-builds leg now (rtl.c / soapy.c / air.c from oracle/_ref) where the builds travelled
-    for name in ("cs16", "f32"):
+    # (round 6: sdrplay.c for the split planes, and rtl.c's in_callback channel by channel for the 8-channels-per-dongle case)
+    for name in ("cs16", "f32", "split16", "share8", "m160", "m192"):
         rb = d["also"][name]["parity"]["reference_builds"]
         if rb is not None:
             assert rb["oracle_vs_ref_o2_blocks_differing"] == 0 and rb["gpu_vs_ref_ofast_blocks_differing"] == 0
     assert c["also"]["hostfed"]["hostfed"]["realtime"] in (True, False)
-    assert c["also"]["shard2048"]["channels"] == 192 and "u8" not in d["also"]["cs16"]["config"]["arithmetic"]
+    assert c["also"]["shard2048"]["ch"] == 192 and "u8" not in d["also"]["cs16"]["config"]["arithmetic"]
+    # rtl.c's own shape on the matrix pipe: 8 channels per dongle stream, the kernel named, its HBM fraction and what a VALU kernel would need
+    s8 = d["also"]["share8"]
+    assert s8["config"]["channels_per_stream"] == 8 and s8["roofline"]["kernel"] == "fir_u8_mm_kernel<25>" and s8["roofline"]["bound"] == "hbm"
+    assert s8["roofline"]["valu_equivalent"]["frac"] > 0 and 0 < s8["roofline"]["mfma_i8"]["frac"] < 1 and "ACARS" in s8["data"]
+    assert c["also"]["share8"]["ch_per_stream"] == 8 and c["also"]["split16"]["fmt"] == "split16" and c["also"]["m160"]["M"] == 160
+    assert d["also"]["m160"]["roofline"]["kernel"].startswith("fir_u8_direct_kernel<20,") and d["also"]["m192"]["roofline"]["kernel"].startswith("fir_u8_direct_kernel<24,")
+    assert d["also"]["split16"]["roofline"]["kernel"] == "fir_fmt_direct_kernel<2, 20, 64>" and "ACARS" in d["also"]["split16"]["data"]
+    assert d["roofline_msk"]["bound"] == "issue" and d["roofline_msk"]["us_per_bit"] > 0 and c["roofline_msk"]["instr_per_bit"] == 325
     for name, a in d["also"].items():
         assert a["parity"]["dm_within_1e5_rel"] is True and a["parity"]["blocks_exact_given_gpu_dm"] is True and a["parity"]["channels_checked"] == 64
-        if name not in ("cs16", "f32"):                   # (the exact-order mode restates rtl.c's u8 loop)
+        if name not in ("cs16", "f32", "split16"):        # (the exact-order mode restates rtl.c's u8 loop)
             assert a["parity"]["exact_order_mode"]["blocks_identical_end_to_end"] is True
         assert 0 < a["roofline"]["frac"] < 1 and 0 < a["whole_job_frac_of_hbm"] < 1 and a["value"] > 0
         # sustained timing: a step is several passes, the timed region lasts what --sustain asked for, value follows from it
         su = a["sustain"]
         assert su["passes_per_step"] >= 1 and a["timed_region_s"] >= 0.25 and len(su["step_ms_min_median_max"]) == 3     # (reps come from the burst rate)
         c = a["config"]
-        want = c["channels_per_gpu"] * c["blocks_per_step"] * 1024 * c["decim"] * 3 / a["timed_region_s"] / 1e6
+        want = c["channels_per_gpu"] * c["blocks_per_step"] * 1024 * c["decim"] * 3 / a["timed_region_s"] / 1e6       # (every channel counts, shared stream or not)
         assert abs(a["value"] - want) < 2e-3 * want and c["blocks_per_step"] == c["blocks_per_pass"] * su["passes_per_step"]
     # the stress and CS16 cases' gate channels carry ACARS (their block comparison is not vacuous at the real sizes; at this
     # test's 0.16 s of signal a block may or may not complete)

@@ -1,6 +1,8 @@
 """Round 6: the shared-stream down-converter on the matrix pipe (fir_mm.hip: rtl.c:344-354 with K channels per dongle as an
 exact int8 contraction), the legacy view's context made at initMsk() time, and the configurations that were never timed before
 (rtlMult 160 / 192, SDRplay planes) through the bench gate.  All through the C ABI; the oracle is the checker."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -139,3 +141,102 @@ def test_matrix_pipe_blocks_one_dongle_sixteen_channels(D, O, S):
         assert got1.get(c, []) == want, c
         total += len(want)
     assert total >= nch
+
+
+@pytest.mark.parametrize("fe", ["rtl", "soapy", "air", "sdrplay", "file"])
+def test_legacy_view_first_callback_fits_its_transfer_period(fe, S, O, tmp_path):
+    """the legacy view made its GPU context inside the FIRST callback (0.14-0.27 s; librtlsdr's four-buffer
+    ring absorbs that, libairspy / SDRplay callbacks do not).  compat_msk.c now makes the context -- and runs one throw-away call
+    through it -- when initMsk() sees the last channel (acarsdec.c:445-454).  Every front end's program: the first entry-point
+    call costs what the others cost (far below the shortest transfer period of its radio: an Airspy transfer of 20 000 samples
+    at 2.5 Msps lasts 8 ms, an rtl.c callback 81.92 ms), the context's cost is reported separately, the output is unchanged
+    (the four test_compat_* tests), and the printed messages arrive."""
+    import os
+    import re
+    import subprocess
+    from conftest import ROOT, GOLDEN
+    exe = os.path.join(ROOT, "acarsdec_amd", "lib", "acarsdec_gpu" + ("" if fe == "file" else "_" + fe))
+    if not os.path.exists(exe):
+        pytest.skip("demo binary not built (needs the reference tree at build time)")
+    z = np.load(os.path.join(GOLDEN, "testwav_pcm16.npz"))
+    wav = (z["pcm"].astype(np.float32) / np.float32(32768.0))
+    freqs = ["131.525", "131.725", "131.825", "131.550"]
+    fr = [int(round(float(f) * 1e6)) for f in freqs]
+    env = S.pad_blocks(0.5 + 0.5 * wav.T.astype(np.float64), 1024, 0.5)
+    env = np.concatenate([env, np.full((4, 1024 * 3), 0.5)], axis=1)
+    ph = [0.3, 1.1, 2.2, 0.7]
+    envv = dict(os.environ, ACARSDEC_AMD_STATS="1")
+    if fe == "file":
+        import wave
+        src = str(tmp_path / "t.wav")                       # the golden recording (tests/golden/testwav_pcm16.npz) as a PCM16 file again
+        with wave.open(src, "wb") as wv:
+            wv.setnchannels(z["pcm"].shape[1])
+            wv.setsampwidth(2)
+            wv.setframerate(12500)
+            wv.writeframes(np.ascontiguousarray(z["pcm"], dtype="<i2").tobytes())
+        args = ["-o", "1", "-f", src]
+    else:
+        if fe == "rtl":
+            fc = O.choose_fc(fr, 160)
+            data = S.iq_u8_from_envelopes(env, 160, [f - fc for f in fr], phases=ph)
+            args = ["-o", "1", "-r", "0"] + freqs
+        elif fe == "soapy":
+            data = S.iq_s16_from_envelopes(env, 160, [f - 131850000 for f in fr], phases=ph)
+            args = ["-o", "1", "-m", "160", "-d", "file"] + freqs
+        elif fe == "air":
+            rate = 2500000
+            fc = O.air_choose_fc(fr)
+            data = S.real_f32_from_envelopes(env, rate // 12500, [fc - f + rate / 4 for f in fr], phases=ph, scale=0.15)
+            args = ["-o", "1", "-s", "0"] + freqs
+        else:
+            data = S.iq_s16_from_envelopes(env, 160, [f - 131850000 for f in fr], phases=ph, full_scale=0.06)
+            args = ["-o", "1", "-s"] + freqs
+        path = tmp_path / ("t." + fe)
+        path.write_bytes(data.tobytes())
+        envv["ACARSDEC_IQ_FILE"] = str(path)
+    r = subprocess.run([exe] + args, env=envv, capture_output=True, timeout=300)
+    err = r.stderr.decode("latin-1")
+    assert r.returncode == 0, err[-800:]
+    m = re.search(r"acarsdec_amd compat: (\d+) calls, .*first call ([0-9.]+) ms; the others ([0-9.]+) ms per call; context made at initMsk\(\) time in ([0-9.]+) ms", err)
+    assert m, err[-600:]
+    calls, first, others, ctx = int(m.group(1)), float(m.group(2)), float(m.group(3)), float(m.group(4))
+    assert calls > 10 and ctx > 5.0                              # the context was paid for before the radio started
+    assert first < 5.0 and first < 8.0, (first, others, ctx)     # < 5 ms: inside every front end's shortest transfer period
+    assert len([l for l in r.stdout.decode("latin-1").splitlines() if l.startswith("#")]) == 7
+
+
+def test_channel_moved_mid_block_keeps_its_soh_stamp(D, O, S):
+    """the SOH stamp (where acars.c:290 stamps blk->tv) was not part of acg_chan_state, so a channel moved to another
+    slot / context with acg_get_state -> acg_set_state while a block was being assembled delivered that block with a stale stamp.
+    acg_chan_state.soh_back carries it as a distance now: cut a stream in the middle of a block, move the channel to slot 1 of a
+    second context whose sample counter stands elsewhere, finish there -- the block's end - SOH distance is the oracle's."""
+    from acarsdec_amd import _capi as K
+    rng = np.random.default_rng(606)
+    n = 8 * 1024
+    a, _ = S.channel_audio(rng, n, nframes=1, gap=(1500, 1600), text_len=(150, 160))
+    x = S.envelope(a, noise=0.003, rng=rng).astype(np.float32)
+    ch = O.Channel(0)
+    ch.demod(x)
+    assert len(ch.frames) == 1
+    f = ch.frames[0]
+    cut = (int(f.soh_sample) + int(f.end_sample)) // 2 // 1024 * 1024          # a call boundary strictly inside the block
+    assert int(f.soh_sample) < cut < int(f.end_sample)
+    d1 = D.Decoder(1, decim=8, ntaps=8, nstreams=1, max_blocks=8)
+    d1.demod_msk(x[:cut].reshape(1, -1))
+    s = K.ChanState()
+    d1._chk(d1.L.acg_get_state(d1.ctx, 0, C.byref(s)))
+    assert s.Acarsstate in (3, 4, 5) and s.soh_back == cut - int(f.soh_sample)
+    assert d1.drain_frames() == []
+    d2 = D.Decoder(2, decim=8, ntaps=8, nstreams=2, max_blocks=8)
+    skew = np.full((2, 3 * 1024), 0.5, dtype=np.float32)                       # the destination has consumed 3072 samples already
+    d2.demod_msk(skew)
+    d2._chk(d2.L.acg_set_state(d2.ctx, 1, C.byref(s)))
+    rest = np.full((2, n - cut), 0.5, dtype=np.float32)
+    rest[1] = x[cut:]
+    d2.demod_msk(rest)
+    got = [g for g in d2.drain_frames() if int(g.chn) == 1]
+    assert len(got) == 1 and D.frame_tuple(got[0])[1:] == O.frame_tuple(f)[1:]
+    assert int(got[0].end_sample) - int(got[0].soh_sample) == int(f.end_sample) - int(f.soh_sample)
+    assert int(got[0].end_sample) == 3 * 1024 + (int(f.end_sample) - cut)      # (the destination's own sample index)
+    d1.close()
+    d2.close()

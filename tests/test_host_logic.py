@@ -81,7 +81,7 @@ def test_tuning_switches_go_through_one_table_not_the_environment():
     lab = open(K.LAB_PATH, "rb").read().decode("latin-1")
     for name in ("fir_u8_coltap_kernel", "fir_u8_mfma_kernel", "fir_u8_dma_kernel", "fir_u8_tile_kernel", "msk_demod2_kernel"):
         assert name not in sym and name in lab, name
-    for name in ("fir_u8_direct_kernel", "fir_u8_persist_kernel", "fir_u8_shared_kernel", "fir_u8_generic_kernel", "fir_fmt_direct_kernel",
+    for name in ("fir_u8_direct_kernel", "fir_u8_persist_kernel", "fir_u8_shared_kernel", "fir_u8_mm_kernel", "fir_u8_generic_kernel", "fir_fmt_direct_kernel",
                  "msk_demod_kernel", "blk_repair_kernel", "msg_split_kernel"):
         assert name in sym, name
     assert os.path.getsize(K.LIB_PATH) < 0.75 * os.path.getsize(K.LAB_PATH)
@@ -404,8 +404,19 @@ def test_bench_compact_line_stays_under_4k_at_the_full_case_shape():
     import bench
     with open(os.path.join(ROOT, "profiles", "r03_bench_line.json")) as f:
         d = json.load(f)
-    for extra in ("shard2048", "hostfed"):
+    for extra in ("shard2048", "hostfed", "m160", "m192", "split16", "share8"):         # (round 6: eleven "also" cases)
         d["also"][extra] = json.loads(json.dumps(d["also"]["wide"]))
+    tele = {"sclk": 1834, "fclk": 2000, "mclk": 2000, "power_w": 1398.5}
+    for k_ in ("wide", "stress", "cs16", "f32"):                                         # the >= 20 s cases carry burst5s and telemetry triples
+        d["also"][k_].setdefault("sustain", {}).update(burst5s=3051234.5, telemetry_start_mid_end=[tele, tele, tele])
+        d["also"][k_]["timed_region_s"] = 20.123
+    d["also"]["share8"]["config"]["channels_per_stream"] = 8
+    d["also"]["share8"]["roofline"].update(kernel="fir_u8_mm_kernel<25>", valu_equivalent={"frac": 0.7512}, mfma_i8={"frac": 0.2012})
+    d["also"]["split16"]["config"]["input_format"] = "split16"
+    for a in [v for v in d["also"].values()] + [d]:
+        a["roofline"]["traffic_src"] = "r05"
+    d["roofline_msk"] = {"bound": "issue", "kernel": "msk_demod_kernel", "us_per_bit": 0.7251, "waves_per_simd": 1.0, "cycles_per_bit_per_wave": 1733.0,
+                         "instr_per_bit": 325, "floor_cycles_per_bit": 1300, "frac": 0.75, "note": "n" * 300}
     d["also"]["hostfed"]["hostfed"] = {"h2d_GBs": 55.12, "frac_of_h2d": 0.931, "realtime_10000ch": True, "value_needed_for_realtime": 25000}
     # round 5: BASELINE configs[1] (ms per callback, legacy view / batched API / CPU reference) and the gate's -Ofast leg per case
     ch = {"channels": 16, "legacy_first_call_ms": 412.345, "legacy_ms_per_callback": 0.9123, "batched_ms_per_callback": 0.4123,
@@ -431,11 +442,14 @@ def test_bench_compact_line_stays_under_4k_at_the_full_case_shape():
               "data", "config", "roofline", "cpu_baseline", "parity", "also"):
         assert k in c, k
     assert c["config"]["workload"] and c["config"]["channels_per_gpu"] == 1024 and c["config"]["callbacks_per_call"] == 8
-    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "bytes_per_launch", "avg_launch_ms", "launches_per_step"):
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_src", "bytes_per_launch", "avg_launch_ms", "launches_per_step"):
         assert k in c["roofline"], k
     assert c["cpu_baseline"]["kind"] == "reference" and c["cpu_baseline"]["cores"] == 1 and c["cpu_baseline"]["all_cores"]["processes"] == 64
     assert c["parity"]["exact_given_gpu_dm"] is True and c["parity"]["msgs_exact"] is True and c["parity"]["ref_builds_differing"] == 1
-    assert set(c["also"]) == {"wide", "stress", "cs16", "f32", "shard2048", "hostfed", "rtl8"}
+    assert set(c["also"]) == {"wide", "stress", "cs16", "f32", "shard2048", "hostfed", "rtl8", "m160", "m192", "split16", "share8"}
+    assert c["roofline_msk"]["bound"] == "issue" and c["roofline_msk"]["instr_per_bit"] == 325
+    assert c["also"]["wide"]["b5"] == 3051234 and c["also"]["wide"]["s"] == 20.1 and c["also"]["share8"]["valu_equiv_frac"] == 0.7512
+    assert c["roofline"]["traffic_src"] == "r05"
     assert all(a["parity_ok"] is True and 0 < a["roofline_frac"] < 1 and a["gpu_vs_ref_ofast"] == 0 for k_, a in c["also"].items() if k_ != "rtl8")
     r8 = c["also"]["rtl8"]
     assert r8["budget_ms"] == 81.92 and r8["ch8"]["parity_ok"] is True and r8["ch16"]["legacy_ms"] == 0.9123 and r8["ch16"]["cpu_ref_ms"] == 12.3456

@@ -136,3 +136,55 @@ def test_collectives_run_with_a_world_of_one():
     assert p.exitcode == 0
     assert mine == np.arange(24, dtype=np.float64).reshape(6, 4).tolist() and (t, c, per) == (0.75, 3.0, [0.75])
     assert merged == [(10, 5, b"s", 4), (20, 7, b"t", 11)]
+
+
+def _bench_dry(args, extra_env=None, timeout=300):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=timeout)
+
+
+def test_bench_eight_ranks_rehearsal_without_gpus():
+    """the launcher's 8-rank path had never run with 8 processes.  `bench.py --gpus 8 --dry-run` is the
+    real thing minus the device: bench.py launches 8 ranks itself (torch.distributed.run, rendezvous on 127.0.0.1), every rank gets
+    its rows of the channel table (shard.scatter_channel_config over gloo), the REAL timed region runs (benchlib.timing.timed_region:
+    barriers, the passes-per-step agreement, max-over-ranks clock, the gather of every rank's time) around a stub that sleeps
+    -- rank r 5 % x r longer than rank 0 -- and rank 0 prints the REAL compact line.  Checked: 8 per_gpu entries in rank order and
+    falling with the rank's sleep, value = all ranks' work / the slowest rank's time, every rank on the same passes per step, the
+    "also" case (BASELINE configs[3]'s per-GPU share) with its own 8 entries, one line under 4 KB that says it measured nothing."""
+    import json
+    r = _bench_dry(["--gpus", "8", "--dry-run", "--steps", "4", "--warmup", "1", "--sustain", "0.4"])
+    assert r.returncode == 0, r.stderr[-1500:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    line = json.loads(lines[-1])
+    detail = json.loads([l for l in lines if l.startswith("# bench_detail: ")][0][len("# bench_detail: "):])
+    assert len(lines[-1]) < 4096 and line["dry_run"] is True and line["n_gpus"] == 8 and line["scaling"] == "weak"
+    for rec, nch in ((detail, 1024), (detail["also"]["shard2048"], 2048)):
+        pg, cfgd = rec["per_gpu"], rec["config"]
+        assert len(pg) == 8 and cfgd["channels_total"] == 8 * nch and len(cfgd["per_rank_seconds"]) == 8
+        secs = cfgd["per_rank_seconds"]
+        # rank r sleeps 1 + 0.05 r times what rank 0 sleeps: the slowest is the last, and per_gpu says so
+        assert secs.index(max(secs)) == 7 and pg.index(min(pg)) == 7 and pg[0] > pg[7]
+        assert 1.25 < secs[7] / secs[0] < 1.45
+        # value = the work of all ranks / the slowest rank's time (timed_region_s is that maximum)
+        work = 8 * cfgd["channels_per_gpu"] * cfgd["blocks_per_step"] * 1024 * cfgd["decim"] * 4
+        assert abs(rec["value"] - work / rec["timed_region_s"] / 1e6) < 2e-3 * rec["value"]
+        assert 0 <= rec["timed_region_s"] - max(secs) < 0.05          # (the job's clock stops behind the barrier, the slowest rank's own just before it)
+        # every rank ran the same number of passes: each rank's own rate x its own time is the same work
+        assert all(abs(p * t - pg[0] * secs[0]) < 2e-3 * pg[0] * secs[0] for p, t in zip(pg, secs))
+        assert cfgd["blocks_per_step"] == cfgd["blocks_per_pass"] * cfgd["passes_per_step"] and cfgd["passes_per_step"] >= 1
+    assert line["per_gpu"] == detail["per_gpu"] or [int(round(x)) for x in detail["per_gpu"]] == line["per_gpu"]
+    assert len(line["also"]["shard2048"]["per_gpu"]) == 8
+
+
+def test_bench_rank_that_dies_takes_the_launch_down():
+    """... and a rank that dies in the middle of the timed region (os._exit inside its third pass) must not leave seven ranks
+    waiting at a barrier: the launcher exits non-zero, quickly, and prints no result line."""
+    import time
+    t0 = time.time()
+    r = _bench_dry(["--gpus", "8", "--dry-run", "--steps", "4", "--warmup", "1", "--sustain", "0.4"], {"ACG_BENCH_DRY_DIE_RANK": "5"}, timeout=240)
+    assert r.returncode != 0 and time.time() - t0 < 200
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
