@@ -77,6 +77,7 @@ def build_lib(force=False, stamp=False, poly=False, lab=False):
     out_lib = LIB_STAMP if stamp else LIB_POLY if poly else LIB_LAB if lab else LIB
     hdrs = [os.path.join(CSRC, "acg_internal.h"), os.path.join(CSRC, "msk_common.h"), os.path.join(INC, "acarsdec_amd.h"),
             os.path.join(INC, "acarsdec_amd_lab.h"), os.path.abspath(__file__)]   # flags live here
+    hdrs += sorted(os.path.join(CSRC, "lab", f) for f in os.listdir(os.path.join(CSRC, "lab")))       # the lab-only kernel families fir.hip includes
     objs = []
     hc = hipcc()
     for name, flags, in_product in UNITS:

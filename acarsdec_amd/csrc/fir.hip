@@ -68,121 +68,7 @@ __device__ __forceinline__ float cabs_like_glibc(float re, float im)
 }
 
 #ifdef ACG_LAB   // round 1's first kernel (ACG_FIR_VARIANT=0): lab build only (libacarsdec_amd_lab.so)
-__global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_tile_kernel(const FirArgs a,
-                                                                  const uint8_t* __restrict__ iq_base,
-                                                                  const float* __restrict__ taps_base,
-                                                                  const int* __restrict__ stream_of,
-                                                                  float* __restrict__ dm_base)
-{
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ch = blockIdx.x / a.nseg;
-    const int seg = blockIdx.x - ch * a.nseg;
-    const int ntile = (a.nwin + ACG_TILE_WIN - 1) / ACG_TILE_WIN;
-    const int t0 = (int)((long long)ntile * seg / a.nseg);
-    const int t1 = (int)((long long)ntile * (seg + 1) / a.nseg);
-    if (t0 >= t1) return;
-
-    const uint8_t* __restrict__ src = iq_base + (size_t)stream_of[ch] * a.pitch;
-    const float* __restrict__ taps = taps_base + (size_t)ch * a.ntaps_pad * 2;
-    float* __restrict__ dm = dm_base + (size_t)ch * a.dm_pitch;
-
-    const int cpr = a.cpr;
-    const int tile_chunks = ACG_TILE_WIN * cpr;
-    const int total_chunks = a.nwin * cpr;              // valid 16-byte chunks of this stream row
-    const int pad = a.row_stride - a.row_bytes;
-    const unsigned int magic = a.cpr_magic;
-    unsigned char* tileL = fir_smem;
-    float4* red = (float4*)(fir_smem + ACG_TILE_WIN * a.row_stride);
-
-    const int nck = a.ntaps_pad >> 3;                   // chunks that carry taps
-    const int c0 = nck * wave / 4;
-    const int c1 = nck * (wave + 1) / 4;
-    const int nld = (tile_chunks + ACG_WG_FIR - 1) / ACG_WG_FIR;
-
-    uint4 stage[FIR_MAXLD];
-
-    // ---- prologue: fetch the first tile
-    {
-        const int base = t0 * tile_chunks;
-#pragma unroll
-        for (int i = 0; i < FIR_MAXLD; ++i) {
-            if (i < nld) {
-                const int c = tid + i * ACG_WG_FIR;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (c < tile_chunks && base + c < total_chunks)
-                    v = *(const uint4*)(src + ((size_t)(base + c) << 4));
-                stage[i] = v;
-            }
-        }
-    }
-
-    for (int t = t0; t < t1; ++t) {
-        // ---- registers -> LDS (padded rows)
-#pragma unroll
-        for (int i = 0; i < FIR_MAXLD; ++i) {
-            if (i < nld) {
-                const int c = tid + i * ACG_WG_FIR;
-                if (c < tile_chunks) {
-                    const int r = (int)(((unsigned int)c * magic) >> 20);
-                    *(uint4*)(tileL + (c << 4) + r * pad) = stage[i];
-                }
-            }
-        }
-        __syncthreads();
-
-        // ---- issue the next tile's loads; they stay in flight during the compute below
-        if (t + 1 < t1) {
-            const int base = (t + 1) * tile_chunks;
-#pragma unroll
-            for (int i = 0; i < FIR_MAXLD; ++i) {
-                if (i < nld) {
-                    const int c = tid + i * ACG_WG_FIR;
-                    uint4 v = make_uint4(0, 0, 0, 0);
-                    if (c < tile_chunks && base + c < total_chunks)
-                        v = *(const uint4*)(src + ((size_t)(base + c) << 4));
-                    stage[i] = v;
-                }
-            }
-        }
-
-        // ---- this wave's share of the taps, lane = window
-        f2 accA = {0.f, 0.f};       // (sum tr*wr, sum ti*wi)
-        f2 accB = {0.f, 0.f};       // (sum tr*wi, sum ti*wr)
-        const unsigned char* rowp = tileL + lane * a.row_stride;
-        for (int c = c0; c < c1; ++c) {
-            const uint4 q = *(const uint4*)(rowp + (c << 4));
-            const float* __restrict__ w = taps + (c << 4);       // wave-uniform -> scalar loads
-            const unsigned int qq[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const unsigned int word = qq[j >> 1];
-                const unsigned int sh = (j & 1) * 16;
-                f2 t;
-                t.x = (float)((word >> sh) & 0xffu) - 127.37f;          // rtl.c:338 (exact in f32)
-                t.y = (float)((word >> (sh + 8)) & 0xffu) - 127.37f;    // rtl.c:339
-                const f2 wv = {w[2 * j], w[2 * j + 1]};
-                const f2 ws = {w[2 * j + 1], w[2 * j]};
-                accA = __builtin_elementwise_fma(t, wv, accA);
-                accB = __builtin_elementwise_fma(t, ws, accB);
-            }
-        }
-        red[wave * 64 + lane] = make_float4(accA.x, accA.y, accB.x, accB.y);
-        __syncthreads();
-
-        if (wave == 0) {
-            const float4 r0 = red[lane], r1 = red[64 + lane], r2 = red[128 + lane], r3 = red[192 + lane];
-            const float Dr = ((r0.x + r1.x) + (r2.x + r3.x)) - ((r0.y + r1.y) + (r2.y + r3.y));
-            const float Di = ((r0.z + r1.z) + (r2.z + r3.z)) + ((r0.w + r1.w) + (r2.w + r3.w));
-            const int m = t * ACG_TILE_WIN + lane;
-            if (m < a.nwin) dm[m] = cabs_like_glibc(Dr, Di);             // rtl.c:353
-        }
-        // the barrier at the top of the next iteration orders wave 0's reads of `red`
-        // before anyone rewrites it.
-    }
-}
-
+#include "lab/fir_tile.inc"
 #endif  // ACG_LAB
 
 // Persistent variant: the grid is exactly the number of workgroups the chip holds at once and the
@@ -531,125 +417,7 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_shared_kernel(const FirArgs
 }
 
 #ifdef ACG_LAB   // LDS-DMA variant (ACG_FIR_VARIANT=4): lab build only
-// LDS-DMA variant (rows that are an odd number of 16-byte slots, e.g. M = 200: no padding needed, so the
-// LDS image of a tile is the linear image of its bytes in HBM).  `global_load_lds_dwordx4 ... nt` moves
-// 1 KiB per wave-instruction straight into LDS: no staging VGPRs, no ds_write pass, one barrier per
-// tile.  Two tile buffers: the DMA of tile t+1 lands while tile t is computed.  Same run dispenser as
-// the register-staged kernel.  LDS: 2 tiles + 2 reduction buffers -> 2 workgroups per CU.
-__global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_dma_kernel(const FirArgs a,
-                                                                 const uint8_t* __restrict__ iq_base,
-                                                                 const float* __restrict__ taps_base,
-                                                                 const int* __restrict__ stream_of,
-                                                                 float* __restrict__ dm_base)
-{
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ntile = (a.nwin + ACG_TILE_WIN - 1) / ACG_TILE_WIN;
-    const long long G = (long long)a.nch * ntile;
-    const long long nrun = (G + FIR_RUN - 1) / FIR_RUN;
-    long long g0 = (long long)blockIdx.x * FIR_RUN;
-    long long g1 = g0 + FIR_RUN < G ? g0 + FIR_RUN : G;
-    if (g0 >= g1) return;
-
-    const int cpr = a.cpr;                               // odd
-    const int tile_bytes = ACG_TILE_WIN * a.row_bytes;   // = cpr KiB
-    const int total_chunks = a.nwin * cpr;
-    unsigned char* buf0 = fir_smem;
-    float4* red = (float4*)(fir_smem + 2 * tile_bytes);  // [2][4][64]
-    int* s_next = (int*)(fir_smem + 2 * tile_bytes + 2 * 4 * 64 * sizeof(float4));
-    const int nck = a.ntaps_pad >> 3;
-    const int c0 = nck * wave / 4;
-    const int c1 = nck * (wave + 1) / 4;
-
-    int ch = (int)(g0 / ntile);
-    int t = (int)(g0 - (long long)ch * ntile);
-
-    auto issue = [&](int fch, int ft, int b) {
-        const uint8_t* __restrict__ src = iq_base + (size_t)stream_of[fch] * a.pitch;
-        const int base = ft * ACG_TILE_WIN * cpr;
-        unsigned char* dst = buf0 + b * tile_bytes;
-        for (int q = wave; q < cpr; q += 4) {            // wave-uniform: 1 KiB per instruction
-            int c = base + q * 64 + lane;
-            if (c >= total_chunks) c = total_chunks - 1;  // partial last tile: rows nobody stores
-            // inline asm: as a builtin the compiler orders every later ds_read behind it with vmcnt(0)
-            const unsigned char* gp = src + ((size_t)c << 4);
-            const unsigned int ldst = __builtin_amdgcn_readfirstlane((unsigned int)(uintptr_t)(dst + q * 1024));
-            unsigned int keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(gp), "s"(ldst) : "memory");
-        }
-    };
-
-    issue(ch, t, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int cur = 0;
-    unsigned int pending_next = 0;
-    for (long long g = g0;;) {
-        if (g == g0 && tid == 0) request_ticket(a.work_counter, pending_next);
-        int nch_ = ch, nt_ = t + 1;
-        if (nt_ == ntile) { nt_ = 0; ++nch_; }
-        bool more = g + 1 < g1;
-        long long ng0 = g0, ng1 = g1, ng = g + 1;
-        if (!more) {
-            const long long nr = (g1 - g0 >= 2) ? (long long)*s_next : nrun;
-            if (nr < nrun) {
-                ng0 = nr * FIR_RUN;
-                ng1 = ng0 + FIR_RUN < G ? ng0 + FIR_RUN : G;
-                ng = ng0;
-                nch_ = (int)((unsigned int)ng0 / (unsigned int)ntile);      // G < 2^31 (launcher)
-                nt_ = (int)((unsigned int)ng0 - (unsigned int)nch_ * (unsigned int)ntile);
-                more = true;
-            }
-        }
-        if (more) issue(nch_, nt_, cur ^ 1);
-
-        const float* __restrict__ taps = taps_base + (size_t)ch * a.ntaps_pad * 2;
-        f2 accA = {0.f, 0.f};
-        f2 accB = {0.f, 0.f};
-        const unsigned char* rowp = buf0 + cur * tile_bytes + lane * a.row_bytes;
-        for (int c = c0; c < c1; ++c) {
-            const uint4 q = *(const uint4*)(rowp + (c << 4));
-            const float* __restrict__ w = taps + (c << 4);
-            const unsigned int qq[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const unsigned int word = qq[j >> 1];
-                const unsigned int sh = (j & 1) * 16;
-                f2 tt;
-                tt.x = (float)((word >> sh) & 0xffu) - 127.37f;
-                tt.y = (float)((word >> (sh + 8)) & 0xffu) - 127.37f;
-                const f2 wv = {w[2 * j], w[2 * j + 1]};
-                const f2 ws = {w[2 * j + 1], w[2 * j]};
-                accA = __builtin_elementwise_fma(tt, wv, accA);
-                accB = __builtin_elementwise_fma(tt, ws, accB);
-            }
-        }
-        float4* rd = red + cur * 256;
-        rd[wave * 64 + lane] = make_float4(accA.x, accA.y, accB.x, accB.y);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of the next tile has landed
-        if (g == g0 && tid == 0) *s_next = (int)(gridDim.x + take_ticket(pending_next));     // published by the barrier below
-        __syncthreads();
-
-        if (wave == 0) {
-            const float4 r0 = rd[lane], r1 = rd[64 + lane], r2 = rd[128 + lane], r3 = rd[192 + lane];
-            const float Dr = ((r0.x + r1.x) + (r2.x + r3.x)) - ((r0.y + r1.y) + (r2.y + r3.y));
-            const float Di = ((r0.z + r1.z) + (r2.z + r3.z)) + ((r0.w + r1.w) + (r2.w + r3.w));
-            const int m = t * ACG_TILE_WIN + lane;
-            if (m < a.nwin) dm_base[(size_t)ch * a.dm_pitch + m] = cabs_like_glibc(Dr, Di);
-        }
-        if (!more) break;
-        ch = nch_;
-        t = nt_;
-        g = ng;
-        g0 = ng0;
-        g1 = ng1;
-        cur ^= 1;
-    }
-    if (tid == 0) dispenser_sign_off(a.work_counter, pending_next);
-}
-
+#include "lab/fir_dma.inc"
 #endif  // ACG_LAB
 
 // ---------------------------------------------------------------------------------------------------
@@ -982,500 +750,7 @@ __global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_direct_kernel(const FirArgs
 }
 
 #ifdef ACG_LAB   // register-tap and matrix-pipe variants (ACG_FIR_VARIANT=7 / 8 / 6, 70..73): lab build only
-// ---------------------------------------------------------------------------------------------------
-// fir_u8_coltap_kernel (ACG_FIR_VARIANT=7, 2.5 Msps only): the wave-private streaming kernel above with the taps in
-// REGISTERS.  What the kernel above pays per 16 input bytes besides its arithmetic is 64 bytes of tap reads from LDS
-// (four ds_read_b128 per step: with 1 KiB wave-loads the column of a lane, (64 q + L) mod 25, changes with every load,
-// so the lane needs all 25 columns over a tile).  Here the wave-loads are cut where the columns repeat: 125 chunks =
-// 5 windows = 2000 bytes are read as load A (chunks 125 g .. 125 g + 63) and load B (chunks 125 g + 64 .. 125 g + 127,
-// the last three of which belong to the next group), so lane L multiplies column L mod 25 in every A load and column
-// (L + 14) mod 25 in every B load: two tap sets of 8 complex taps = 32 VGPRs per lane, loaded once per run, and no tap
-// table in LDS at all (LDS traffic per 16 input bytes: 80 -> 16 bytes; 13 KiB instead of 18 KiB per wave, so twelve
-// waves fit a CU).  A tile is still 64 windows = 1600 chunks = 25 KiB contiguous: 12 groups + 100 chunks = 26
-// wave-loads (4 % of the lanes idle); the loads start 16-byte aligned instead of 1 KiB aligned (a wave-load touches 9
-// cache lines instead of 8; the two partial lines are shared with the neighbouring load of the same wave).
-// Lanes past the group (61..63 of a B load, 36..63 of the tile's last load) multiply bytes of the next group with
-// whatever taps they hold and write the result where the next group's A load overwrites it (LDS operations of a wave
-// execute in order) or into 28 pad entries behind the tile's partial sums: no predicate, no zero taps.
-// Everything else -- partial sums through LDS, lane = window reduction, |D|, dispenser, runs, the 127.37 fold -- is
-// the kernel above.
-template <int U_ = 13, int B_ = 1>
-struct FirC {
-    static constexpr int CPR = 25;
-    static constexpr int SPT = 26;                                 // wave-loads (steps) per tile
-    static constexpr int U = U_;                                   // staging slots per lane; divides the 52 loads of a body
-    static constexpr int B = B_;                                   // loads per burst: U - B .. U KiB per wave in flight
-    static constexpr int P_ENT = 64 * CPR + 28;                    // partial sums of a tile + the idle lanes of its last load
-    static constexpr int P_BYTES = (P_ENT * 8 + 15) & ~15;
-    static constexpr int CAP = 16;                                 // tiles of results a wave can hold back (staged variant)
-    static constexpr int STAGE_BYTES = CAP * 256 + CAP * 8;        // 64 floats per tile + where they go
-    static constexpr int WAVE_LDS = P_BYTES;
-    static constexpr int WAVE_LDS_STAGED = P_BYTES + STAGE_BYTES;
-    static_assert((FIRD_R * SPT) % U == 0 && (FIRD_R * SPT) % B == 0 && B <= U, "slots and bursts must divide the loads per body");
-    // first chunk of step q of a tile, byte offset of load position pos of a body
-    static constexpr int chunk0(int q) { return (q >> 1) * 125 + (q & 1) * 64; }
-    static constexpr unsigned int offset(int pos) { return (unsigned int)(pos / SPT) * (CPR * 1024u) + (unsigned int)chunk0(pos % SPT) * 16u; }
-};
-
-// Complex multiply-accumulate of one sample (tt = (I, Q)) with one tap (w = (wr, wi)) as two packed fmas on ONE register
-// pair per tap:  P += (I wr, I wi),  Q += (-Q wi, Q wr);  the chunk's sum is P + Q (one v_pk_add_f32, written as it is).
-// P.x, -Q.x, P.y, Q.y are exactly the four sums the kernel above keeps as accA.x, accA.y, accB.x, accB.y (negating a
-// product is exact), so the results are bit-identical to it; the half selection and the sign are instruction modifiers.
-// As inline asm because the taps are loop invariants here: left to the compiler, the swapped pair (wi, wr) is hoisted
-// into a second register copy of both tap sets (32 VGPRs, a wave per SIMD less) instead of an op_sel.
-__device__ __forceinline__ void firc_cmac_first(f2& P, f2& Q, f2 tt, f2 w)
-{
-    asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(P) : "v"(tt), "v"(w));
-    asm("v_pk_fma_f32 %0, %1, %2, 0 op_sel:[1,1,0] op_sel_hi:[1,0,0] neg_lo:[0,1,0]" : "=v"(Q) : "v"(tt), "v"(w));
-}
-__device__ __forceinline__ void firc_cmac(f2& P, f2& Q, f2 tt, f2 w)
-{
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(P) : "v"(tt), "v"(w));
-    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(Q) : "v"(tt), "v"(w));
-}
-
-// STAGED: the 64 results of a tile are parked in LDS (with their destination) instead of being stored; see firc_flush.
-template <int TILE, bool FOLD, int UU, int BB, bool STAGED>
-__device__ __forceinline__ void firc_tile(u4v_t* st /* [U] */, __amdgpu_buffer_rsrc_t cur, __amdgpu_buffer_rsrc_t nxt,
-                                          unsigned int voff, const f2 (&wa)[8], const f2 (&wb)[8], f2* Pw, const f2* Pr,
-                                          float* __restrict__ dm_out, int lane, f2 dc, float* stage, float** stage_dst, int nst)
-{
-    typedef FirC<UU, BB> F;
-#pragma unroll
-    for (int q = 0; q < F::SPT; ++q) {
-        __builtin_amdgcn_sched_barrier(0);
-        const int p = TILE * F::SPT + q;                       // load position of the body consumed by this step
-        const u4v_t d = st[p % F::U];
-        if (p % F::B == 0) {
-#pragma unroll
-            for (int b = 0; b < F::B; ++b) {
-                const int pos = p + F::U - F::B + b;           // the slots of positions p - B .. p - 1 are free
-                if (pos < FIRD_R * F::SPT) st[pos % F::U] = fird_load(cur, voff, F::offset(pos));
-                else st[pos % F::U] = fird_load(nxt, voff, F::offset(pos - FIRD_R * F::SPT));
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const f2 (&w)[8] = (q & 1) ? wb : wa;
-        f2 accP, accQ;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const unsigned int word = d[j >> 1];
-            const unsigned int sh = (j & 1) * 16;
-            f2 tt;
-            tt.x = (float)((word >> sh) & 0xffu);                      // rtl.c:338
-            tt.y = (float)((word >> (sh + 8)) & 0xffu);                // rtl.c:339
-            if (!FOLD) { tt.x -= 127.37f; tt.y -= 127.37f; }
-            if (j == 0) firc_cmac_first(accP, accQ, tt, w[j]);
-            else firc_cmac(accP, accQ, tt, w[j]);
-        }
-        Pw[F::chunk0(q)] = accP + accQ;                                // chunk i = chunk0(q) + lane; rows of 25 (odd: conflict free)
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // lane = window: add the 25 partial sums of the row, |D| (rtl.c:353), 64 consecutive floats
-    f2 D = {0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < F::CPR; ++j) D = D + Pr[j];
-    if (FOLD) D = D - dc;
-    if (STAGED) {
-        stage[nst * 64 + lane] = cabs_like_glibc(D.x, D.y);
-        stage_dst[nst] = dm_out;                                       // (every lane writes the same word: no branch)
-    } else {
-        dm_out[lane] = cabs_like_glibc(D.x, D.y);
-    }
-}
-
-// The write stream.  dm is 1 % of the kernel's traffic, and it costs 5-15 % of its read bandwidth: a pure streaming reader
-// at 7.1 TB/s drops to 6.0-6.7 TB/s when every wave adds 256 bytes of stores per 25.6 KB read, by how much depends on where
-// the output happens to lie relative to the input (profiles/probe/write_beside_read_probe.hip; the down-converter itself:
-// 0.75-0.83 of spec with its dm, 0.84-0.85 with the dm rows folded into one).  What helps is to make the writes of the WHOLE
-// CHIP come in bursts instead of a trickle: every wave parks its results in LDS (up to CAP tiles, each with its
-// destination, so that runs and channels may change in between) and flushes when the chip-wide 100 MHz clock
-// (s_memrealtime) crosses a multiple of 2^13 ticks = 82 us -- all waves see that within one tile -- or when the buffer is
-// full; the stores are write-through (sc0 sc1), 16 bytes per lane, four tiles per instruction.  Between two flushes HBM
-// sees reads only.  The probe: 6.0 -> 6.7 TB/s on a bad placement, 6.7 -> 6.85 on a good one.
-#define FIRC_EPOCH_SHIFT 13
-typedef float f4v_stage_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void firc_flush(const float* stage, float* const* stage_dst, int nst, int lane)
-{
-    for (int q = lane; q < nst * 16; q += 64) {
-        const f4v_stage_t v = *(const f4v_stage_t*)&stage[q * 4];
-        float* p = stage_dst[q >> 4] + (q & 15) * 4;
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
-    }
-}
-
-template <bool FOLD, int UU, int BB, bool STAGED>
-__device__ __forceinline__ void firc_body(const FirArgs& a, const uint8_t* __restrict__ iq_base, const float* __restrict__ taps_base,
-                                          const int* __restrict__ stream_of, float* __restrict__ dm_base)
-{
-    typedef FirC<UU, BB> F;
-    constexpr unsigned int NONE = 0xffffffffu;
-    if (a.high_prio) __builtin_amdgcn_s_setprio(2);
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    unsigned char* my = fir_smem + wave * (STAGED ? F::WAVE_LDS_STAGED : F::WAVE_LDS);
-    f2* P = (f2*)my;
-    float* stage = (float*)(my + F::P_BYTES);                      // STAGED: CAP x 64 results ...
-    float** stage_dst = (float**)(my + F::P_BYTES + F::CAP * 256); // ... and where each tile goes
-    int nst = 0;                                                   // tiles parked
-    unsigned long long epoch = STAGED ? (__builtin_amdgcn_s_memrealtime() >> FIRC_EPOCH_SHIFT) : 0ull;
-    // after a tile: flush when the chip-wide clock entered a new epoch or the buffer is full
-    auto tile_done = [&]() {
-        if (!STAGED) return;
-        ++nst;
-        const unsigned long long e = __builtin_amdgcn_s_memrealtime() >> FIRC_EPOCH_SHIFT;
-        if (e != epoch || nst == F::CAP) {
-            epoch = e;
-            firc_flush(stage, stage_dst, nst, lane);
-            nst = 0;
-        }
-    };
-    f2* Pw = P + lane;                                             // + chunk0(q) entries
-    const f2* Pr = P + lane * F::CPR;
-    const int colA = lane - (lane >= 25 ? 25 : 0) - (lane >= 50 ? 25 : 0);             // lane % 25
-    const int lb = lane + 14;
-    const int colB = lb - (lb >= 25 ? 25 : 0) - (lb >= 50 ? 25 : 0) - (lb >= 75 ? 25 : 0);   // (lane + 14) % 25
-
-    // runs, dispenser, run -> address: as in fird_body (a run is `pairs` consecutive two-tile bodies of one channel)
-    const unsigned int pairs = (unsigned int)a.run_pairs;
-    const unsigned int ntile = (unsigned int)a.nwin / ACG_TILE_WIN;
-    const unsigned int runs_per_ch = ntile / (FIRD_R * pairs);
-    const unsigned int nrun = (unsigned int)a.nch * runs_per_ch;
-    const unsigned int wpg = blockDim.x >> 6;
-    const unsigned int nwaves = gridDim.x * wpg;
-    const unsigned int wg = blockIdx.x * wpg + (unsigned int)wave;
-    unsigned int* ctr = a.work_counter;
-    constexpr unsigned int tile_bytes = (unsigned int)F::CPR * 1024u;
-    constexpr unsigned int run_bytes = FIRD_R * tile_bytes;
-    const unsigned int voff = (unsigned int)lane << 4;
-    const int nck = a.ntaps_pad >> 3;                                               // tap columns that carry taps
-
-    auto shard_runs = [&](unsigned int s) { return (nrun + ACG_DISP_SHARDS - 1 - s) / ACG_DISP_SHARDS; };
-    auto shard_static = [&](unsigned int s) { return (nwaves + ACG_DISP_SHARDS - 1 - s) / ACG_DISP_SHARDS; };
-    auto run_of_ticket = [&](unsigned int s, unsigned int t) -> unsigned int {
-        const unsigned long long k = (unsigned long long)shard_static(s) + t;
-        return k < shard_runs(s) ? (unsigned int)k * ACG_DISP_SHARDS + s : NONE;
-    };
-    auto probe = [&](unsigned int& s) -> unsigned int {
-        for (int k = 0; k < ACG_DISP_SHARDS; ++k) {
-            unsigned int t = 0;
-            if (lane == 0) t = __hip_atomic_fetch_add(ctr + s * ACG_DISP_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
-            const unsigned int r = run_of_ticket(s, t);
-            if (r != NONE) return r;
-            s = (s + 1 == ACG_DISP_SHARDS) ? 0 : s + 1;
-        }
-        return NONE;
-    };
-    auto sign_off = [&]() {
-        if (lane == 0) {
-            const unsigned int d = atomicAdd(ctr + ACG_DISP_SHARDS * ACG_DISP_STRIDE, 1u);
-            if (d == nwaves - 1) {
-#pragma unroll
-                for (int k = 0; k <= ACG_DISP_SHARDS; ++k)
-                    __hip_atomic_store(ctr + k * ACG_DISP_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    };
-    auto run_base = [&](unsigned int run, unsigned int& ch, unsigned int& t0) -> const uint8_t* {
-        ch = run / runs_per_ch;
-        t0 = (run - ch * runs_per_ch) * FIRD_R * pairs;
-        const size_t row = (size_t)(a.stream_identity ? (int)ch : stream_of[ch]) * a.pitch;
-        return iq_base + row + (size_t)t0 * tile_bytes;
-    };
-    // the two tap columns of this lane for channel ch (64 bytes each); not looked at before adopt_taps, so the loads
-    // stay in flight under the last tile of the run
-    const bool onA = colA < nck, onB = colB < nck;                  // columns beyond the last tap: zero
-    auto fetch_taps = [&](unsigned int ch, float4 (&ta)[4], float4 (&tb)[4]) {
-        const float4* src = (const float4*)(taps_base + (size_t)ch * a.ntaps_pad * 2);
-        const float4* sa = src + (onA ? colA : 0) * 4;
-        const float4* sb = src + (onB ? colB : 0) * 4;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { ta[k] = sa[k]; tb[k] = sb[k]; }
-    };
-    f2 wa[8], wb[8];
-    f2 dc = {0.f, 0.f};                                             // 127.37 (1 + j) sum w of the current run's channel
-    auto adopt_taps = [&](const float4 (&ta)[4], const float4 (&tb)[4]) {
-        if (FOLD) {                                                 // lanes 0..24 hold every column once in set A
-            float sr = 0.f, si = 0.f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { sr += ta[k].x + ta[k].z; si += ta[k].y + ta[k].w; }
-            const bool mine = onA && lane < F::CPR;
-            sr = mine ? sr : 0.f;
-            si = mine ? si : 0.f;
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) { sr += __shfl_xor(sr, m, 64); si += __shfl_xor(si, m, 64); }
-            dc.x = 127.37f * (sr - si);
-            dc.y = 127.37f * (sr + si);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            wa[2 * k] = f2{onA ? ta[k].x : 0.f, onA ? ta[k].y : 0.f};
-            wa[2 * k + 1] = f2{onA ? ta[k].z : 0.f, onA ? ta[k].w : 0.f};
-            wb[2 * k] = f2{onB ? tb[k].x : 0.f, onB ? tb[k].y : 0.f};
-            wb[2 * k + 1] = f2{onB ? tb[k].z : 0.f, onB ? tb[k].w : 0.f};
-        }
-    };
-
-    unsigned int s = wg % ACG_DISP_SHARDS;
-    unsigned int run = wg < nrun ? wg : NONE;
-    if (run == NONE) {                                              // tiny launches: fewer runs than waves
-        s = (s + 1 == ACG_DISP_SHARDS) ? 0 : s + 1;
-        run = probe(s);
-    }
-    if (run == NONE) { sign_off(); return; }
-
-    unsigned int ch, t0;
-    const uint8_t* base = run_base(run, ch, t0);
-    {
-        float4 ta[4], tb[4];
-        fetch_taps(ch, ta, tb);
-        adopt_taps(ta, tb);
-    }
-    __amdgpu_buffer_rsrc_t cur = fird_rsrc(base, run_bytes);
-    u4v_t st[F::U];
-#pragma unroll
-    for (int i = 0; i < F::U - F::B; ++i) {                         // step 0 issues the burst U - B .. U - 1 itself
-        st[i] = fird_load(cur, voff, F::offset(i));
-        __builtin_amdgcn_sched_barrier(0);                          // keep the loads in issue order (the waits count on it)
-    }
-
-    for (;;) {
-        unsigned int tk;
-        if (lane == 0) ticket_request(ctr + s * ACG_DISP_STRIDE, tk);
-        float* __restrict__ dm_out = dm_base + (size_t)ch * a.dm_pitch + (size_t)t0 * ACG_TILE_WIN;
-        static_assert(FIRD_R == 2, "a body is unrolled by hand: first tile, second tile");
-        bool has_next = true;
-        unsigned int nrun_ = NONE, nch_ = ch, nt0 = t0;
-        float4 ta[4], tb[4];
-        for (unsigned int j = 0; j < pairs; ++j) {
-            firc_tile<0, FOLD, UU, BB, STAGED>(st, cur, cur, voff, wa, wb, Pw, Pr, dm_out, lane, dc, stage, stage_dst, nst);
-            tile_done();
-            const uint8_t* nbase = base + run_bytes;                // the next body of this run ...
-            if (j + 1 == pairs) {                                   // ... or the first body of the next run
-                // (U loads and a store are in flight, all younger than the ticket)
-                nrun_ = run_of_ticket(s, ticket_take<F::U + 1>(tk));
-                if (nrun_ == NONE) {
-                    s = (s + 1 == ACG_DISP_SHARDS) ? 0 : s + 1;
-                    nrun_ = probe(s);
-                }
-                has_next = nrun_ != NONE;
-                nbase = base;
-                if (has_next) nbase = run_base(nrun_, nch_, nt0);
-                fetch_taps(nch_, ta, tb);
-            }
-            const __amdgpu_buffer_rsrc_t nxt = fird_rsrc(nbase, has_next ? run_bytes : 0u);
-            firc_tile<1, FOLD, UU, BB, STAGED>(st, cur, nxt, voff, wa, wb, Pw, Pr, dm_out + ACG_TILE_WIN, lane, dc, stage, stage_dst, nst);
-            tile_done();
-            dm_out += FIRD_R * ACG_TILE_WIN;
-            base = nbase;
-            cur = nxt;
-        }
-        if (!has_next) break;
-        adopt_taps(ta, tb);
-        run = nrun_;
-        ch = nch_;
-        t0 = nt0;
-    }
-    if (STAGED && nst) firc_flush(stage, stage_dst, nst, lane);
-    sign_off();
-}
-
-template <bool FOLD = true, int UU = 13, int BB = 1, bool STAGED = false>
-__global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_coltap_kernel(const FirArgs a,
-                                                                    const uint8_t* __restrict__ iq_base,
-                                                                    const float* __restrict__ taps_base,
-                                                                    const int* __restrict__ stream_of,
-                                                                    float* __restrict__ dm_base)
-{
-    firc_body<FOLD, UU, BB, STAGED>(a, iq_base, taps_base, stream_of, dm_base);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// fir_u8_mfma_kernel<CPR>: the same sums through the matrix pipe -- not for its flop rate (the kernel moves 8 flop
-// per 2 bytes) but for what the arithmetic costs beside a saturated memory path: the wave-private kernel above spends
-// 16 v_cvt + 16 v_pk_fma_f32 per 16 input bytes and sustained runs sit at the package power limit.
-// Here a tile (32 windows x 2M bytes) is parked in LDS as it lies in HBM, lane = window reads its row back 16 bytes
-// at a time (conflict free: 16 lanes x 4 banks at a stride of 25 * 4 dwords), two v_perm_b32 + two v_pk_add_f16 turn 4
-// bytes into (b - 127) as four exact f16, and ONE v_mfma_f32_4x4x4_16b_f16 (16 blocks of 4 x 4 x 4) multiplies the 4
-// bytes of all 64 windows with four columns of the channel's tap table: re and im, each split hi + lo in f16 (22 bits
-// of the f32 tap, scaled by a power of two into f16's range), f32 accumulation.  Per 4 bytes per lane: 1 MFMA + 4 VALU
-// instead of 4 v_cvt + 4 v_pk_fma.  The remaining 0.37 of the 127.37 is the per-channel constant of the fold above.
-//   block b = lane / 4, row i = lane % 4: A[b][i][0..3] = the 4 bytes of window `lane`;
-//   column j = lane % 4: B[.][0..3][j] = (wr, -wi, wr', -wi') hi | (wi, wr, wi', wr') hi | the same lo   (j = 0..3);
-//   D[b][i][j] lands in lane 4 b + j, register i  (profiles/probe/mfma_layout_probe.hip).
-// The next tile's wave-loads wait in registers while this tile is multiplied, then go to LDS.
-// Tile = 32 windows (CPR / 2 KiB, ceil(CPR / 2) wave-loads): lanes 0..31 multiply columns 0 .. NG - 1 of their window,
-// lanes 32..63 columns NG .. 2 NG - 1 of the same windows (a column past the window meets a zero table entry), so all 16
-// blocks of every MFMA work and a wave's LDS stays at ~17 KiB (9 waves per CU keep ~115 KiB per CU in flight).
-template <int CPR>
-struct FirM {
-    static constexpr int WIN = 32;                                 // windows per tile
-    static constexpr int NG = (CPR + 1) / 2;                       // 16-byte column groups per half
-    static constexpr int NLD = (WIN * CPR + 63) / 64;              // wave-loads per tile (the last one may run into the next tile)
-    static constexpr int TILE_BYTES = WIN * CPR * 16;
-    static constexpr int TILE_LDS = NLD * 1024;
-    static constexpr int TAB_BYTES = 2 * NG * 128;                 // [2 NG groups][4 columns][4 steps][4 f16]
-    static constexpr int OUT_BYTES = 2 * WIN * 16;
-    static constexpr int WAVE_LDS = TILE_LDS + TAB_BYTES + OUT_BYTES;
-};
-
-typedef _Float16 h4v_t __attribute__((ext_vector_type(4)));
-typedef _Float16 h2v_t __attribute__((ext_vector_type(2)));
-typedef float f4v_t __attribute__((ext_vector_type(4)));
-
-// bytes (b0, b1) / (b2, b3) of a dword -> packed f16 (b - 127, b' - 127): 0x6400 | b is the f16 1024 + b, exactly
-__device__ __forceinline__ h2v_t firm_pair(unsigned int d, unsigned int sel)
-{
-    const unsigned int biased = __builtin_amdgcn_perm(d, 0x64646464u, sel);
-    union { unsigned int u; h2v_t h; } x;
-    x.u = biased;
-    const h2v_t off = {(_Float16)1151.0f, (_Float16)1151.0f};
-    return x.h - off;
-}
-
-template <int CPR>
-__global__ __launch_bounds__(ACG_WG_FIR) void fir_u8_mfma_kernel(const FirArgs a, const uint8_t* __restrict__ iq_base,
-                                                                  const float* __restrict__ taps_base,
-                                                                  const int* __restrict__ stream_of, float* __restrict__ dm_base)
-{
-    typedef FirM<CPR> F;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    unsigned char* my = fir_smem + wave * F::WAVE_LDS;
-    u4v_t* tileL = (u4v_t*)my;                                    // [32 windows][CPR chunks], as in HBM
-    u4v_t* tabL = (u4v_t*)(my + F::TILE_LDS);                     // [2 NG][4][2] x 16 bytes
-    _Float16* tabH = (_Float16*)(my + F::TILE_LDS);
-    float* outL = (float*)(my + F::TILE_LDS + F::TAB_BYTES);      // [2 halves][32 windows][4 columns]
-    const unsigned int wpg = blockDim.x >> 6;
-    const unsigned int nwaves = gridDim.x * wpg;
-    const unsigned int wg = blockIdx.x * wpg + (unsigned int)wave;
-    const unsigned int ntile = (unsigned int)a.nwin / F::WIN;                       // 32-window tiles (nwin is a multiple of 128: launcher)
-    const unsigned int tiles_per_run = (unsigned int)a.run_pairs * FIRD_R * (ACG_TILE_WIN / F::WIN);
-    const unsigned int runs_per_ch = ntile / tiles_per_run;
-    const unsigned int nrun = (unsigned int)a.nch * runs_per_ch;
-    const unsigned int voff = (unsigned int)lane << 4;
-    const int j = lane & 3;
-    const int half = lane >> 5;
-    const u4v_t* rowL = tileL + (lane & 31) * CPR + half * F::NG;                   // this lane's window, this half's first column
-    const u4v_t* tabR = tabL + (half * F::NG * 4 + j) * 2;
-
-    // two tiles wait in registers: while tile t is multiplied, t + 1 has landed or is landing and t + 2 is being asked for,
-    // so the wave always has a tile's worth of loads in the memory system
-    u4v_t stA[F::NLD], stB[F::NLD];
-    auto tile_step = [&](u4v_t (&st)[F::NLD], unsigned int t, unsigned int tiles_per_run_, __amdgpu_buffer_rsrc_t rs, float* __restrict__ dm_out,
-                         float inv_scale, f2 dc) {
-        // ---- this tile: registers -> LDS (as it lies in memory), then ask for the tile after the next one
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int p = 0; p < F::NLD; ++p) tileL[p * 64 + lane] = st[p];
-#pragma unroll
-        for (int p = 0; p < F::NLD; ++p)                            // beyond the run: the descriptor returns zeros without touching memory
-            st[p] = fird_load(rs, voff, (t + 2) * (unsigned int)F::TILE_BYTES + (unsigned int)p * 1024u);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // ---- 4 * NG matrix steps
-        f4v_t acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int g = 0; g < F::NG; ++g) {
-            const u4v_t d = rowL[g];
-            const u4v_t b01 = tabR[g * 8 + 0];                                  // steps 0, 1 of the group: 2 x 4 f16
-            const u4v_t b23 = tabR[g * 8 + 1];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                union { h2v_t h[2]; h4v_t v; } A;
-                A.h[0] = firm_pair(d[r], 0x00050004u);                          // bytes 3..0 of the result: 0x64, b1, 0x64, b0
-                A.h[1] = firm_pair(d[r], 0x00070006u);                          //                           0x64, b3, 0x64, b2
-                union { unsigned int u[2]; h4v_t v; } B;
-                const u4v_t& bb = (r < 2) ? b01 : b23;
-                B.u[0] = bb[(r & 1) * 2 + 0];
-                B.u[1] = bb[(r & 1) * 2 + 1];
-                if (r & 1) acc1 = __builtin_amdgcn_mfma_f32_4x4x4f16(A.v, B.v, acc1, 0, 0, 0);
-                else acc0 = __builtin_amdgcn_mfma_f32_4x4x4f16(A.v, B.v, acc0, 0, 0, 0);
-            }
-        }
-        const f4v_t acc = acc0 + acc1;
-        // ---- D[b][i][j] sits in lane 4 b + j, register i: through LDS to lane = window, the two halves added there
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) outL[((lane & ~3) + i) * 4 + j] = acc[i];   // lanes 32..63 land in rows 32..63 = the second half
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (lane < F::WIN) {
-            const f4v_t o = *(const f4v_t*)(outL + lane * 4) + *(const f4v_t*)(outL + (F::WIN + lane) * 4);
-            const float re = (o[0] + o[2]) * inv_scale - dc.x;
-            const float im = (o[1] + o[3]) * inv_scale - dc.y;
-            dm_out[t * F::WIN + lane] = cabs_like_glibc(re, im);
-        }
-        (void)tiles_per_run_;
-    };
-
-    for (unsigned int run = wg; run < nrun; run += nwaves) {       // static interleave (measurement build of the idea)
-        const unsigned int ch = run / runs_per_ch;
-        const unsigned int t0 = (run - ch * runs_per_ch) * tiles_per_run;
-        const size_t row = (size_t)(a.stream_identity ? (int)ch : stream_of[ch]) * a.pitch;
-        const uint8_t* base = iq_base + row + (size_t)t0 * F::TILE_BYTES;
-        float* __restrict__ dm_out = dm_base + (size_t)ch * a.dm_pitch + (size_t)t0 * F::WIN;
-        __amdgpu_buffer_rsrc_t rs = fird_rsrc(base, tiles_per_run * (unsigned int)F::TILE_BYTES);
-#pragma unroll
-        for (int p = 0; p < F::NLD; ++p) stA[p] = fird_load(rs, voff, (unsigned int)p * 1024u);
-#pragma unroll
-        for (int p = 0; p < F::NLD; ++p) stB[p] = fird_load(rs, voff, (unsigned int)F::TILE_BYTES + (unsigned int)p * 1024u);
-
-        // ---- the channel's table: scale, split, sign pattern (the loads above are in flight meanwhile).  Lane takes the taps
-        // n = lane + 64 q: one (wr, wi) load each, then the four 2 x f16 words that tap owns in each of the four columns.
-        const f2* tp = (const f2*)(taps_base + (size_t)ch * a.ntaps_pad * 2);
-        const int ntap = a.ntaps_pad;                                                // complex taps that exist; the rest of the window: 0
-        f2 w[4];
-        float mx = 0.f, sr = 0.f, si = 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int n = lane + 64 * q;
-            const f2 z = {0.f, 0.f};
-            w[q] = n < ntap ? tp[n] : z;
-            mx = fmaxf(mx, fmaxf(fabsf(w[q].x), fabsf(w[q].y)));
-            sr += w[q].x;
-            si += w[q].y;
-        }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            mx = fmaxf(mx, __shfl_xor(mx, m, 64));
-            sr += __shfl_xor(sr, m, 64);
-            si += __shfl_xor(si, m, 64);
-        }
-        const unsigned int ebits = __float_as_uint(mx) & 0x7f800000u;               // 2^E <= max |w| < 2^(E+1)
-        const float inv_scale = ebits ? __uint_as_float(ebits) : 1.0f;              // 2^E
-        const float scale = ebits ? __uint_as_float(0x7f000000u - ebits) : 1.0f;    // 2^-E: scaled taps in (-2, 2)
-        const float crem = 127.37f - 127.0f;                                        // what the f16 bytes do not carry
-        const f2 dc = {crem * (sr - si), crem * (sr + si)};
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int n = lane + 64 * q;                                            // sample n of the window: k-step n / 2, slots 2 (n & 1), + 1
-            if (n < 2 * F::NG * 8) {
-                const int s2 = n >> 1, g = s2 >> 2, r = s2 & 3;
-                const float wr = w[q].x * scale, wi = w[q].y * scale;
-                const _Float16 rh = (_Float16)wr, ih = (_Float16)wi;
-                const _Float16 rl = (_Float16)(wr - (float)rh), il = (_Float16)(wi - (float)ih);
-                h2v_t* dst = (h2v_t*)tabH + (((g * 4) * 4 + r) * 4 + 2 * (n & 1)) / 2;   // column 0; the next columns are 16 f16 = 8 words on
-                const h2v_t c0 = {rh, -ih}, c1 = {ih, rh}, c2 = {rl, -il}, c3 = {il, rl};
-                dst[0] = c0;
-                dst[8] = c1;
-                dst[16] = c2;
-                dst[24] = c3;
-            }
-        }
-
-        for (unsigned int t = 0; t < tiles_per_run; t += 2) {                        // tiles_per_run is even (launcher)
-            tile_step(stA, t, tiles_per_run, rs, dm_out, inv_scale, dc);
-            tile_step(stB, t + 1, tiles_per_run, rs, dm_out, inv_scale, dc);
-        }
-    }
-}
-
+#include "lab/fir_coltap_mfma.inc"
 #endif  // ACG_LAB
 
 // ---------------------------------------------------------------------------------------------------
@@ -2157,67 +1432,7 @@ static int launch_direct(const FirArgs* a, int num_cu, hipStream_t stream)
 }
 
 #ifdef ACG_LAB   // launchers of the lab variants
-// register-resident taps (ACG_FIR_VARIANT=7 / 8, 2.5 Msps): 13 / 17 KiB of LDS per wave
-template <bool FOLD = true, int UU = 13, int BB = 1, bool STAGED = false>
-static int launch_coltap(const FirArgs* a, int num_cu, hipStream_t stream)
-{
-    int wpg = env_int("ACG_FIR_WAVES_PER_WG", a->shares_cus ? 1 : 4);
-    if (wpg != 1 && wpg != 2 && wpg != 4) wpg = 4;
-    const size_t lds = (size_t)wpg * (STAGED ? FirC<UU, BB>::WAVE_LDS_STAGED : FirC<UU, BB>::WAVE_LDS);
-    int per_cu = (int)((160 * 1024) / lds);
-    // (twelve waves per CU fit and measure 1-6 % slower than eight, alone and beside the demodulator: profiles/r02_experiments)
-    if (per_cu > 8 / wpg) per_cu = 8 / wpg;
-    if (a->shares_cus && wpg == 1 && per_cu > 7) per_cu = 7;        // leave the demodulator's workgroups their LDS (28 KiB per CU)
-    per_cu = env_int("ACG_FIR_WG_PER_CU", per_cu);
-    long long grid = (long long)(a->ncu > 0 ? a->ncu : num_cu) * per_cu;
-    const long long bodies_per_ch = a->nwin / ACG_TILE_WIN / FIRD_R;
-    const long long bodies = (long long)a->nch * bodies_per_ch;
-    int pairs = 1;
-    while (pairs < 8 && bodies_per_ch % (2 * pairs) == 0 && bodies / (2 * pairs) >= 32 * grid * wpg) pairs *= 2;
-    pairs = env_int("ACG_FIR_RUN_PAIRS", pairs);
-    if (pairs < 1 || pairs > 8 || (pairs & (pairs - 1)) || bodies_per_ch % pairs) pairs = 1;
-    const long long nrun = bodies / pairs;
-    const long long need = (nrun + wpg - 1) / wpg;
-    if (grid > need) grid = need;
-    FirArgs b = *a;
-    b.run_pairs = pairs;
-    if (acg_tune_has("ACG_FIR_DEBUG_SHAPE"))
-        fprintf(stderr, "fir_u8_coltap: nch %d nwin %d  wpg %d per_cu %d grid %lld  bodies/ch %lld pairs %d runs %lld  shares_cus %d prio %d lds %zu\n",
-                a->nch, a->nwin, wpg, per_cu, grid, bodies_per_ch, pairs, nrun, a->shares_cus, a->high_prio, lds);
-    FIR_LAUNCH((fir_u8_coltap_kernel<FOLD, UU, BB, STAGED>), dim3((unsigned int)grid), dim3(64 * wpg), lds, stream, b, a->iq, a->taps,
-                       a->stream_of, a->dm);
-    return (int)hipGetLastError();
-}
-
-// matrix-pipe variant (ACG_FIR_VARIANT=6): single-wave workgroups, as many as the LDS holds (5 per CU at 2.5 Msps)
-template <int CPR>
-static int launch_mfma(const FirArgs* a, int num_cu, hipStream_t stream)
-{
-    int wpg = env_int("ACG_FIR_WAVES_PER_WG", a->shares_cus ? 1 : 4);
-    if (wpg != 1 && wpg != 2 && wpg != 4) wpg = 4;
-    const size_t lds = (size_t)wpg * FirM<CPR>::WAVE_LDS;
-    int per_cu = (int)((160 * 1024) / lds);
-    if (per_cu > 12 / wpg) per_cu = 12 / wpg;
-    if (a->shares_cus && wpg == 1 && per_cu > 7) per_cu = 7;        // leave the demodulator's workgroups their LDS
-    per_cu = env_int("ACG_FIR_WG_PER_CU", per_cu);
-    long long grid = (long long)(a->ncu > 0 ? a->ncu : num_cu) * per_cu;
-    const long long bodies_per_ch = a->nwin / ACG_TILE_WIN / FIRD_R;
-    const long long bodies = (long long)a->nch * bodies_per_ch;
-    int pairs = 1;
-    while (pairs < 8 && bodies_per_ch % (2 * pairs) == 0 && bodies / (2 * pairs) >= 32 * grid * wpg) pairs *= 2;
-    pairs = env_int("ACG_FIR_RUN_PAIRS", pairs);
-    if (pairs < 1 || pairs > 8 || (pairs & (pairs - 1)) || bodies_per_ch % pairs) pairs = 1;
-    const long long nrun = bodies / pairs;
-    const long long need = (nrun + wpg - 1) / wpg;
-    if (grid > need) grid = need;
-    FirArgs b = *a;
-    b.run_pairs = pairs;
-    if (acg_tune_has("ACG_FIR_DEBUG_SHAPE"))
-        fprintf(stderr, "fir_u8_mfma<%d>: nch %d nwin %d  wpg %d per_cu %d grid %lld pairs %d runs %lld lds %zu\n", CPR, a->nch, a->nwin, wpg, per_cu, grid, pairs, nrun, lds);
-    FIR_LAUNCH((fir_u8_mfma_kernel<CPR>), dim3((unsigned int)grid), dim3(64 * wpg), lds, stream, b, a->iq, a->taps, a->stream_of, a->dm);
-    return (int)hipGetLastError();
-}
-
+#include "lab/fir_lab_launch.inc"
 #endif  // ACG_LAB
 
 extern "C" int acg_launch_fir(const FirArgs* a, void* stream)

@@ -19,9 +19,11 @@ def _probe_ab(args, J, step, drain, steps, nch, nout, M):
     ab = {}
     ab_name, _, ab_vals = args.ab.rpartition("=")                # "5,55,8" or "ACG_MSK_LPC_LIVE=2,4"
     ab_name = ab_name or "ACG_FIR_VARIANT"
+    names = ab_name.split("+")                                   # "A+B=a1:b1,a2:b2": two switches set together
     for rnd in range(2):
         for v in ab_vals.split(","):
-            K.tune(ab_name, v)
+            for n_, v_ in zip(names, v.split(":")):
+                K.tune(n_, v_)
             step()
             drain()
             torch.cuda.synchronize()
@@ -35,7 +37,8 @@ def _probe_ab(args, J, step, drain, steps, nch, nout, M):
             torch.cuda.synchronize()
             ab.setdefault(v, []).append(round(nch * nout * M * steps / (time.perf_counter() - t1) / 1e6, 0))
             ab.setdefault(v + " telemetry", []).append(clk_ab)
-    K.tune(ab_name, os.environ.get(ab_name))
+    for n_ in names:
+        K.tune(n_, os.environ.get(n_))
     return ab
 
 
