@@ -136,7 +136,7 @@ def test_coltap_load_groups_cover_a_tile_with_two_fixed_columns_per_lane():
     the lane that loaded exactly that chunk, a lane multiplies column lane % 25 in every even step and (lane + 14) % 25 in
     every odd one, idle lanes only ever land in slots that are overwritten later or in the 28 pad entries, and the byte offsets
     of a two-tile body are what FirC::offset computes.  The constants are read from the source."""
-    src = open(os.path.join(ROOT, "acarsdec_amd", "csrc", "fir.hip")).read()
+    src = open(os.path.join(ROOT, "acarsdec_amd", "csrc", "lab", "fir_coltap_mfma.inc")).read()
     src = src[src.index("struct FirC {"):src.index("// Complex multiply-accumulate of one sample")]
     assert "SPT = 26" in src and "(q >> 1) * 125 + (q & 1) * 64" in src and "P_ENT = 64 * CPR + 28" in src
     assert "(pos / SPT) * (CPR * 1024u) + (unsigned int)chunk0(pos % SPT) * 16u" in src
