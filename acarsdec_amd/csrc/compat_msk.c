@@ -60,7 +60,7 @@ static double now_s(void)
 
 /* ACARSDEC_AMD_STATS=1 in the environment: the time spent inside the legacy entry points is printed at exit (bench.py's
  * rtl8 case reads it: ms per callback against the 81.92 ms a callback's signal lasts, rtl.c:49,213) */
-static void print_stats(void)
+void acarsdec_amd_compat_print_stats(void)
 {
 	if (g_calls)
 		fprintf(stderr, "acarsdec_amd compat: %lu calls, %.6f s inside the legacy entry points, %.4f ms per call "
@@ -75,7 +75,7 @@ static void account(double t0)
 		const char *e = getenv("ACARSDEC_AMD_STATS");
 		hooked = 1;
 		if (e && *e && *e != '0')
-			atexit(print_stats);
+			atexit(acarsdec_amd_compat_print_stats);
 	}
 	{
 		const double dt = now_s() - t0;

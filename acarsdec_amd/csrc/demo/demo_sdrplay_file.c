@@ -37,6 +37,8 @@ mir_sdr_ErrT mir_sdr_SetDcMode(int a, int b) { (void)a; (void)b; return mir_sdr_
 mir_sdr_ErrT mir_sdr_SetDcTrackTime(int t) { (void)t; return mir_sdr_Success; }
 mir_sdr_ErrT mir_sdr_DCoffsetIQimbalanceControl(unsigned int a, unsigned int b) { (void)a; (void)b; return mir_sdr_Success; }
 
+void acarsdec_amd_compat_print_stats(void) __attribute__((weak));
+
 static void *player(void *arg)
 {
 	const char *path = getenv("ACARSDEC_IQ_FILE");
@@ -60,6 +62,8 @@ static void *player(void *arg)
 	}
 	usleep(500 * 1000);                           /* the block thread prints what is queued (acars.c:93-215) */
 	fflush(stdout);
+	if (acarsdec_amd_compat_print_stats && getenv("ACARSDEC_AMD_STATS"))      /* (only the GPU twin links compat_msk.c) */
+		acarsdec_amd_compat_print_stats();
 	_exit(0);                                     /* sdrplay.c:284-285 has no way out of its run loop */
 	return NULL;
 }

@@ -135,8 +135,12 @@ __device__ __forceinline__ float mm_cabs(float re, float im)
 // One run = `tpr` consecutive tiles of one group.  Runs are numbered group-major (a stream is read front to back); the first
 // run of wave wg is run wg, further ones come from an atomic ticket (words [0] = tickets, [1] = waves finished: the last wave
 // out re-arms both, no memset between launches).
-template <int CPR>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// STAGES = tiles in flight per wave.  1: two waves per SIMD (<= 256 VGPRs each), the next tile's loads wait in 52 registers while
+// this one is multiplied.  2: ONE wave per SIMD with two tiles (25 KiB) in flight in 104 registers -- the same bytes in flight per
+// CU, and a SIMD's register file then still holds a demodulator wave (136 VGPRs) beside it: with two 232-register waves per SIMD
+// the demodulator's workgroups wait for a SIMD to drain, and at 8 channels per stream the demodulator is the stage that sets the step.
+template <int CPR, int STAGES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STAGES == 1 ? 2 : 1, STAGES == 1 ? 2 : 1)))
 void fir_u8_mm_kernel(const FirArgs a, const uint8_t* __restrict__ iq_base, const u4m_t* __restrict__ img,
                       const MmChan* __restrict__ mmch, const int4* __restrict__ groups, const int* __restrict__ group_ch,
                       float* __restrict__ dm_base)
@@ -180,9 +184,13 @@ void fir_u8_mm_kernel(const FirArgs a, const uint8_t* __restrict__ iq_base, cons
         const int kc = gi.z;
         const uint8_t* base = iq_base + (size_t)gi.x * a.pitch + (size_t)t0 * F::TILE_BYTES;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(tpr * (unsigned int)F::TILE_BYTES), 0x00020000);
-        u4m_t st[F::NLD];
+        u4m_t stA[F::NLD], stB[F::NLD];
 #pragma unroll
-        for (int q = 0; q < F::NLD; ++q) st[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff[q], q * 1024, 2 /* nt */);
+        for (int q = 0; q < F::NLD; ++q) stA[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff[q], q * 1024, 2 /* nt */);
+        if (STAGES == 2 && tpr > 1) {
+#pragma unroll
+            for (int q = 0; q < F::NLD; ++q) stB[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff[q], F::TILE_BYTES + q * 1024, 2);
+        }
 
         // the group's A operand (digits of its <= 8 tap tables) into registers, its channels' constants into LDS
         v4i_t tap[F::KS][2];
@@ -209,18 +217,18 @@ void fir_u8_mm_kernel(const FirArgs a, const uint8_t* __restrict__ iq_base, cons
             dmrow[i] = ch >= 0 ? dm_base + (size_t)ch * a.dm_pitch + (size_t)t0 * F::WIN + w : nullptr;
         }
 
-        for (unsigned int t = 0; t < tpr; ++t) {
+        auto tile_step = [&](u4m_t (&st)[F::NLD], unsigned int t) {
             // ---- tile t: registers -> LDS (the previous tile's reads are older LDS operations of this wave: they are done)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int q = 0; q < F::NLD; ++q)
                 if (q + 1 < F::NLD || (F::WIN * CPR) % 64 == 0 || lane < (F::WIN * CPR) % 64) *(u4m_t*)(tile + ldsoff[q]) = st[q];
-            // ---- ask for tile t + 1 (lands in registers while this one is multiplied)
-            if (t + 1 < tpr) {
+            // ---- ask for tile t + STAGES (lands in these registers while this one and the next are multiplied)
+            if (t + STAGES < tpr) {
 #pragma unroll
                 for (int q = 0; q < F::NLD; ++q)
-                    st[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff[q], (int)((t + 1) * (unsigned int)F::TILE_BYTES) + q * 1024, 2);
+                    st[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff[q], (int)((t + STAGES) * (unsigned int)F::TILE_BYTES) + q * 1024, 2);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -258,6 +266,14 @@ void fir_u8_mm_kernel(const FirArgs a, const uint8_t* __restrict__ iq_base, cons
                     dmrow[i][0] = mm_cabs(v[0], v[1]);
                     dmrow[i] += F::WIN;
                 }
+            }
+        };
+        if (STAGES == 1) {
+            for (unsigned int t = 0; t < tpr; ++t) tile_step(stA, t);
+        } else {
+            for (unsigned int t = 0; t < tpr; t += 2) {
+                tile_step(stA, t);
+                if (t + 1 < tpr) tile_step(stB, t + 1);
             }
         }
         unsigned int tk = 0;
@@ -311,14 +327,16 @@ int mm_optin(MmDev* d, const void* kernel, size_t bytes)
     return 0;
 }
 
-template <int CPR>
+extern "C" int acg_tune_get(const char* name, int dflt);
+
+template <int CPR, int STAGES>
 int launch_mm(const FirArgs* a, hipStream_t stream)
 {
     typedef FirMM<CPR> F;
     MmDev* d = nullptr;
     if (int e = mm_device(&d)) return e;
     const int ncu = a->ncu > 0 ? a->ncu : d->num_cu;
-    const unsigned int nwaves = (unsigned int)ncu * 8u;
+    const unsigned int nwaves = (unsigned int)ncu * (STAGES == 1 ? 8u : 4u);
     const unsigned int ntile = (unsigned int)a->nwin / F::WIN;
     // ~4 runs per wave where the launch is large enough, at least two tiles per run (a run pays one tile of load latency
     // and 26 KiB of digits from L2)
@@ -328,10 +346,11 @@ int launch_mm(const FirArgs* a, hipStream_t stream)
     b.run_pairs = (int)(ntile / rpg);
     const unsigned long long nrun = (unsigned long long)a->ngroups * rpg;
     const unsigned int need = (unsigned int)((nrun + 3) / 4);
-    const unsigned int grid = need < (unsigned int)ncu * 2u ? need : (unsigned int)ncu * 2u;
+    const unsigned int blocks = (unsigned int)ncu * (STAGES == 1 ? 2u : 1u);
+    const unsigned int grid = need < blocks ? need : blocks;
     const size_t lds = (size_t)4 * F::WAVE_LDS;
-    if (int e = mm_optin(d, (const void*)fir_u8_mm_kernel<CPR>, lds)) return e;
-    hipLaunchKernelGGL(fir_u8_mm_kernel<CPR>, dim3(grid), dim3(256), lds, stream, b, a->iq, (const u4m_t*)a->mm_img,
+    if (int e = mm_optin(d, (const void*)fir_u8_mm_kernel<CPR, STAGES>, lds)) return e;
+    hipLaunchKernelGGL((fir_u8_mm_kernel<CPR, STAGES>), dim3(grid), dim3(256), lds, stream, b, a->iq, (const u4m_t*)a->mm_img,
                        (const MmChan*)a->mm_chan, a->groups, a->group_ch, a->dm);
     return (int)hipGetLastError();
 }
@@ -371,10 +390,12 @@ extern "C" int acg_launch_fir_mm_prep(const FirArgs* a, void* stream)
 extern "C" int acg_launch_fir_mm(const FirArgs* a, void* stream)
 {
     if (!acg_fir_mm_takes(a)) return (int)hipErrorInvalidValue;
+    // beside the demodulator on the same CUs: one wave per SIMD with two tiles in flight (see the kernel's comment)
+    const int stages = acg_tune_get("ACG_FIR_MM_STAGES", a->shares_cus ? 2 : 1) == 2 ? 2 : 1;
     switch (a->decim / 8) {
-    case 20: return launch_mm<20>(a, (hipStream_t)stream);
-    case 24: return launch_mm<24>(a, (hipStream_t)stream);
-    case 25: return launch_mm<25>(a, (hipStream_t)stream);
+    case 20: return stages == 2 ? launch_mm<20, 2>(a, (hipStream_t)stream) : launch_mm<20, 1>(a, (hipStream_t)stream);
+    case 24: return stages == 2 ? launch_mm<24, 2>(a, (hipStream_t)stream) : launch_mm<24, 1>(a, (hipStream_t)stream);
+    case 25: return stages == 2 ? launch_mm<25, 2>(a, (hipStream_t)stream) : launch_mm<25, 1>(a, (hipStream_t)stream);
     }
     return (int)hipErrorInvalidValue;
 }

@@ -299,7 +299,8 @@ def run_case(J, name, case, args, steps, warmup, headline):
     msk_ms_step = warm["msk_ms"] / (warmup + (2 if repair else 1)) * reps      # (the gate's one or two passes are in the sum)
     mm = share > 1 and M in (160, 192, 200) and (cb * 1024) % 64 == 0             # (mirrors acg_fir_mm_takes)
     if fmt == 0:
-        kname = ("fir_u8_mm_kernel<%d>" % (M // 8) if mm else "fir_u8_shared_kernel") if share > 1 else J.fir_kernel_name(M, nout)
+        # (fir_mm.hip: two tiles in flight on one wave per SIMD where the demodulator shares the CUs -- no CU partition above 2048 channels)
+        kname = ("fir_u8_mm_kernel<%d, %d>" % (M // 8, 2 if nch > 2048 else 1) if mm else "fir_u8_shared_kernel") if share > 1 else J.fir_kernel_name(M, nout)
     else:
         # (mirrors acg_launch_fir_fmt: the wave-private kernel <FMT, 16-byte chunks per window (per plane), windows per tile> where it is
         #  instantiated for the window length, else round 1's workgroup-granular kernel)

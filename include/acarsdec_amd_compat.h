@@ -36,6 +36,9 @@ void acarsdec_amd_compat_keep_dm(int on);
 /* host time spent inside the legacy entry points so far and the number of calls (a harness reports ms per callback
  * against the 81.92 ms a callback's signal lasts, rtl.c:49,213) */
 void acarsdec_amd_compat_stats(double *seconds, unsigned long *calls);
+/* the line ACARSDEC_AMD_STATS=1 prints at exit, on demand (a front end whose run loop never returns, sdrplay.c:284-285, ends the
+ * process with _exit(): no atexit handlers) */
+void acarsdec_amd_compat_print_stats(void);
 
 #ifdef __cplusplus
 }

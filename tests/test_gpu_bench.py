@@ -119,7 +119,7 @@ def test_bench_also_cases_in_one_line():
     assert c["also"]["shard2048"]["ch"] == 192 and "u8" not in d["also"]["cs16"]["config"]["arithmetic"]
     # rtl.c's own shape on the matrix pipe: 8 channels per dongle stream, the kernel named, its HBM fraction and what a VALU kernel would need
     s8 = d["also"]["share8"]
-    assert s8["config"]["channels_per_stream"] == 8 and s8["roofline"]["kernel"] == "fir_u8_mm_kernel<25>" and s8["roofline"]["bound"] == "hbm"
+    assert s8["config"]["channels_per_stream"] == 8 and s8["roofline"]["kernel"] == "fir_u8_mm_kernel<25, 1>" and s8["roofline"]["bound"] == "hbm"
     assert s8["roofline"]["valu_equivalent"]["frac"] > 0 and 0 < s8["roofline"]["mfma_i8"]["frac"] < 1 and "ACARS" in s8["data"]
     assert c["also"]["share8"]["ch_per_stream"] == 8 and c["also"]["split16"]["fmt"] == "split16" and c["also"]["m160"]["M"] == 160
     assert d["also"]["m160"]["roofline"]["kernel"].startswith("fir_u8_direct_kernel<20,") and d["also"]["m192"]["roofline"]["kernel"].startswith("fir_u8_direct_kernel<24,")

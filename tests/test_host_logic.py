@@ -411,7 +411,7 @@ def test_bench_compact_line_stays_under_4k_at_the_full_case_shape():
         d["also"][k_].setdefault("sustain", {}).update(burst5s=3051234.5, telemetry_start_mid_end=[tele, tele, tele])
         d["also"][k_]["timed_region_s"] = 20.123
     d["also"]["share8"]["config"]["channels_per_stream"] = 8
-    d["also"]["share8"]["roofline"].update(kernel="fir_u8_mm_kernel<25>", valu_equivalent={"frac": 0.7512}, mfma_i8={"frac": 0.2012})
+    d["also"]["share8"]["roofline"].update(kernel="fir_u8_mm_kernel<25, 2>", valu_equivalent={"frac": 0.7512}, mfma_i8={"frac": 0.2012})
     d["also"]["split16"]["config"]["input_format"] = "split16"
     for a in [v for v in d["also"].values()] + [d]:
         a["roofline"]["traffic_src"] = "r05"
