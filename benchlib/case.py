@@ -253,7 +253,10 @@ def run_case(J, name, case, args, steps, warmup, headline):
     # ---- correctness gate on the first pass (state starts from reset): benchlib/gate.py
     from types import SimpleNamespace
     from . import gate
-    parity = gate.first_pass(SimpleNamespace(args=args, J=J, name=name, rank=rank, nch=nch, share=share, fmt=fmt, M=M, taps=taps, ntaps=ntaps, iq=iq, row=row,
+    # channels the gate looks at: --check-channels (64), more where a case says so (wide: 8 callbacks = 0.66 s of signal per
+    # channel is half a block per channel -- VERDICT r05 weak 1: "also.wide gates on 32 blocks")
+    check = case.get("check_channels", args.check_channels) if args.check_channels == 64 else args.check_channels
+    parity = gate.first_pass(SimpleNamespace(check=check, args=args, J=J, name=name, rank=rank, nch=nch, share=share, fmt=fmt, M=M, taps=taps, ntaps=ntaps, iq=iq, row=row,
                                              nout=nout, cb=cb, ncall=ncall, cb_bytes=cb_bytes, stream=stream, maxfr=maxfr, repair=repair, dec=dec, step=step))
 
     # ---- timing.  A "pass" = the hot path once over the resident batch (the step of rounds 1-2).  `burst`: `steps` single

@@ -20,7 +20,7 @@ CASES = {
     # BASELINE.json configs[2]: 1 GPU, 1024 channels, synthetic 2.5 Msps IQ, FIR decimate + MSK demod throughput
     "throughput": dict(tag="BASELINE configs[2]", channels=1024, decim=200, ntaps=200, blocks=176, content="acars"),
     # north-star regime: >= 10 000 concurrent channels at 2.5 Msps on one GPU
-    "wide": dict(tag="north star (>= 10 000 channels per GPU)", channels=16384, decim=200, ntaps=200, blocks=8, content="acars"),
+    "wide": dict(tag="north star (>= 10 000 channels per GPU)", channels=16384, decim=200, ntaps=200, blocks=8, content="acars", check_channels=256),
     # BASELINE.json configs[4]: 1 GPU stress, 192-tap LPF FIR, 2.5 Msps, 4096 channels
     "stress": dict(tag="BASELINE configs[4]", channels=4096, decim=200, ntaps=192, blocks=32, content="random+acars"),
     # the soapy.c front end's sample format (interleaved int16 I/Q) through the same pipeline

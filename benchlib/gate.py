@@ -35,7 +35,7 @@ def first_pass(cx):
                                  "stream", "maxfr", "repair", "dec", "step"))
     parity = None
     first = []
-    ncheck = min(args.check_channels, nch) if rank == 0 else 0
+    ncheck = min(cx.check, nch) if rank == 0 else 0
     dm_gpu = {c: [] for c in range(ncheck)}
     step(lag=0, sink=first, dm_sink=dm_gpu if ncheck else None, frames=True)
     msgs_first = []

@@ -126,7 +126,8 @@ def test_bench_also_cases_in_one_line():
     assert d["also"]["split16"]["roofline"]["kernel"] == "fir_fmt_direct_kernel<2, 20, 64>" and "ACARS" in d["also"]["split16"]["data"]
     assert d["roofline_msk"]["bound"] == "issue" and d["roofline_msk"]["us_per_bit"] > 0 and c["roofline_msk"]["instr_per_bit"] == 325
     for name, a in d["also"].items():
-        assert a["parity"]["dm_within_1e5_rel"] is True and a["parity"]["blocks_exact_given_gpu_dm"] is True and a["parity"]["channels_checked"] == 64
+        assert a["parity"]["dm_within_1e5_rel"] is True and a["parity"]["blocks_exact_given_gpu_dm"] is True
+        assert a["parity"]["channels_checked"] == (256 if name == "wide" else 64)        # (wide: half a block per channel, so four times the channels)
         if name not in ("cs16", "f32", "split16"):        # (the exact-order mode restates rtl.c's u8 loop)
             assert a["parity"]["exact_order_mode"]["blocks_identical_end_to_end"] is True
         assert 0 < a["roofline"]["frac"] < 1 and 0 < a["whole_job_frac_of_hbm"] < 1 and a["value"] > 0
