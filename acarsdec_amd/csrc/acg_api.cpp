@@ -188,6 +188,8 @@ struct acg_ctx {
     void* d_mm_chan = nullptr;
     size_t mm_img_bytes = 0;
     bool mm_dirty = true;
+    void* d_mm1_img = nullptr;      // ... and per channel for the one-stream-per-channel kernel (fir_u8_mm1_kernel), made on first use
+    bool mm1_dirty = true;
     float* d_dm = nullptr;          // dm buffer of the newest call (one of the two halves of d_dm_all)
     float* d_dm_all = nullptr;      // two dm buffers: the down-converter of call i+1 fills one while the demodulator of call i reads the other
     int dm_par = 0;
@@ -282,7 +284,7 @@ extern "C" int acg_device_count(void)
 static void free_all(acg_ctx* c)
 {
     if (!c) return;
-    hipFree(c->d_taps); hipFree(c->d_stream_of); hipFree(c->d_groups); hipFree(c->d_group_ch); hipFree(c->d_gtaps); hipFree(c->d_mm_img); hipFree(c->d_mm_chan); hipFree(c->d_dm_all); hipFree(c->d_st);
+    hipFree(c->d_taps); hipFree(c->d_stream_of); hipFree(c->d_groups); hipFree(c->d_group_ch); hipFree(c->d_gtaps); hipFree(c->d_mm_img); hipFree(c->d_mm1_img); hipFree(c->d_mm_chan); hipFree(c->d_dm_all); hipFree(c->d_st);
     hipFree(c->d_h); hipFree(c->d_sctab); hipFree(c->d_txt); hipFree(c->d_frames); hipFree(c->d_frame_count);
     hipFree(c->d_stamp);
     hipFree(c->d_msgs); std::free(c->h_msgs);
@@ -320,6 +322,10 @@ extern "C" void acg_destroy(acg_ctx* ctx)
 
 // Channel -> stream map, plus its inverse for the shared-stream down-converter: channels ordered by
 // stream and cut into groups of <= 8 channels of one stream (rtl.c's shape: one dongle, several channels).
+#ifndef ACG_FIR_MM1_DEFAULT
+#define ACG_FIR_MM1_DEFAULT 0
+#endif
+
 static int upload_stream_map(acg_ctx* c, const int* so)
 {
     const int nch = c->cfg.nch, ns = c->cfg.nstreams;
@@ -621,6 +627,7 @@ extern "C" int acg_set_taps(acg_ctx* ctx, int ch0, int n, const float* taps)
                             src_pitch, (size_t)n, hipMemcpyHostToDevice));
     ctx->gtaps_dirty = true;
     ctx->mm_dirty = true;
+    ctx->mm1_dirty = true;
     return ACG_OK;
 }
 
@@ -738,7 +745,28 @@ static int launch_fir(acg_ctx* c, const uint8_t* iq_dev, size_t pitch, int nbloc
         // several channels per stream: the contraction goes to the matrix pipe (fir_mm.hip) where it takes the shape
         // (rtlMult 160 / 192 / 200, whole tiles), else to the vector-pipe kernel below
         const bool mm = c->ngroups > 0 && acg_tune_get("ACG_FIR_MM", 1) && acg_fir_mm_takes(&a);
-        if (mm) {
+        // one stream per channel: the same exact contraction with K = 1 takes the arithmetic off the vector pipe (fir_u8_mm1_kernel)
+        bool mm1 = false;
+        if (c->ngroups == 0 && acg_tune_get("ACG_FIR_MM1", ACG_FIR_MM1_DEFAULT) && acg_fir_mm1_image_bytes(g.decim, 1) != 0) {
+            if (!c->d_mm1_img) {
+                HIPCHK(c, hipMalloc(&c->d_mm1_img, acg_fir_mm1_image_bytes(g.decim, g.nch)));
+                c->mm1_dirty = true;
+            }
+            if (!c->d_mm_chan) HIPCHK(c, hipMalloc(&c->d_mm_chan, (size_t)g.nch * sizeof(MmChan)));
+            a.mm_img = c->d_mm1_img;
+            a.mm_chan = c->d_mm_chan;
+            mm1 = acg_fir_mm1_takes(&a) != 0;
+        }
+        if (mm1) {
+            if (c->mm1_dirty) {
+                if ((e = acg_launch_fir_mm1_prep(&a, s)) != 0) {
+                    c->err = std::string("tap digit launch: ") + hipGetErrorString((hipError_t)e);
+                    return ACG_EHIP;
+                }
+                c->mm1_dirty = false;
+            }
+            e = acg_launch_fir_mm1(&a, s);
+        } else if (mm) {
             if (c->mm_dirty) {
                 if ((e = acg_launch_fir_mm_prep(&a, s)) != 0) {
                     c->err = std::string("tap digit launch: ") + hipGetErrorString((hipError_t)e);

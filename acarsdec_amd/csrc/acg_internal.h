@@ -161,6 +161,10 @@ size_t acg_fir_mm_image_bytes(int decim, int ngroups);               // fir_mm.h
 int acg_fir_mm_takes(const FirArgs* a);
 int acg_launch_fir_mm_prep(const FirArgs* a, void* stream);
 int acg_launch_fir_mm(const FirArgs* a, void* stream);
+size_t acg_fir_mm1_image_bytes(int decim, int nch);                  // fir_mm.hip, one stream per channel: 256 B per channel and k-step
+int acg_fir_mm1_takes(const FirArgs* a);
+int acg_launch_fir_mm1_prep(const FirArgs* a, void* stream);
+int acg_launch_fir_mm1(const FirArgs* a, void* stream);
 int acg_launch_fir_fmt(const FirArgs* a, int fmt, void* stream);     // fmt: 1 CS16, 2 split int16 planes, 3 real f32
 size_t acg_fir_lds_bytes(const FirArgs* a);
 int acg_launch_msk(const MskArgs* a, int lanes_per_channel, void* stream);

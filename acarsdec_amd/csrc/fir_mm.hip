@@ -41,6 +41,7 @@ typedef int v16i_t __attribute__((ext_vector_type(16)));
 typedef unsigned int u4m_t __attribute__((ext_vector_type(4)));
 
 extern __shared__ __attribute__((aligned(16))) unsigned char mm_smem[];
+extern "C" int acg_tune_get(const char* name, int dflt);          // measurement / layout switches (acg_api.cpp)
 
 template <int CPR>
 struct FirMM {
@@ -289,6 +290,158 @@ void fir_u8_mm_kernel(const FirArgs a, const uint8_t* __restrict__ iq_base, cons
     }
 }
 
+// ---- one stream per channel on the matrix pipe ---------------------------------------------------------------------------
+// fir_u8_mm1_kernel: the K = 1 case of the contraction above.  It does not need the matrix pipe for its arithmetic rate (8 flop per
+// 2 bytes) -- it uses it to get the arithmetic OFF the vector pipe: the wave-private streaming kernel of fir.hip spends 16 v_cvt +
+// 16 v_pk_fma + 4 ds_read_b128 of taps per 16 input bytes and lane (~40 VALU / LDS issues per KiB and wave: 40 % of every SIMD's
+// issue slots at 6 TB/s), and beside it runs the demodulator, a serial chain that needs ~75 % of a SIMD by itself -- together they
+// are VALU-bound before they are HBM-bound, and the arithmetic's power sets the shader clock the demodulator runs at.  Here a KiB
+// costs 4 v_xor + one ds_write_b128 / ds_read_b128 pair + one MFMA issue, and the sum is exact (see above).
+//   rows of the MFMA: digit + 8 (re / im) -- 8 of the 32 rows carry the channel's digits, the others are zero (the matrix pipe is
+//   at ~10 % either way); C/D layout: lanes 0..31 hold re (regs 0..3) and im (regs 4..7) of their window, lanes 32..63 hold zeros.
+//   A operand: 13 x 4 VGPRs, loaded once per run from the channel's compact digit image ([k-step][half][8 rows][16 B] = 3.3 KiB).
+// Workgroup = one wave (LDS is handed out in 13 KiB pieces: seven fit beside the demodulator's 62 KiB per CU).
+template <int CPR>
+__global__ void mm1_image_kernel(const float* __restrict__ taps, int ntaps_pad, int M, const MmChan* __restrict__ mmch,
+                                 u4m_t* __restrict__ img)
+{
+    typedef FirMM<CPR> F;
+    const int ch = blockIdx.x;
+    const int n1 = ntaps_pad < M ? ntaps_pad : M;
+    const float2* tp = (const float2*)(taps + (size_t)ch * ntaps_pad * 2);
+    const double up = mmch[ch].up;
+    for (int item = threadIdx.x; item < F::KS * 16; item += blockDim.x) {            // (k, h, compact row): 16 bytes each
+        const int ci = item & 7, h = (item >> 3) & 1, k = item >> 4;
+        const int piece = ci & 3, reim = ci >> 2;
+        u4m_t w = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int b = 32 * k + 16 * h + j, n = b >> 1;
+            int q = 0;
+            if (n < n1) {
+                const float2 t = tp[n];
+                const float coef = reim ? ((b & 1) ? t.x : t.y) : ((b & 1) ? -t.y : t.x);
+                q = __double2int_rn((double)coef * up);
+            }
+            for (int p = 0; p < piece; ++p) q = (q - (int)(signed char)(q & 255)) >> 8;
+            const unsigned int d = (unsigned int)(int)(signed char)(q & 255) & 255u;
+            w[j >> 2] |= d << (8 * (j & 3));
+        }
+        img[(size_t)ch * (F::KS * 16) + item] = w;
+    }
+}
+
+template <int CPR>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 3)))
+void fir_u8_mm1_kernel(const FirArgs a, const uint8_t* __restrict__ iq_base, const u4m_t* __restrict__ img,
+                       const MmChan* __restrict__ mmch, const int* __restrict__ stream_of, float* __restrict__ dm_base)
+{
+    typedef FirMM<CPR> F;
+    const int lane = threadIdx.x & 63;
+    unsigned char* tile = mm_smem;
+    const unsigned int nwaves = gridDim.x;
+    const unsigned int wg = blockIdx.x;
+    const unsigned int tpr = (unsigned int)a.run_pairs;                              // tiles per run (launcher)
+    const unsigned int rpc = ((unsigned int)a.nwin / F::WIN) / tpr;                  // runs per channel
+    const unsigned int nrun = (unsigned int)a.nch * rpc;
+    unsigned int* ctr = a.work_counter;
+    const int w = lane & 31, h = lane >> 5;
+    const unsigned char* rowp = tile + w * F::S + 16 * h;
+    if (a.high_prio) __builtin_amdgcn_s_setprio(2);
+
+    unsigned int voff[F::NLD];
+    unsigned int ldsoff[F::NLD];
+#pragma unroll
+    for (int q = 0; q < F::NLD; ++q) {
+        const unsigned int c = (unsigned int)(q * 64 + lane);
+        const unsigned int r = (c * ((65536u + CPR - 1) / CPR)) >> 16;
+        ldsoff[q] = (c << 4) + r * (unsigned int)(F::S - F::RB);
+        voff[q] = c < (unsigned int)(F::WIN * CPR) ? ((unsigned int)lane << 4) : 0x80000000u;
+    }
+    // this lane's piece of the A operand: row = lane & 31 -- rows 0..3 (re digits) and 8..11 (im digits) exist
+    const int arow = lane & 31;
+    const bool ahas = (arow & 4) == 0 && arow < 12;
+    const int aci = (arow & 3) + 4 * (arow >> 3);
+
+    unsigned int run = wg;
+    if (run >= nrun) {
+        unsigned int t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        run = nwaves + (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+    }
+    while (run < nrun) {
+        const unsigned int ch = run / rpc;
+        const unsigned int t0 = (run - ch * rpc) * tpr;
+        const size_t srow = (size_t)(a.stream_identity ? (int)ch : stream_of[ch]) * a.pitch;
+        const uint8_t* base = iq_base + srow + (size_t)t0 * F::TILE_BYTES;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(tpr * (unsigned int)F::TILE_BYTES), 0x00020000);
+        u4m_t st[F::NLD];
+#pragma unroll
+        for (int q = 0; q < F::NLD; ++q) st[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff[q], q * 1024, 2 /* nt */);
+        v4i_t tap[F::KS];
+        {
+            const v4i_t* ip = (const v4i_t*)img + (size_t)ch * (F::KS * 16) + (h * 8 + aci);
+            const v4i_t z = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < F::KS; ++k) tap[k] = ahas ? ip[k * 16] : z;
+        }
+        const MmChan cc = mmch[ch];                                                   // (wave-uniform: scalar loads)
+        float* dmp = dm_base + (size_t)ch * a.dm_pitch + (size_t)t0 * F::WIN + w;
+
+        for (unsigned int t = 0; t < tpr; ++t) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < F::NLD; ++q)
+                if (q + 1 < F::NLD || (F::WIN * CPR) % 64 == 0 || lane < (F::WIN * CPR) % 64) *(u4m_t*)(tile + ldsoff[q]) = st[q];
+            if (t + 1 < tpr) {
+#pragma unroll
+                for (int q = 0; q < F::NLD; ++q)
+                    st[q] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff[q], (int)((t + 1) * (unsigned int)F::TILE_BYTES) + q * 1024, 2);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // two accumulator chains (even / odd k-steps): no MFMA waits for the one before it; integer sums add up exactly
+            v16i_t acc0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            v16i_t acc1 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < F::KS; ++k) {
+                u4m_t d = *(const u4m_t*)(rowp + 32 * k);
+                d ^= 0x80808080u;
+                v4i_t b;
+                b[0] = (int)d[0]; b[1] = (int)d[1]; b[2] = (int)d[2]; b[3] = (int)d[3];
+                if (k & 1) acc1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(tap[k], b, acc1, 0, 0, 0);
+                else acc0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(tap[k], b, acc0, 0, 0, 0);
+            }
+            if (h == 0) {                                                             // lanes 0..31: re in regs 0..3, im in regs 4..7
+                float v[2];
+#pragma unroll
+                for (int ri = 0; ri < 2; ++ri) {
+                    const int a0 = acc0[4 * ri + 0] + acc1[4 * ri + 0], a1 = acc0[4 * ri + 1] + acc1[4 * ri + 1];
+                    const int a2 = acc0[4 * ri + 2] + acc1[4 * ri + 2], a3 = acc0[4 * ri + 3] + acc1[4 * ri + 3];
+                    const int lo = a1 * 256 + a0;
+                    const int hi = a3 * 256 + a2;
+                    const double D = __fma_rn((double)hi, 65536.0, (double)lo);
+                    v[ri] = (float)__fma_rn(D, cc.scale, ri ? cc.dc_im : cc.dc_re);
+                }
+                const float mag = mm_cabs(v[0], v[1]);
+                asm volatile("global_store_dword %0, %1, off sc0 sc1" : : "v"(dmp), "v"(mag) : "memory");      // write-through, as fir.hip's kernel
+            }
+            dmp += F::WIN;
+        }
+        unsigned int tk = 0;
+        if (lane == 0) tk = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        run = nwaves + (unsigned int)__builtin_amdgcn_readfirstlane((int)tk);
+    }
+    if (lane == 0) {
+        const unsigned int d = atomicAdd(ctr + 1, 1u);
+        if (d == nwaves - 1) {
+            __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(ctr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // ---- launch side ------------------------------------------------------------------------------------------------------
 namespace {
 struct MmDev {
@@ -326,8 +479,6 @@ int mm_optin(MmDev* d, const void* kernel, size_t bytes)
     }
     return 0;
 }
-
-extern "C" int acg_tune_get(const char* name, int dflt);
 
 template <int CPR, int STAGES>
 int launch_mm(const FirArgs* a, hipStream_t stream)
@@ -396,6 +547,75 @@ extern "C" int acg_launch_fir_mm(const FirArgs* a, void* stream)
     case 20: return stages == 2 ? launch_mm<20, 2>(a, (hipStream_t)stream) : launch_mm<20, 1>(a, (hipStream_t)stream);
     case 24: return stages == 2 ? launch_mm<24, 2>(a, (hipStream_t)stream) : launch_mm<24, 1>(a, (hipStream_t)stream);
     case 25: return stages == 2 ? launch_mm<25, 2>(a, (hipStream_t)stream) : launch_mm<25, 1>(a, (hipStream_t)stream);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
+// ---- one stream per channel (fir_u8_mm1_kernel) ---------------------------------------------------------------------------
+namespace {
+template <int CPR>
+int launch_mm1(const FirArgs* a, hipStream_t stream)
+{
+    typedef FirMM<CPR> F;
+    MmDev* d = nullptr;
+    if (int e = mm_device(&d)) return e;
+    const int ncu = a->ncu > 0 ? a->ncu : d->num_cu;
+    int per_cu = a->shares_cus ? 7 : 8;                              // (13.2 KiB of LDS each; the demodulator's 62 KiB fit beside seven)
+    per_cu = acg_tune_get("ACG_FIR_MM1_WAVES", per_cu);
+    if (per_cu < 1 || per_cu > 12) per_cu = 8;
+    const unsigned int nwaves = (unsigned int)ncu * (unsigned int)per_cu;
+    const unsigned int ntile = (unsigned int)a->nwin / F::WIN;
+    unsigned int rpc = 1;                                            // ~4 runs per wave, at least 8 tiles per run
+    while (rpc * 2 * (unsigned int)a->nch <= 4 * nwaves && ntile % (rpc * 2) == 0 && ntile / (rpc * 2) >= 8) rpc *= 2;
+    FirArgs b = *a;
+    b.run_pairs = (int)(ntile / rpc);
+    const unsigned long long nrun = (unsigned long long)a->nch * rpc;
+    const unsigned int grid = nrun < nwaves ? (unsigned int)nrun : nwaves;
+    const size_t lds = (size_t)F::WAVE_LDS;
+    if (int e = mm_optin(d, (const void*)fir_u8_mm1_kernel<CPR>, lds)) return e;
+    hipLaunchKernelGGL(fir_u8_mm1_kernel<CPR>, dim3(grid), dim3(64), lds, stream, b, a->iq, (const u4m_t*)a->mm_img,
+                       (const MmChan*)a->mm_chan, a->stream_of, a->dm);
+    return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" size_t acg_fir_mm1_image_bytes(int decim, int nch)
+{
+    const int cpr = decim / 8;
+    if (decim % 8 != 0 || !(cpr == 20 || cpr == 24 || cpr == 25)) return 0;
+    return (size_t)nch * (size_t)((cpr + 1) / 2) * 256;
+}
+
+extern "C" int acg_fir_mm1_takes(const FirArgs* a)
+{
+    return a->ngroups == 0 && a->mm_img && a->mm_chan && acg_fir_mm1_image_bytes(a->decim, 1) != 0 && a->nwin > 0 && a->nwin % 256 == 0 &&
+           a->ntaps_pad <= a->decim && (unsigned long long)a->nwin * 2ull * (unsigned long long)a->decim < (1ull << 31) &&
+           (unsigned long long)a->nch * ((unsigned long long)a->nwin / 32) < (1ull << 31);
+}
+
+extern "C" int acg_launch_fir_mm1_prep(const FirArgs* a, void* stream)
+{
+    hipLaunchKernelGGL(mm_chan_kernel, dim3((unsigned int)a->nch), dim3(64), 0, (hipStream_t)stream, a->taps, a->ntaps_pad, a->decim,
+                       (MmChan*)a->mm_chan);
+    switch (a->decim / 8) {
+    case 20: hipLaunchKernelGGL(mm1_image_kernel<20>, dim3((unsigned int)a->nch), dim3(64), 0, (hipStream_t)stream, a->taps, a->ntaps_pad, a->decim,
+                                (const MmChan*)a->mm_chan, (u4m_t*)a->mm_img); break;
+    case 24: hipLaunchKernelGGL(mm1_image_kernel<24>, dim3((unsigned int)a->nch), dim3(64), 0, (hipStream_t)stream, a->taps, a->ntaps_pad, a->decim,
+                                (const MmChan*)a->mm_chan, (u4m_t*)a->mm_img); break;
+    case 25: hipLaunchKernelGGL(mm1_image_kernel<25>, dim3((unsigned int)a->nch), dim3(64), 0, (hipStream_t)stream, a->taps, a->ntaps_pad, a->decim,
+                                (const MmChan*)a->mm_chan, (u4m_t*)a->mm_img); break;
+    default: return (int)hipErrorInvalidValue;
+    }
+    return (int)hipGetLastError();
+}
+
+extern "C" int acg_launch_fir_mm1(const FirArgs* a, void* stream)
+{
+    if (!acg_fir_mm1_takes(a)) return (int)hipErrorInvalidValue;
+    switch (a->decim / 8) {
+    case 20: return launch_mm1<20>(a, (hipStream_t)stream);
+    case 24: return launch_mm1<24>(a, (hipStream_t)stream);
+    case 25: return launch_mm1<25>(a, (hipStream_t)stream);
     }
     return (int)hipErrorInvalidValue;
 }

@@ -21,6 +21,8 @@ STUB(acg_launch_fir) STUB(acg_launch_fir_generic) STUB(acg_launch_fir_shared) ST
 STUB(acg_launch_fir_fmt) STUB(acg_launch_msk) STUB(acg_launch_msk2) STUB(acg_launch_blk_repair) STUB(acg_launch_sincos_selftest)
 STUB(acg_launch_div2_selftest) STUB(acg_launch_msg_split) STUB(acg_launch_synth_iq) STUB(acg_launch_fill_random) STUB(acg_launch_read_probe)
 STUB(acg_fir_mm_takes) STUB(acg_launch_fir_mm_prep) STUB(acg_launch_fir_mm)
+STUB(acg_fir_mm1_takes) STUB(acg_launch_fir_mm1_prep) STUB(acg_launch_fir_mm1)
+size_t acg_fir_mm1_image_bytes() { return 0; }
 size_t acg_fir_lds_bytes() { return 0; }
 size_t acg_fir_mm_image_bytes() { return 0; }
 

@@ -240,3 +240,104 @@ def test_channel_moved_mid_block_keeps_its_soh_stamp(D, O, S):
     assert int(got[0].end_sample) == 3 * 1024 + (int(f.end_sample) - cut)      # (the destination's own sample index)
     d1.close()
     d2.close()
+
+
+@pytest.mark.parametrize("M,ntaps,nblk", [(200, 200, 2), (160, 160, 1), (192, 192, 1), (200, 192, 1), (160, 37, 1)])
+def test_matrix_pipe_one_stream_per_channel_kernel(D, O, M, ntaps, nblk, tune):
+    """fir_u8_mm1_kernel (ACG_FIR_MM1=1): the exact int8 contraction with ONE channel per stream -- not for its arithmetic rate but
+    to take the down-converter's arithmetic off the vector pipe.  Channels on scrambled streams (an explicit channel -> stream map
+    and the identity), the extremes of the u8 range, a tap table replaced between calls: dm within the 1e-5 bar of the oracle,
+    within 2e-7 of the f64-exact value, and the wave-private vector kernel agrees within the bar."""
+    rng = np.random.default_rng(7000 + M + ntaps)
+    nch = 37
+    nout = nblk * 1024
+    iq = rng.integers(0, 256, size=(nch, nout * M * 2), dtype=np.uint8)
+    iq[0, : 4 * M] = 0
+    iq[1, : 4 * M] = 255
+    iq[2, : 4 * M] = 128
+    taps = np.zeros((nch, ntaps, 2), dtype=np.float32)
+    for c in range(nch):
+        taps[c] = O.rtl_taps(131000000 + 25000 * int(rng.integers(-40, 41)), 131000000, M)[:ntaps]
+    taps[3] *= np.float32(1.0 / 1024)
+    taps[5, ::2] = 0
+
+    def run(smap):
+        dec = D.Decoder(nch, decim=M, ntaps=ntaps, nstreams=nch, max_blocks=nblk)
+        dec.set_taps(taps)
+        if smap is not None:
+            dec.set_channel_streams(smap)
+        dec.in_callback(iq)
+        out = np.stack([dec.dm(c, nout) for c in range(nch)])
+        dec.set_taps(taps[::-1].copy())
+        dec.in_callback(iq)
+        out2 = np.stack([dec.dm(c, nout) for c in range(nch)])
+        dec.close()
+        return out, out2
+
+    perm = rng.permutation(nch)
+    tune("ACG_FIR_MM1", "1")
+    mm_id, mm_id2 = run(None)
+    mm_pm, mm_pm2 = run(perm)
+    tune("ACG_FIR_MM1", "0")
+    va_id, va_id2 = run(None)
+    assert not np.array_equal(mm_id, va_id)
+    worst, worst_v = 0.0, 0.0
+    for c in range(nch):
+        for got, other, row, tp in ((mm_id[c], va_id[c], c, taps[c]), (mm_id2[c], va_id2[c], c, taps[nch - 1 - c]),
+                                    (mm_pm[c], None, perm[c], taps[c]), (mm_pm2[c], None, perm[c], taps[nch - 1 - c])):
+            want = O.fir_u8(iq[row], M, tp, nout=nout, ntaps=ntaps)
+            assert np.all(np.abs(got - want) <= 1e-5 * np.abs(want) + 1e-6), c
+            ex = exact_dm(iq[row], M, tp, nout)
+            err = np.abs(got.astype(np.float64) - ex)
+            assert np.all(err <= 2e-7 * ex + 1e-9), (c, float((err / (ex + 1e-9)).max()))
+            worst = max(worst, float((err / (ex + 1e-3)).max()))
+            if other is not None:
+                assert np.all(np.abs(got - other) <= 1e-5 * np.abs(other) + 1e-6), c
+                worst_v = max(worst_v, float((np.abs(other.astype(np.float64) - ex) / (ex + 1e-3)).max()))
+    assert worst < 2e-7 and worst < worst_v, (worst, worst_v)
+
+
+def test_matrix_pipe_one_stream_per_channel_blocks(D, O, S, tune):
+    """the same kernel end to end: 24 channels of ACARS traffic, eight callbacks at a time and one at a time -- identical blocks
+    and dm for both chunkings, blocks exact given the GPU's dm, dm inside the bar."""
+    tune("ACG_FIR_MM1", "1")
+    rng = np.random.default_rng(4242)
+    M, nch, nblk = 200, 24, 8
+    nout = nblk * 1024
+    offs = [25000.0 * int(k) for k in rng.integers(2, 40, size=nch) * rng.choice([-1, 1], size=nch)]
+    rows, taps = [], []
+    for c in range(nch):
+        a, _ = S.channel_audio(rng, nout, nframes=2, gap=(1500, 2500), text_len=(10, 60))
+        rows.append(S.iq_u8_from_envelopes(np.array([0.5 * (1 + 0.5 * a)]), M, [offs[c]], phases=[float(rng.uniform(0, 6.28))], noise=0.01, rng=rng))
+        taps.append(O.rtl_taps(int(131000000 + offs[c]), 131000000, M))
+    iq = np.stack(rows)
+    taps = np.stack(taps)
+
+    def run(chunks):
+        dec = D.Decoder(nch, decim=M, nstreams=nch, max_blocks=nblk)
+        dec.set_taps(taps)
+        per = nblk // chunks
+        dms = [[] for _ in range(nch)]
+        for k in range(chunks):
+            dec.in_callback(np.ascontiguousarray(iq[:, k * per * 1024 * M * 2:(k + 1) * per * 1024 * M * 2]), nblocks=per)
+            for c in range(nch):
+                dms[c].append(dec.dm(c, per * 1024))
+        got = {}
+        for f in dec.drain_frames():
+            got.setdefault(int(f.chn), []).append(D.frame_tuple(f))
+        dec.close()
+        return got, [np.concatenate(d) for d in dms]
+
+    g1, d1 = run(1)
+    g8, d8 = run(8)            # (one callback per call: launches of 1024 windows still take the matrix path)
+    assert g1 == g8 and all(np.array_equal(a, b) for a, b in zip(d1, d8))
+    total = 0
+    for c in range(nch):
+        want_dm = O.fir_u8(iq[c], M, taps[c])
+        assert np.all(np.abs(d1[c] - want_dm) <= 1e-5 * np.abs(want_dm) + 1e-6)
+        ch = O.Channel(c)
+        ch.demod(d1[c])
+        want = [O.frame_tuple(f) for f in ch.frames]
+        assert g1.get(c, []) == want, c
+        total += len(want)
+    assert total >= nch
