@@ -479,3 +479,97 @@ def test_crc_is_the_xor_of_the_syndromes_of_the_set_bits():
             if (c1 >> bit) & 1:
                 x ^= int(synd[bit])
         assert x == want, n
+
+
+def test_matrix_pipe_digit_arithmetic_is_exact():
+    """fir_mm.hip's arithmetic restated in numpy (integers only where the kernel uses integers): a channel's f32 taps are scaled by
+    2^(30 - e) against the channel's largest tap and rounded to int32, split into four balanced base-256 digits, the samples are
+    u8 - 128; the four digit sums are int32 dot products (what v_mfma_i32_32x32x32_i8 accumulates, |sum| < 2^23), recombined as
+    hi * 65536 + lo in f64 (exact), scaled, the constant (128 - 127.37f)(1 + j) sum w added.  Claims checked: the digits rebuild q
+    exactly and fit int8; no digit sum leaves int32 / the 2^23 bound the recombination relies on; hi, lo fit int32; the result is
+    within 1.2e-10 of full scale of the f64-exact value of rtl.c:349-351's sum -- the tap cut at 2^-31 of the largest tap --
+    before its one rounding to f32, for rtlMult 160 / 192 / 200, a low-pass table and a table 2^-10 below full scale."""
+    rng = np.random.default_rng(31)
+    for M, ntaps, shrink in ((200, 200, 1.0), (160, 160, 1.0), (192, 192, 1.0), (200, 192, 1.0), (160, 37, 1.0), (200, 200, 2.0 ** -10)):
+        n = np.arange(ntaps)
+        ph = -2.0 * np.pi * (25000.0 * int(rng.integers(-40, 41))) / (12500.0 * M) * n
+        win = np.ones(ntaps) if ntaps == M else np.hamming(ntaps) / np.hamming(ntaps).mean() * (M / ntaps)
+        w = np.zeros((M, 2), dtype=np.float32)
+        w[:ntaps, 0] = (np.cos(ph) * win / M / 127.5 * shrink).astype(np.float32)
+        w[:ntaps, 1] = (np.sin(ph) * win / M / 127.5 * shrink).astype(np.float32)
+        mx = float(np.abs(w).max())
+        e = int(np.frexp(np.float32(mx))[1])
+        up = 2.0 ** (30 - e)
+        q = np.rint(w.astype(np.float64) * up).astype(np.int64)
+        assert np.abs(q).max() <= 2 ** 30
+        # balanced digits: the signed low byte, then an exact shift
+        digs, r = [], q.copy()
+        for p in range(4):
+            d = ((r + 128) % 256) - 128
+            digs.append(d)
+            r = (r - d) // 256
+        assert np.all(r == 0) and all(np.abs(d).max() <= 128 and d.min() >= -128 and d.max() <= 127 for d in digs)
+        assert np.array_equal(digs[0] + 256 * digs[1] + 65536 * digs[2] + (1 << 24) * digs[3], q)
+        nwin = 64
+        u = rng.integers(0, 256, size=(nwin, M, 2))
+        u[0], u[1], u[2] = 0, 255, 128
+        s = (u - 128).astype(np.int64)
+        # coefficient of byte b: column "re" (b odd ? -wi : wr), column "im" (b odd ? wr : wi)
+        sums = {}
+        for name, ci, cq, sq in (("re", 0, 1, -1), ("im", 1, 0, 1)):
+            acc = []
+            for p in range(4):
+                a = s[:, :, 0] @ digs[p][:, ci] + sq * (s[:, :, 1] @ digs[p][:, cq])
+                assert np.abs(a).max() < 2 ** 23
+                acc.append(a)
+            lo = acc[1] * 256 + acc[0]
+            hi = acc[3] * 256 + acc[2]
+            assert np.abs(lo).max() < 2 ** 31 and np.abs(hi).max() < 2 ** 31
+            D = hi.astype(np.float64) * 65536.0 + lo.astype(np.float64)
+            assert np.array_equal(D.astype(np.int64), hi * 65536 + lo)              # exact in f64
+            sums[name] = D
+        scale = 2.0 ** (e - 30)
+        c = 128.0 - float(np.float32(127.37))
+        sr, si = int(q[:, 0].sum()), int(q[:, 1].sum())
+        re = sums["re"] * scale + c * (sr - si) * scale
+        im = sums["im"] * scale + c * (sr + si) * scale
+        x = u.astype(np.float64) - float(np.float32(127.37))
+        wd = w.astype(np.float64)
+        ex_re = x[:, :, 0] @ wd[:, 0] - x[:, :, 1] @ wd[:, 1]
+        ex_im = x[:, :, 0] @ wd[:, 1] + x[:, :, 1] @ wd[:, 0]
+        full = 2.0 * M * 128.0 * mx                                                  # the largest the sum can get with these taps
+        assert np.abs(re - ex_re).max() <= 1.2e-10 * full + 1e-18 and np.abs(im - ex_im).max() <= 1.2e-10 * full + 1e-18, (M, ntaps)
+
+
+def test_matrix_pipe_kernels_isa():
+    """fir_mm.hip compiled with the product's flags: no scratch access anywhere; per 32-window tile the shared-stream kernel issues
+    two v_mfma_i32_32x32x32_i8 per 32-byte k-step (2 x 13 at rtlMult 200: one tile's worth, straight-line) and the one-stream kernel
+    one; the one-tile variant stays inside 256 VGPRs (two waves per SIMD), the two-tile variant leaves room for a demodulator wave
+    (<= 512 - 136), the one-stream kernel fits three waves per SIMD."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else shutil.which("hipcc")
+    if not hipcc:
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "acarsdec_amd", "csrc")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "--cuda-device-only", "-std=c++17", "-O3", "-I" + csrc, "-I" + os.path.join(ROOT, "include"),
+                        "-S", "-o", "-", os.path.join(csrc, "fir_mm.hip")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asm = r.stdout
+    assert "scratch_" not in asm
+    vg = {m.group(1): int(m.group(2)) for m in re.finditer(r"\.name:\s+(_Z\d+fir_u8_mm1?_kernel\w+)\n(?:.*\n)*?\s+\.vgpr_count:\s+(\d+)", asm)}
+    assert len(vg) == 9, sorted(vg)
+    for name, n in vg.items():
+        if "mm1_kernel" in name:
+            assert n <= 168, (name, n)
+        elif name.split("kernelILi")[1].split("ELi")[1].startswith("1"):
+            assert n <= 256, (name, n)
+        else:
+            assert 256 < n <= 512 - 136, (name, n)
+    for cpr, ks in ((20, 10), (24, 12), (25, 13)):
+        for name, per in (("_Z16fir_u8_mm_kernelILi%dELi1EE" % cpr, 2 * ks), ("_Z17fir_u8_mm1_kernelILi%dEE" % cpr, ks)):
+            start = next(k for k, l in enumerate(asm.splitlines()) if l.startswith(name) and ": ; @" in l)
+            body = asm.splitlines()[start:]
+            body = body[:next(k for k, l in enumerate(body) if "s_endpgm" in l)]
+            assert sum("v_mfma_i32_32x32x32_i8" in l for l in body) == per, (name, per)
