@@ -88,6 +88,8 @@ SYMBOLS = {
     "acg_set_state": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(ChanState)]),
     "acg_get_state_n": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(ChanState)]),
     "acg_set_state_n": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(ChanState)]),
+    "acg_get_block_text": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "acg_set_block_text": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "acg_read_dm_n": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int]),
     "acg_replay_bits": (C.c_int, [C.c_void_p, BIT_SINK, C.c_void_p]),
     "acg_get_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int),

@@ -1460,6 +1460,25 @@ extern "C" int acg_set_state_n(acg_ctx* ctx, int ch0, int n, const acg_chan_stat
 
 extern "C" int acg_set_state(acg_ctx* ctx, int ch, const acg_chan_state* st) { return acg_set_state_n(ctx, ch, 1, st); }
 
+// blk->txt being assembled (the device keeps 256 bytes per channel, ACG_TXTMAX of them are the reference's msgblk_t::txt)
+extern "C" int acg_get_block_text(acg_ctx* ctx, int ch, unsigned char* txt)
+{
+    if (!ctx || !txt || ch < 0 || ch >= ctx->cfg.nch) return ACG_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    HIPCHK(ctx, hipMemcpy(txt, ctx->d_txt + (size_t)ch * 256, ACG_TXTMAX, hipMemcpyDeviceToHost));
+    return ACG_OK;
+}
+
+extern "C" int acg_set_block_text(acg_ctx* ctx, int ch, const unsigned char* txt)
+{
+    if (!ctx || !txt || ch < 0 || ch >= ctx->cfg.nch) return ACG_EINVAL;
+    HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
+    HIPCHK(ctx, hipDeviceSynchronize());
+    HIPCHK(ctx, hipMemcpy(ctx->d_txt + (size_t)ch * 256, txt, ACG_TXTMAX, hipMemcpyHostToDevice));
+    return ACG_OK;
+}
+
 // ---- lab: the block counters next to their wrap (acarsdec_amd_lab.h) ----------------------------------------------------
 extern "C" int acg_lab_set_block_counter(acg_ctx* ctx, unsigned int value)
 {

@@ -53,7 +53,7 @@ from benchlib.cpu_baseline import cpu_baseline_child, run_cpu_baseline          
 from benchlib.hostfed import run_hostfed                                                 # noqa: E402
 from benchlib.launch import free_port, self_launch                                       # noqa: E402
 from benchlib.line import MULTI_GPU_NOTE, _short, compact_line                           # noqa: E402,F401
-from benchlib.rtl8 import rtl8_cpu_child, run_rtl8                                       # noqa: E402
+from benchlib.rtl8 import rtl8_cpu_child, rtl8_freqs, rtl8_oneline, run_rtl8                # noqa: E402,F401
 from benchlib.traffic import live_traffic                                                # noqa: E402
 
 

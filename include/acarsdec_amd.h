@@ -264,6 +264,12 @@ int  acg_set_state(acg_ctx *ctx, int ch, const acg_chan_state *st);
 int  acg_get_state_n(acg_ctx *ctx, int ch0, int n, acg_chan_state *st);
 int  acg_set_state_n(acg_ctx *ctx, int ch0, int n, const acg_chan_state *st);
 int  acg_read_dm_n(acg_ctx *ctx, int ch0, int n, float *dm, size_t pitch_floats, int nfloats);
+/* blk->txt of the block channel ch is assembling (acars.c:304 appends to it; blk_len bytes of it are meaningful): the part of
+ * channel_t's state that is not a scalar.  A host that moves a channel between slots or contexts in the middle of a block takes
+ * it along with acg_get_state / acg_set_state (the legacy view does not need it: there the text lives in the caller's ch->blk).
+ * txt: ACG_TXTMAX bytes. */
+int  acg_get_block_text(acg_ctx *ctx, int ch, unsigned char *txt);
+int  acg_set_block_text(acg_ctx *ctx, int ch, const unsigned char *txt);
 
 /* Replays the bit records of the last call through a putbit()-shaped sink, channel by channel
  * in channel order: for every bit sink(user, ch, vo, lvl).  The legacy shim's sink performs

@@ -209,11 +209,13 @@ def test_channel_moved_mid_block_keeps_its_soh_stamp(D, O, S):
     """the SOH stamp (where acars.c:290 stamps blk->tv) was not part of acg_chan_state, so a channel moved to another
     slot / context with acg_get_state -> acg_set_state while a block was being assembled delivered that block with a stale stamp.
     acg_chan_state.soh_back carries it as a distance now: cut a stream in the middle of a block, move the channel to slot 1 of a
-    second context whose sample counter stands elsewhere, finish there -- the block's end - SOH distance is the oracle's."""
+    second context whose sample counter stands elsewhere, finish there -- the block's end - SOH distance is the oracle's.  (The
+    text assembled so far travels with acg_get_block_text / acg_set_block_text: it is the one part of the block state that is not
+    in acg_chan_state.)"""
     from acarsdec_amd import _capi as K
     rng = np.random.default_rng(606)
-    n = 8 * 1024
-    a, _ = S.channel_audio(rng, n, nframes=1, gap=(1500, 1600), text_len=(150, 160))
+    n = 12 * 1024
+    a, _ = S.channel_audio(rng, n, nframes=1, gap=(1500, 1600), text_len=(100, 110))
     x = S.envelope(a, noise=0.003, rng=rng).astype(np.float32)
     ch = O.Channel(0)
     ch.demod(x)
@@ -221,16 +223,20 @@ def test_channel_moved_mid_block_keeps_its_soh_stamp(D, O, S):
     f = ch.frames[0]
     cut = (int(f.soh_sample) + int(f.end_sample)) // 2 // 1024 * 1024          # a call boundary strictly inside the block
     assert int(f.soh_sample) < cut < int(f.end_sample)
-    d1 = D.Decoder(1, decim=8, ntaps=8, nstreams=1, max_blocks=8)
+    d1 = D.Decoder(1, decim=8, ntaps=8, nstreams=1, max_blocks=12)
     d1.demod_msk(x[:cut].reshape(1, -1))
     s = K.ChanState()
     d1._chk(d1.L.acg_get_state(d1.ctx, 0, C.byref(s)))
-    assert s.Acarsstate in (3, 4, 5) and s.soh_back == cut - int(f.soh_sample)
+    txt = (C.c_ubyte * 250)()
+    d1._chk(d1.L.acg_get_block_text(d1.ctx, 0, txt))           # blk->txt so far: the part of the state that is not a scalar
+    assert s.Acarsstate in (3, 4, 5) and s.soh_back == cut - int(f.soh_sample) and 0 < s.blk_len < int(f.len)
+    assert bytes(txt[: s.blk_len]) != bytes(s.blk_len)
     assert d1.drain_frames() == []
-    d2 = D.Decoder(2, decim=8, ntaps=8, nstreams=2, max_blocks=8)
+    d2 = D.Decoder(2, decim=8, ntaps=8, nstreams=2, max_blocks=12)
     skew = np.full((2, 3 * 1024), 0.5, dtype=np.float32)                       # the destination has consumed 3072 samples already
     d2.demod_msk(skew)
     d2._chk(d2.L.acg_set_state(d2.ctx, 1, C.byref(s)))
+    d2._chk(d2.L.acg_set_block_text(d2.ctx, 1, txt))
     rest = np.full((2, n - cut), 0.5, dtype=np.float32)
     rest[1] = x[cut:]
     d2.demod_msk(rest)
