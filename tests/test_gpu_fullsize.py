@@ -195,3 +195,41 @@ def test_stream_permutation_permutes_outputs(env):
         outs.append(digest(dec, nch, 1024))
         dec.close()
     assert [outs[0][p] for p in perm] == outs[1]
+
+
+def test_shared_stream_north_star_width_is_group_independent(env):
+    """rtl.c's own shape at the north-star width: 16 384 channels on 2 048 dongle streams (8 per stream) through fir_u8_mm_kernel.
+    The kernel's sums are integer-exact, so a channel's dm cannot depend on which channels share its group, on the launch shape or
+    on the wave that computed it: 48 channels re-run as 24 two-channel dongles (another context, groups of 2 instead of 8, a
+    144-run launch instead of 8 192) give the SAME BITS; the same channels sit inside the 1e-5 bar of the oracle; and replicas
+    (channels of one dongle given the same tap table) agree bit for bit across the whole width."""
+    torch, D, S, K, O = env
+    nstreams, kps, M = 2048, 8, 200
+    nch = nstreams * kps
+    rng = np.random.default_rng(2048)
+    iq = rng.integers(0, 256, size=(nstreams, 1024 * M * 2), dtype=np.uint8)
+    base = np.stack([D.rtl_taps(131000000 + 25000 * int(k), 131000000, M) for k in rng.integers(-44, 45, size=64)])
+    pick = (np.arange(nch) * 7 + np.arange(nch) // kps) % 64
+    pick[1::kps] = pick[0::kps]                                  # channel 1 of every dongle repeats channel 0's table: replicas
+    taps = base[pick]
+    dec = D.Decoder(nch, decim=M, nstreams=nstreams, max_blocks=1, bitlog=False)
+    dec.set_taps(taps)
+    dec.set_channel_streams(np.arange(nch) // kps)
+    dec.in_callback(iq)
+    streams = [int(s) for s in rng.choice(nstreams, size=24, replace=False)]
+    chans = [(s * kps + int(rng.integers(2, kps)), s * kps + 1) for s in streams]            # one ordinary channel + the replica
+    full = {c: dec.dm(c, 1024) for pair in chans for c in pair}
+    for s in streams:
+        assert np.array_equal(dec.dm(s * kps, 1024), full[s * kps + 1]), s                   # replicas inside the full launch
+    dec.close()
+    sub = D.Decoder(48, decim=M, nstreams=24, max_blocks=1, bitlog=False)
+    sub.set_taps(np.stack([taps[c] for pair in chans for c in pair]))
+    sub.set_channel_streams(np.arange(48) // 2)
+    sub.in_callback(np.ascontiguousarray(iq[streams]))
+    for i, pair in enumerate(chans):
+        for j, c in enumerate(pair):
+            got = sub.dm(2 * i + j, 1024)
+            assert np.array_equal(got, full[c]), (c, "group composition or launch shape changed the bits")
+            want = O.fir_u8(iq[c // kps], M, taps[c])
+            assert np.all(np.abs(got - want) <= 1e-5 * np.abs(want) + 1e-6), c
+    sub.close()
