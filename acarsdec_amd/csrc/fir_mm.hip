@@ -560,7 +560,10 @@ int launch_mm1(const FirArgs* a, hipStream_t stream)
     MmDev* d = nullptr;
     if (int e = mm_device(&d)) return e;
     const int ncu = a->ncu > 0 ? a->ncu : d->num_cu;
-    int per_cu = a->shares_cus ? 7 : 8;                              // (13.2 KiB of LDS each; the demodulator's 62 KiB fit beside seven)
+    // 13.2 KiB of LDS and 160 VGPRs per wave: twelve fit a CU that the demodulator does not share (<= 2048 channels: measured
+    // 8 / 10 / 12 waves 2.30 / 2.33 / 2.46 M channel*Msps at 2048 channels); beside the demodulator's workgroups (15.4 KiB each: two
+    // per CU up to 4096 channels, four from 8192) nine or seven (profiles/r06_mm1_waves_ab_*.json)
+    int per_cu = !a->shares_cus ? 12 : a->nch >= 8192 ? 7 : 9;
     per_cu = acg_tune_get("ACG_FIR_MM1_WAVES", per_cu);
     if (per_cu < 1 || per_cu > 12) per_cu = 8;
     const unsigned int nwaves = (unsigned int)ncu * (unsigned int)per_cu;
