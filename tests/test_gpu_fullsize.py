@@ -90,8 +90,9 @@ def test_replicated_channels_agree_and_match_oracle(env, nch, M, ntaps, nblk):
     dec.close()
 
 
-@pytest.mark.parametrize("nch,ntaps,exact", [(1024, 200, False), (2048, 200, False), (4096, 192, False), (16384, 200, False), (1024, 200, True)])
-def test_default_kernels_one_stream_per_channel_at_baseline_widths(env, nch, ntaps, exact):
+@pytest.mark.parametrize("nch,M,ntaps,exact", [(1024, 200, 200, False), (2048, 200, 200, False), (4096, 200, 192, False), (16384, 200, 200, False),
+                                               (1024, 200, 200, True), (4096, 160, 160, False), (4096, 192, 192, False)])
+def test_default_kernels_one_stream_per_channel_at_baseline_widths(env, nch, M, ntaps, exact):
     """the DEFAULT pipeline -- nstreams == nch, so fir_u8_direct_kernel (wave-private, dispensed runs) with
     the CU partition up to 2048 channels, the two-stage stream pipeline above -- at BASELINE's widths: configs[2] (1024),
     configs[3]'s per-GPU share (2048), configs[4] (4096 channels, 192 taps) and the north-star regime (16 384).  The 64
@@ -99,9 +100,10 @@ def test_default_kernels_one_stream_per_channel_at_baseline_widths(env, nch, nta
     oracle still covers 64 and the replicas must equal their originals: dm bit for bit, every soft bit, every block.  Originals:
     dm within 1e-5 of the oracle's down-converter, blocks bit-exact against the oracle's demodulator fed with the GPU's dm, end
     to end at most one razor-edge block apart; with ACG_F_EXACT_FIR (the exact-order kernel at full width) dm is bit-identical
-    to the oracle's and the blocks are identical end to end."""
+    to the oracle's and the blocks are identical end to end.  (Round 6: rtlMult 160 -- the reference's default, acarsdec.c:57 -- and
+    192 at 4096 channels: fir_u8_direct_kernel<20> / <24> at full width.)"""
     torch, D, S, K, O = env
-    M, nblk, nsrc = 200, 2, 64
+    nblk, nsrc = 2, 64
     iq, offs = make_streams(S, nsrc, nblk, M, 777 + nch + ntaps)
     win = np.ones(ntaps) if ntaps == M else np.hamming(ntaps) / np.hamming(ntaps).mean() * (M / ntaps)
     base = [(D.rtl_taps(131000000 + int(o), 131000000, M)[:ntaps] * win[:, None]).astype(np.float32) for o in offs]
