@@ -30,7 +30,8 @@
 // Memory path: the wave-private streaming pattern of fir.hip -- 1 KiB coalesced non-temporal wave-loads of a tile (32 windows,
 // contiguous in HBM) into registers while the previous tile is multiplied, then one pass of ds_write_b128 into the wave's LDS
 // tile (row stride an odd number of 16-byte slots: the window-per-lane reads are bank-conflict free) -- no barrier, no other
-// wave involved.  8 waves per CU, 13.2 KiB of LDS and 10-12.5 KiB of loads in flight each.
+// wave involved.  8 waves per CU with 13.2 KiB of LDS and 10-12.5 KiB of loads in flight each, or (beside the demodulator) 4 waves
+// per CU with two tiles = 20-25 KiB in flight each.
 #include <hip/hip_runtime.h>
 #include <map>
 #include <mutex>
@@ -138,8 +139,11 @@ __device__ __forceinline__ float mm_cabs(float re, float im)
 // out re-arms both, no memset between launches).
 // STAGES = tiles in flight per wave.  1: two waves per SIMD (<= 256 VGPRs each), the next tile's loads wait in 52 registers while
 // this one is multiplied.  2: ONE wave per SIMD with two tiles (25 KiB) in flight in 104 registers -- the same bytes in flight per
-// CU, and a SIMD's register file then still holds a demodulator wave (136 VGPRs) beside it: with two 232-register waves per SIMD
-// the demodulator's workgroups wait for a SIMD to drain, and at 8 channels per stream the demodulator is the stage that sets the step.
+// CU, and a SIMD's register file then still holds a demodulator wave (136 VGPRs) beside it (two 232-register waves do not leave room
+// for one).  Measured in one process at 16 384 channels on 2 048 streams: 12.24 M channel*Msps against 12.12 M (+1 %): taken beside the
+// demodulator, but register co-residency is not what bounds this shape -- the vector pipe is: the demodulator needs ~75 % of a SIMD's
+// issue slots and this kernel's epilogue (the exact recombination and |D| of 256 outputs per tile: ~200 instructions, 120 of them
+// f64) ~20 % at this rate (profiles/LEDGER.md, round 6).
 template <int CPR, int STAGES>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(STAGES == 1 ? 2 : 1, STAGES == 1 ? 2 : 1)))
 void fir_u8_mm_kernel(const FirArgs a, const uint8_t* __restrict__ iq_base, const u4m_t* __restrict__ img,
