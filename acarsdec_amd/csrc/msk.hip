@@ -222,6 +222,17 @@ __global__ __launch_bounds__(64 * WPG) MSK_KERNEL_ATTR void msk_demod_kernel(con
 #ifndef ACG_MSK_AB_UNCOUNTED
         constexpr int PERIODS = (WB - 8) / 6;          // 9 (WB 64), 4 (WB 32)
         static_assert(6 * PERIODS <= WB - 1 && 12 * PERIODS <= 2 * WB - 1, "the counted periods must stay inside the dm window");
+        // Round 6: the counted loop is UNROLLED (all 9 periods straight-line, ~6 400 instructions, no spill: 106 VGPRs): no loop
+        // counter / branch between periods and the tail of a period scheduled against the head of the next.  Same box, alone:
+        // 0.724 -> 0.720 (3 x) -> 0.714 us per bit at 1024 channels, 0.730 -> 0.717 at 2048, 0.990 -> 0.951 at 16 384 (4 lanes per
+        // channel), headline 1.426 -> 1.441 -> 1.448 M channel*Msps (profiles/r06_msk_unroll_ab.txt).  ACG_MSK_AB_UNROLL=n: A/B builds.
+#define ACG_MSK_PRAGMA_(x) _Pragma(#x)
+#define ACG_MSK_PRAGMA(x) ACG_MSK_PRAGMA_(x)
+#ifdef ACG_MSK_AB_UNROLL
+        ACG_MSK_PRAGMA(unroll ACG_MSK_AB_UNROLL)
+#else
+        ACG_MSK_PRAGMA(unroll)
+#endif
         for (int period_ = 0; period_ < PERIODS; ++period_) {
 #endif
 #ifdef ACG_MSK_STAMP

@@ -32,7 +32,7 @@ for spec in sys.argv[1:]:
         open(src, "w").write(subprocess.run(["git", "show", "%s:acarsdec_amd/csrc/msk.hip" % rev], cwd=ROOT, capture_output=True, text=True, check=True).stdout)
     obj = os.path.join(out, "msk_%s.o" % name)
     B._run([B.hipcc(), "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-I" + B.INC, "-I" + B.CSRC] + base + flags + ["-c", src, "-o", obj])
-    objs = [os.path.join(B.OBJDIR, n) for n in ("fir.hip.o", "synth.hip.o", "blk.hip.o", "acg_api.cpp.o", "host_setup.o")] + [obj]
+    objs = [os.path.join(B.OBJDIR, n) for n in ("fir.hip.o", "fir_mm.hip.o", "synth.hip.o", "blk.hip.o", "acg_api.cpp.o", "host_setup.o")] + [obj]
     lib = os.path.join(out, "lib%s.so" % name)
     B._run([B.hipcc(), "--offload-arch=gfx950", "-shared", "-o", lib] + objs + ["-ldl", "-lm"])
     print(lib)

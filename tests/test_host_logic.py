@@ -84,7 +84,7 @@ def test_tuning_switches_go_through_one_table_not_the_environment():
     for name in ("fir_u8_direct_kernel", "fir_u8_persist_kernel", "fir_u8_shared_kernel", "fir_u8_mm_kernel", "fir_u8_generic_kernel", "fir_fmt_direct_kernel",
                  "msk_demod_kernel", "blk_repair_kernel", "msg_split_kernel"):
         assert name in sym, name
-    assert os.path.getsize(K.LIB_PATH) < 0.75 * os.path.getsize(K.LAB_PATH)
+    assert os.path.getsize(K.LIB_PATH) < 0.8 * os.path.getsize(K.LAB_PATH)      # (round 6: the unrolled demodulator is in both)
 
 
 def test_device_sincos_model_keeps_the_mixer_products_of_glibc_cexp(tmp_path):
