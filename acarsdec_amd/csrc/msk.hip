@@ -413,7 +413,16 @@ __global__ __launch_bounds__(64 * WPG) MSK_KERNEL_ATTR void msk_demod_kernel(con
         __builtin_amdgcn_wave_barrier();
         STAMP(2);                                                          // B
         // ---- C: bit decision (replicated; side effects by the group leader only)
+#ifdef ACG_MSK_AB_FLAT
+        // A/B build: the bit-decision part WITHOUT a branch around it -- every pass runs it and a pass without a bit (rare: the
+        // one-sample passes at a call's tail or out of lock) masks its side effects -- so that the pass is one basic block and the
+        // scheduler may run the decision / framing of this period (off the chain that feeds the next one) beside what follows
+        const bool FB = fired;
+        {
+#else
+        constexpr bool FB = true;
         if (MSK_LIKELY(fired)) {
+#endif
 #ifdef ACG_MSK_STAMP
             ++stamp_bits;
 #endif
@@ -448,8 +457,8 @@ __global__ __launch_bounds__(64 * WPG) MSK_KERNEL_ATTR void msk_demod_kernel(con
                 vr = (float)qr;
                 vi = (float)qi;
             }
-            L.lvlsum += (double)(lvl * lvl / 4);
-            L.bitcount++;
+            L.lvlsum += FB ? (double)(lvl * lvl / 4) : 0.0;                // (+ 0.0 is exact)
+            L.bitcount += FB ? 1 : 0;
 #ifdef ACG_MSK_STAMP
             asm volatile("" : "+v"(vr), "+v"(vi));
 #endif
@@ -463,19 +472,22 @@ __global__ __launch_bounds__(64 * WPG) MSK_KERNEL_ATTR void msk_demod_kernel(con
             const unsigned int flip = ((vo >= 0) == odd) ? 0x80000000u : 0u;
             const double dphi = (double)__uint_as_float(__float_as_uint(ot) ^ flip);
             const float sv = __uint_as_float(__float_as_uint(vo) ^ ((L.S & 2u) << 30));   // msk.c:122-126
-            bits[nb < bit_cap ? nb : bit_cap - 1] = make_float2(sv, lvl);                  // (no bit log: one scratch record in the text buffer's tail)
-            ++nb;
+            bits[(FB && nb < bit_cap) ? nb : bit_cap - 1] = make_float2(sv, lvl);          // (no bit log: one scratch record in the text buffer's tail)
+            nb += FB ? 1 : 0;
             // putbit, msk.c:53-63
-            L.outbits = (L.outbits >> 1) & 0x7fu;
-            if (sv > 0) L.outbits |= 0x80u;
-            L.nbits--;
+            {
+                unsigned int ob = (L.outbits >> 1) & 0x7fu;
+                if (sv > 0) ob |= 0x80u;
+                L.outbits = FB ? ob : L.outbits;
+            }
+            L.nbits -= FB ? 1 : 0;
             {
                 // decodeAcars (acars.c:246-375) runs when nbits reaches 0.  Two cases cover nearly every call and are
                 // taken without a branch: hunting for sync with no SYN in sight (acars.c:252-265, every bit of an idle
                 // channel) and a plain text byte -- good parity, no terminator, room left (acars.c:303-341, every 8th
                 // bit of a channel inside a block).  Everything else (sync, SOH, parity errors, ETX/ETB/DLE, CRC
                 // bytes, resets: a few per block) goes through the full state machine.
-                const bool ev = L.nbits <= 0;
+                const bool ev = FB && L.nbits <= 0;
                 const unsigned int r = L.outbits & 0xffu;
                 const bool syn = (r == SYN) | (r == (0xffu & ~SYN));
                 const bool hunt = ev & (L.astate == WSYN) & !syn;
@@ -486,13 +498,16 @@ __global__ __launch_bounds__(64 * WPG) MSK_KERNEL_ATTR void msk_demod_kernel(con
                 L.nbits = hunt ? 1 : (plain ? 8 : L.nbits);
                 if (MSK_UNLIKELY(ev & !hunt & !plain)) decode_acars(L, a, ch, txt, samp0 + n - 1, leader, &st->soh32);
             }
-            L.nbit_total++;
-            L.S++;
+            L.nbit_total += FB ? 1 : 0;
+            L.S += FB ? 1u : 0u;
             STAMP(5);                                                      // C3: decision, bit record, putbit, framing FSM
             // PLL filter, msk.c:130 (float constants promoted to double)
             // (forming the products ahead -- 0.52 * MskDf at the top of the pass, the dphi term before decodeAcars -- and
             //  1 / s for the tap phase as soon as s exists: no measurable difference, the chain is bound by issue, not latency)
-            L.df = (double)0.52f * L.df + (1.0 - (double)0.52f) * (double)38e-4f * dphi;
+            {
+                const double df_n = (double)0.52f * L.df + (1.0 - (double)0.52f) * (double)38e-4f * dphi;
+                L.df = FB ? df_n : L.df;
+            }
 #ifdef ACG_MSK_STAMP
             asm volatile("" : "+v"(L.df));
 #endif
