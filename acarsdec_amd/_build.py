@@ -51,7 +51,7 @@ MSK_FLAGS = ["-O3", "-ffp-contract=off", "-mllvm", "-amdgpu-sched-strategy=max-i
              "-mllvm", "-disable-branch-fold", "-mllvm", "-disable-tail-duplicate",
              "-mllvm", "-structurizecfg-skip-uniform-regions", "-mllvm", "-phi-node-folding-threshold=4"]
 # unit -> (flags, in the product library?).  msk2.hip (the two-wave demodulator: bit-identical and slower) is lab only.
-UNITS = [("fir.hip", ["-O3"], True), ("fir_mm.hip", ["-O3"], True), ("msk.hip", MSK_FLAGS, True), ("msk2.hip", MSK_FLAGS, False), ("synth.hip", ["-O3"], True),
+UNITS = [("fir.hip", ["-O3"], True), ("fir_mm.hip", ["-O3"], True), ("msk.hip", MSK_FLAGS, True), ("msk_lean.hip", MSK_FLAGS, True), ("msk2.hip", MSK_FLAGS, False), ("synth.hip", ["-O3"], True),
          ("blk.hip", ["-O3"], True), ("acg_api.cpp", ["-O2"], True)]
 # which units see which define (the others are compiled once and shared between the libraries)
 SEES = {"-DACG_LAB": ("fir.hip", "msk2.hip", "acg_api.cpp"), "-DACG_MSK_STAMP": ("msk.hip", "msk2.hip", "acg_api.cpp"),

@@ -168,6 +168,7 @@ int acg_launch_fir_mm1(const FirArgs* a, void* stream);
 int acg_launch_fir_fmt(const FirArgs* a, int fmt, void* stream);     // fmt: 1 CS16, 2 split int16 planes, 3 real f32
 size_t acg_fir_lds_bytes(const FirArgs* a);
 int acg_launch_msk(const MskArgs* a, int lanes_per_channel, void* stream);
+int acg_launch_msk_lean(const MskArgs* a, int lanes_per_channel, int waves_per_group, unsigned int grid, void* stream);   // msk_lean.hip: launches without a bit log
 int acg_launch_msk2(const MskArgs* a, int pairs_per_group, void* stream);     // msk2.hip: the stream split over two waves (8 lanes per channel)
 int acg_launch_blk_repair(AcgFrameRec* frames, unsigned int cap, const unsigned int* upto, unsigned int* done_upto,
                           unsigned int* done_ctr, const unsigned short* synd, const unsigned short* crctab, int nch, void* stream);

@@ -608,6 +608,13 @@ extern "C" int acg_launch_msk(const MskArgs* a, int lpc, void* stream)
     const dim3 blk(64 * wpg);
     hipStream_t s = (hipStream_t)stream;
     const bool vec = ((uintptr_t)a->dm % 16 == 0) && (a->dm_pitch % 4 == 0) && (a->len % 32 == 0) && !acg_tune_has("ACG_MSK_NOVEC") && !a->precise_mixer;
+    // Round 6: the in_callback-shaped launches go to msk_lean.hip (the framing state machine off the per-bit path: same bits,
+    // blocks and state); ACG_MSK_NOLEAN=1 keeps this file's kernel for same-process A/B.  The stamp build measures this file's kernel.
+#ifndef ACG_MSK_STAMP
+    // (8 lanes per channel: 0.716 -> 0.643 us per bit alone, the headline 1.451 -> 1.574 M channel*Msps; 4 lanes per channel -- 16 channels
+    //  share a wave's segment -- measured no gain with the bit log on and -5.6 % beside the matrix-pipe down-converter: ACG_MSK_LEAN4=1)
+    if (vec && (lpc == 8 || (lpc == 4 && acg_tune_has("ACG_MSK_LEAN4"))) && !acg_tune_has("ACG_MSK_NOLEAN")) return acg_launch_msk_lean(a, lpc, wpg, grid, stream);
+#endif
     // (the verification mode is instantiated for the scalar-refill shape only: six more kernels, not twelve)
 #define MSK_LAUNCH(L_, W_) do { if (a->precise_mixer) hipLaunchKernelGGL((msk_demod_kernel<L_, W_, false, true>), dim3(grid), blk, 0, s, *a); \
                                 else if (vec) hipLaunchKernelGGL((msk_demod_kernel<L_, W_, true>), dim3(grid), blk, 0, s, *a); \

@@ -64,7 +64,8 @@ def test_tuning_switches_go_through_one_table_not_the_environment():
     assert L.acg_is_lab_build() == 0 and K.load(lab=True).acg_is_lab_build() == 1
     assert L.acg_tune(b"ACG_FIR_VARIANT", b"3") == K.OK and L.acg_tune(b"ACG_FIR_VARIANT", None) == K.OK
     assert L.acg_tune(b"LD_PRELOAD", b"x") == K.EINVAL and L.acg_tune(None, b"1") == K.EINVAL
-    src = open(os.path.join(ROOT, "acarsdec_amd", "csrc", "fir.hip")).read() + open(os.path.join(ROOT, "acarsdec_amd", "csrc", "msk.hip")).read()
+    src = open(os.path.join(ROOT, "acarsdec_amd", "csrc", "fir.hip")).read() + open(os.path.join(ROOT, "acarsdec_amd", "csrc", "msk.hip")).read() + \
+        open(os.path.join(ROOT, "acarsdec_amd", "csrc", "msk_lean.hip")).read()
     assert "getenv(" not in src                                   # no launch path reads the environment
     code = ("import os, sys; sys.path.insert(0, %r); os.environ['ACG_FIR_DEBUG_SHAPE'] = '1'\n"
             "from acarsdec_amd import _capi as K; K.tune('ACG_MSK_LPC', 4, lab=%%s)" % ROOT)
@@ -82,7 +83,7 @@ def test_tuning_switches_go_through_one_table_not_the_environment():
     for name in ("fir_u8_coltap_kernel", "fir_u8_mfma_kernel", "fir_u8_dma_kernel", "fir_u8_tile_kernel", "msk_demod2_kernel"):
         assert name not in sym and name in lab, name
     for name in ("fir_u8_direct_kernel", "fir_u8_persist_kernel", "fir_u8_shared_kernel", "fir_u8_mm_kernel", "fir_u8_generic_kernel", "fir_fmt_direct_kernel",
-                 "msk_demod_kernel", "blk_repair_kernel", "msg_split_kernel"):
+                 "msk_demod_kernel", "msk_lean_kernel", "blk_repair_kernel", "msg_split_kernel"):
         assert name in sym, name
     assert os.path.getsize(K.LIB_PATH) < 0.8 * os.path.getsize(K.LAB_PATH)      # (round 6: the unrolled demodulator is in both)
 
