@@ -320,8 +320,10 @@ def run_case(J, name, case, args, steps, warmup, headline):
     k5 = next((i for i in range(1, len(marks)) if marks[i] - marks[0] >= 5.0), len(marks) - 1)
     burst5s = world * samples_per_step * k5 / (marks[k5] - marks[0]) / 1e6 if (sustain_s > 5.0 and k5 < len(marks) - 1) else None
     tele3 = [T["tele0"], tele_mid, T["tele1"]]
-    # the demodulator's own bound (it sets the step of the <= 2048-channel cases): a serial recurrence per channel, ~325
-    # instructions per bit period issued from one wave per SIMD at >= 4 cycles each (profiles/r05_probe_msk_phase_stamps.txt)
+    # the demodulator's own bound (it sets the step of the <= 2048-channel cases): a serial recurrence per channel whose wave
+    # issues ~275 instructions per bit period (msk_lean.hip, 8 lanes per channel: 261 in a period inside a segment + the segment's
+    # set-up and framing spread over its 8 bits; counted in the product's ISA, tests/test_host_logic.py) or ~325 (msk.hip, the other
+    # launch shapes) from one wave per SIMD at >= 4 cycles each (profiles/r05_probe_msk_phase_stamps.txt)
     msk_launches = max(1, warm["msk_launches"]) if "msk_launches" in warm else None
     roofline_msk = None
     if msk_launches and clk_mid:
@@ -333,11 +335,15 @@ def run_case(J, name, case, args, steps, warmup, headline):
         msk_cus = min(80, (5 * max(1, int((msk_waves + 3) // 4)) + 1) // 2) if nch <= 2048 else 256
         waves_per_simd = max(1.0, msk_waves / (4.0 * msk_cus))
         cyc = us_bit * clk_mid / waves_per_simd
-        roofline_msk = {"bound": "issue", "kernel": "msk_demod_kernel", "us_per_bit": round(us_bit, 4), "waves_per_simd": round(waves_per_simd, 2),
-                        "cycles_per_bit_per_wave": round(cyc, 0), "instr_per_bit": 325, "floor_cycles_per_bit": 1300,
-                        "frac": round(1300.0 / cyc, 3) if cyc > 0 else None,
-                        "note": "launch time / bit periods per channel, at the shader clock read mid-run; floor = 325 instructions x 4 issue cycles "
-                                "(one wave per SIMD cannot issue faster); the arithmetic is the reference's operation for operation"}
+        # (mirrors acg_launch_msk: in_callback-shaped launches with 8 lanes per channel take msk_lean.hip)
+        lean = dec_lpc == 8 and (cb * 1024) % 32 == 0 and not os.environ.get("ACG_MSK_NOLEAN")
+        ipb = 275 if lean else 325
+        roofline_msk = {"bound": "issue", "kernel": "msk_lean_kernel" if lean else "msk_demod_kernel", "us_per_bit": round(us_bit, 4),
+                        "waves_per_simd": round(waves_per_simd, 2),
+                        "cycles_per_bit_per_wave": round(cyc, 0), "instr_per_bit": ipb, "floor_cycles_per_bit": 4 * ipb,
+                        "frac": round(4.0 * ipb / cyc, 3) if cyc > 0 else None,
+                        "note": "launch time / bit periods per channel, at the shader clock read mid-run; floor = %d instructions x 4 issue cycles "
+                                "(one wave per SIMD cannot issue faster); the arithmetic is the reference's operation for operation" % ipb}
     out = {
         "value": round(value, 1),
         "ms_per_step": round(dt / steps * 1e3, 4),
@@ -383,7 +389,7 @@ def run_case(J, name, case, args, steps, warmup, headline):
                      "frac_of_measured_copy_ceiling_6290": round(achieved / COPY_CEILING_GBS, 4)},
         "whole_job_frac_of_hbm": round(whole / HBM_PEAK_GBS, 4),
         "whole_job_GBs_per_gpu": round(whole, 1),
-        "time_dominant_kernel": "msk_demod_kernel" if msk_ms_step > fir_ms_step else kname,
+        "time_dominant_kernel": (roofline_msk or {}).get("kernel", "msk_demod_kernel") if msk_ms_step > fir_ms_step else kname,
         "kernels": {"fir_ms_per_step": round(fir_ms_step, 4), "msk_ms_per_step": round(msk_ms_step, 4),
                     "note": "per-step sums of event-timed launches; the stages overlap (down-converter of call/chunk i+1 beside the "
                             "demodulator of i); the demodulator figure is taken during warm-up (its events are off in the timed region)"},

@@ -85,7 +85,7 @@ def test_tuning_switches_go_through_one_table_not_the_environment():
     for name in ("fir_u8_direct_kernel", "fir_u8_persist_kernel", "fir_u8_shared_kernel", "fir_u8_mm_kernel", "fir_u8_generic_kernel", "fir_fmt_direct_kernel",
                  "msk_demod_kernel", "msk_lean_kernel", "blk_repair_kernel", "msg_split_kernel"):
         assert name in sym, name
-    assert os.path.getsize(K.LIB_PATH) < 0.8 * os.path.getsize(K.LAB_PATH)      # (round 6: the unrolled demodulator is in both)
+    assert os.path.getsize(K.LIB_PATH) < 0.82 * os.path.getsize(K.LAB_PATH)     # (round 6: the unrolled demodulator and msk_lean.hip are in both)
 
 
 def test_device_sincos_model_keeps_the_mixer_products_of_glibc_cexp(tmp_path):
@@ -269,6 +269,7 @@ def test_build_recipe_keeps_the_exactness_critical_flags():
     src = open(os.path.join(ROOT, "acarsdec_amd", "_build.py")).read()
     unit = src[src.index('MSK_FLAGS = ['):src.index('UNITS = [')]
     assert '"-ffp-contract=off"' in unit and '("msk.hip", MSK_FLAGS, True)' in src and '("msk2.hip", MSK_FLAGS, False)' in src
+    assert '("msk_lean.hip", MSK_FLAGS, True)' in src
     assert "fast-math" not in src and "-Ofast" not in src and "-ffast" not in src
     assert re.search(r'"gcc", "-O2", "-ffp-contract=off"', src)
     allowed = {"-amdgpu-sched-strategy=max-ilp", "-disable-machine-sink", "-disable-branch-fold", "-disable-tail-duplicate",
@@ -363,6 +364,34 @@ def test_demodulator_loop_keeps_its_state_in_registers():
     assert len(kernels) >= 18, sorted(kernels)
     for name, body in kernels.items():
         assert not any("scratch_" in l for l in body), name
+    for m in re.finditer(r"\.amdhsa_private_segment_fixed_size (\d+)", r.stdout):
+        assert int(m.group(1)) == 0
+    # msk_lean.hip (round 6: the framing state machine off the per-bit path): no scratch either; a period inside a segment keeps
+    # exactly the two shift-register updates (v_addc_co_u32) of framing work, eight periods per segment; and what a wave issues per
+    # bit period there -- the figure bench.py's roofline_msk quotes -- stays where it was counted
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "--cuda-device-only", "-std=c++17", "-I" + csrc, "-I" + os.path.join(ROOT, "include")] +
+                       B.MSK_FLAGS + ["-S", "-o", "-", os.path.join(csrc, "msk_lean.hip")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    kernels, cur = {}, None
+    for line in r.stdout.splitlines():
+        m = re.match(r"^(_Z15msk_lean_kernelILi\d+ELi\d+ELb[01]EEv7MskArgs):", line)
+        if m:
+            cur = m.group(1)
+            kernels[cur] = []
+        elif line.startswith(".Lfunc_end"):
+            cur = None
+        elif cur and not line.lstrip().startswith(";") and line.strip():
+            kernels[cur].append(line)
+    assert len(kernels) == 8, sorted(kernels)
+    for name, body in kernels.items():
+        assert not any("scratch_" in l for l in body), name
+        marks = [i for i, l in enumerate(body) if "v_addc_co_u32_e64" in l]
+        assert len(marks) == 16, (name, len(marks))
+        if "ILi8ELi1ELb1E" in name:
+            # between the same point of two consecutive periods, everything the compiler laid out there (the one-sample path of
+            # a period out of lock and the copies on the way out of the segment included): the instructions of one period
+            gaps = sorted(marks[i + 2] - marks[i] for i in range(0, 14, 2))
+            assert 250 <= gaps[0] <= gaps[3] <= 300, gaps
     for m in re.finditer(r"\.amdhsa_private_segment_fixed_size (\d+)", r.stdout):
         assert int(m.group(1)) == 0
 
