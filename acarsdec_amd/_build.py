@@ -50,8 +50,12 @@ LIB_LAB = os.path.join(LIBDIR, "libacarsdec_amd_lab.so")
 MSK_FLAGS = ["-O3", "-ffp-contract=off", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-disable-machine-sink",
              "-mllvm", "-disable-branch-fold", "-mllvm", "-disable-tail-duplicate",
              "-mllvm", "-structurizecfg-skip-uniform-regions", "-mllvm", "-phi-node-folding-threshold=4"]
+# msk_lean.hip (round 6): the same recipe with machine sinking left on (A/B builds on one box, every switch dropped in turn:
+# -0.7 % per bit without -disable-machine-sink, +4 % without max-ilp, +2 % without the structurizer switch, the others nil;
+# profiles/r06_msk_lean_builds_ab.txt)
+MSK_LEAN_FLAGS = [f for i, f in enumerate(MSK_FLAGS) if not (f == "-disable-machine-sink" or (f == "-mllvm" and MSK_FLAGS[i + 1] == "-disable-machine-sink"))]
 # unit -> (flags, in the product library?).  msk2.hip (the two-wave demodulator: bit-identical and slower) is lab only.
-UNITS = [("fir.hip", ["-O3"], True), ("fir_mm.hip", ["-O3"], True), ("msk.hip", MSK_FLAGS, True), ("msk_lean.hip", MSK_FLAGS, True), ("msk2.hip", MSK_FLAGS, False), ("synth.hip", ["-O3"], True),
+UNITS = [("fir.hip", ["-O3"], True), ("fir_mm.hip", ["-O3"], True), ("msk.hip", MSK_FLAGS, True), ("msk_lean.hip", MSK_LEAN_FLAGS, True), ("msk2.hip", MSK_FLAGS, False), ("synth.hip", ["-O3"], True),
          ("blk.hip", ["-O3"], True), ("acg_api.cpp", ["-O2"], True)]
 # which units see which define (the others are compiled once and shared between the libraries)
 SEES = {"-DACG_LAB": ("fir.hip", "msk2.hip", "acg_api.cpp"), "-DACG_MSK_STAMP": ("msk.hip", "msk2.hip", "acg_api.cpp"),

@@ -598,6 +598,7 @@ extern "C" int acg_launch_sincos_selftest(const double* x, double* s, double* c,
 }
 
 extern "C" int acg_tune_has(const char* name);
+extern "C" int acg_tune_get(const char* name, int dflt);
 
 extern "C" int acg_launch_msk(const MskArgs* a, int lpc, void* stream)
 {
@@ -613,7 +614,7 @@ extern "C" int acg_launch_msk(const MskArgs* a, int lpc, void* stream)
 #ifndef ACG_MSK_STAMP
     // (8 lanes per channel: 0.716 -> 0.643 us per bit alone, the headline 1.451 -> 1.574 M channel*Msps; 4 lanes per channel -- 16 channels
     //  share a wave's segment -- measured no gain with the bit log on and -5.6 % beside the matrix-pipe down-converter: ACG_MSK_LEAN4=1)
-    if (vec && (lpc == 8 || (lpc == 4 && acg_tune_has("ACG_MSK_LEAN4"))) && !acg_tune_has("ACG_MSK_NOLEAN")) return acg_launch_msk_lean(a, lpc, wpg, grid, stream);
+    if (vec && (lpc == 8 || (lpc == 4 && acg_tune_get("ACG_MSK_LEAN4", 0))) && !acg_tune_get("ACG_MSK_NOLEAN", 0)) return acg_launch_msk_lean(a, lpc, wpg, grid, stream);
 #endif
     // (the verification mode is instantiated for the scalar-refill shape only: six more kernels, not twelve)
 #define MSK_LAUNCH(L_, W_) do { if (a->precise_mixer) hipLaunchKernelGGL((msk_demod_kernel<L_, W_, false, true>), dim3(grid), blk, 0, s, *a); \

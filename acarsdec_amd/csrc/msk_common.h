@@ -276,7 +276,14 @@ __device__ __forceinline__ float sqrtf_of_sum_of_squares(double x)
 // the loop is bound by the number of instructions it issues, not by the depth of this chain).
 __device__ __forceinline__ double wrap_2pi(double p)
 {
+#ifdef ACG_MSK_AB_WRAP3
+    // A/B build (round 6, on msk_lean.hip's shorter period): the difference beside the compare, then a two-word select -- one
+    // instruction more, one level less on the phase chain
+    const double w = p - K_TWOPI;
+    return p >= K_TWOPI ? w : p;
+#else
     const double k = __hiloint2double(p >= K_TWOPI ? (int)0xBFF00000 : (int)0x80000000, 0);
     return __builtin_fma(k, K_TWOPI, p);
+#endif
 }
 

@@ -304,7 +304,13 @@ __global__ __launch_bounds__(64 * WPG) void msk_lean_kernel(const MskArgs a)
             front();
             // every lane fired a bit and may let its framing wait?  (One lane that cannot: the wave closes the segment and
             // takes this period the way msk.hip does.)
+#ifdef ACG_LEAN_AB_UICMP
+            // A/B build: the wave-wide test as ONE compare whose lane mask is the answer (the ballot of an `and` of two conditions goes
+            // through v_cndmask + v_cmp_ne)
+            if (__builtin_amdgcn_uicmp((unsigned int)(fired ? lim : 0), (unsigned int)k, 34 /* ugt */) != ~0ull) { tail = true; break; }
+#else
             if (__builtin_amdgcn_ballot_w64(fired && lim > k) != ~0ull) { tail = true; break; }
+#endif
             decide();
             // decision + phase detector (msk.c:115-121); S + k is odd where S is odd and k even, ...
             const bool odd = (k & 1) ? !odd0 : odd0;

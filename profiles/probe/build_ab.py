@@ -32,7 +32,11 @@ for spec in sys.argv[1:]:
         open(src, "w").write(subprocess.run(["git", "show", "%s:acarsdec_amd/csrc/msk.hip" % rev], cwd=ROOT, capture_output=True, text=True, check=True).stdout)
     obj = os.path.join(out, "msk_%s.o" % name)
     B._run([B.hipcc(), "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-I" + B.INC, "-I" + B.CSRC] + base + flags + ["-c", src, "-o", obj])
-    objs = [os.path.join(B.OBJDIR, n) for n in ("fir.hip.o", "fir_mm.hip.o", "synth.hip.o", "blk.hip.o", "acg_api.cpp.o", "host_setup.o")] + [obj]
+    # msk_lean.hip (round 6) under the same flags: its A/B switches are ACG_LEAN_AB_*
+    obj2 = os.path.join(out, "msk_lean_%s.o" % name)
+    lean_base = [f for i, f in enumerate(base) if not (f == "-disable-machine-sink" or (f == "-mllvm" and i + 1 < len(base) and base[i + 1] == "-disable-machine-sink"))]
+    B._run([B.hipcc(), "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-I" + B.INC, "-I" + B.CSRC] + lean_base + flags + ["-c", os.path.join(B.CSRC, "msk_lean.hip"), "-o", obj2])
+    objs = [os.path.join(B.OBJDIR, n) for n in ("fir.hip.o", "fir_mm.hip.o", "synth.hip.o", "blk.hip.o", "acg_api.cpp.o", "host_setup.o")] + [obj, obj2]
     lib = os.path.join(out, "lib%s.so" % name)
     B._run([B.hipcc(), "--offload-arch=gfx950", "-shared", "-o", lib] + objs + ["-ldl", "-lm"])
     print(lib)

@@ -269,7 +269,9 @@ def test_build_recipe_keeps_the_exactness_critical_flags():
     src = open(os.path.join(ROOT, "acarsdec_amd", "_build.py")).read()
     unit = src[src.index('MSK_FLAGS = ['):src.index('UNITS = [')]
     assert '"-ffp-contract=off"' in unit and '("msk.hip", MSK_FLAGS, True)' in src and '("msk2.hip", MSK_FLAGS, False)' in src
-    assert '("msk_lean.hip", MSK_FLAGS, True)' in src
+    assert '("msk_lean.hip", MSK_LEAN_FLAGS, True)' in src
+    from acarsdec_amd import _build as B_
+    assert "-ffp-contract=off" in B_.MSK_LEAN_FLAGS and set(B_.MSK_LEAN_FLAGS) <= set(B_.MSK_FLAGS)
     assert "fast-math" not in src and "-Ofast" not in src and "-ffast" not in src
     assert re.search(r'"gcc", "-O2", "-ffp-contract=off"', src)
     allowed = {"-amdgpu-sched-strategy=max-ilp", "-disable-machine-sink", "-disable-branch-fold", "-disable-tail-duplicate",
@@ -370,7 +372,7 @@ def test_demodulator_loop_keeps_its_state_in_registers():
     # exactly the two shift-register updates (v_addc_co_u32) of framing work, eight periods per segment; and what a wave issues per
     # bit period there -- the figure bench.py's roofline_msk quotes -- stays where it was counted
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "--cuda-device-only", "-std=c++17", "-I" + csrc, "-I" + os.path.join(ROOT, "include")] +
-                       B.MSK_FLAGS + ["-S", "-o", "-", os.path.join(csrc, "msk_lean.hip")], capture_output=True, text=True, timeout=900)
+                       B.MSK_LEAN_FLAGS + ["-S", "-o", "-", os.path.join(csrc, "msk_lean.hip")], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     kernels, cur = {}, None
     for line in r.stdout.splitlines():
