@@ -612,9 +612,11 @@ extern "C" int acg_launch_msk(const MskArgs* a, int lpc, void* stream)
     // Round 6: the in_callback-shaped launches go to msk_lean.hip (the framing state machine off the per-bit path: same bits,
     // blocks and state); ACG_MSK_NOLEAN=1 keeps this file's kernel for same-process A/B.  The stamp build measures this file's kernel.
 #ifndef ACG_MSK_STAMP
-    // (8 lanes per channel: 0.716 -> 0.643 us per bit alone, the headline 1.451 -> 1.574 M channel*Msps; 4 lanes per channel -- 16 channels
-    //  share a wave's segment -- measured no gain with the bit log on and -5.6 % beside the matrix-pipe down-converter: ACG_MSK_LEAN4=1)
-    if (vec && (lpc == 8 || (lpc == 4 && acg_tune_get("ACG_MSK_LEAN4", 0))) && !acg_tune_get("ACG_MSK_NOLEAN", 0)) return acg_launch_msk_lean(a, lpc, wpg, grid, stream);
+    // (8 lanes per channel: 0.716 -> 0.643 us per bit alone, the headline 1.451 -> 1.574 M channel*Msps.  4 lanes per channel -- 16 channels
+    //  share a wave's segments, two mixer evaluations per lane and period -- gain nothing alone with the bit log on and 0.5-1.4 % beside
+    //  the down-converter in the same process (16 384 channels: streaming kernel +0.6 %, matrix-pipe kernel +0.6 ... +1.4 %, +4.4 % without
+    //  the log; GPU calls 25, 27, 28): taken too; ACG_MSK_LEAN4=0 keeps this file's kernel for them.)
+    if (vec && (lpc == 8 || (lpc == 4 && acg_tune_get("ACG_MSK_LEAN4", 1))) && !acg_tune_get("ACG_MSK_NOLEAN", 0)) return acg_launch_msk_lean(a, lpc, wpg, grid, stream);
 #endif
     // (the verification mode is instantiated for the scalar-refill shape only: six more kernels, not twelve)
 #define MSK_LAUNCH(L_, W_) do { if (a->precise_mixer) hipLaunchKernelGGL((msk_demod_kernel<L_, W_, false, true>), dim3(grid), blk, 0, s, *a); \

@@ -321,7 +321,7 @@ def run_case(J, name, case, args, steps, warmup, headline):
     burst5s = world * samples_per_step * k5 / (marks[k5] - marks[0]) / 1e6 if (sustain_s > 5.0 and k5 < len(marks) - 1) else None
     tele3 = [T["tele0"], tele_mid, T["tele1"]]
     # the demodulator's own bound (it sets the step of the <= 2048-channel cases): a serial recurrence per channel whose wave
-    # issues ~275 instructions per bit period (msk_lean.hip, 8 lanes per channel: 261 in a period inside a segment + the segment's
+    # issues ~275 instructions per bit period (msk_lean.hip, 8 lanes per channel -- 4: ~40 more --: 261 in a period inside a segment + the segment's
     # set-up and framing spread over its 8 bits; counted in the product's ISA, tests/test_host_logic.py) or ~325 (msk.hip, the other
     # launch shapes) from one wave per SIMD at >= 4 cycles each (profiles/r05_probe_msk_phase_stamps.txt)
     msk_launches = max(1, warm["msk_launches"]) if "msk_launches" in warm else None
@@ -336,8 +336,9 @@ def run_case(J, name, case, args, steps, warmup, headline):
         waves_per_simd = max(1.0, msk_waves / (4.0 * msk_cus))
         cyc = us_bit * clk_mid / waves_per_simd
         # (mirrors acg_launch_msk: in_callback-shaped launches with 8 lanes per channel take msk_lean.hip)
-        lean = dec_lpc == 8 and (cb * 1024) % 32 == 0 and not os.environ.get("ACG_MSK_NOLEAN")
-        ipb = 275 if lean else 325
+        lean = dec_lpc in (4, 8) and (cb * 1024) % 32 == 0 and not os.environ.get("ACG_MSK_NOLEAN")
+        # (4 lanes per channel: two mixer evaluations per lane and period, ~40 instructions more in either kernel)
+        ipb = (275 if lean else 325) + (40 if dec_lpc == 4 else 0)
         roofline_msk = {"bound": "issue", "kernel": "msk_lean_kernel" if lean else "msk_demod_kernel", "us_per_bit": round(us_bit, 4),
                         "waves_per_simd": round(waves_per_simd, 2),
                         "cycles_per_bit_per_wave": round(cyc, 0), "instr_per_bit": ipb, "floor_cycles_per_bit": 4 * ipb,

@@ -52,7 +52,8 @@ extern "C" {
 #define ACG_TXTMAX      250       /* acarsdec.h:55 */
 
 /* acg_config.flags */
-#define ACG_F_BITLOG    1u        /* keep per-bit {soft symbol, level} records of each call */
+#define ACG_F_BITLOG    1u        /* keep per-bit {soft symbol, level} records of each call (8 B per bit to device memory: 2 % of the
+                                   * demodulator's time at 1024 channels, 5 % at 16 384; a host that only wants messages leaves it off) */
 #define ACG_F_TIMING    2u        /* bracket kernels with HIP events (acg_get_timing) */
 #define ACG_F_REPAIR    4u        /* run the block thread's check/repair (acars.c:93-215) on the device:
                                      drain/collect then return what outputmsg() receives -- parity/CRC

@@ -110,7 +110,6 @@ def test_lean_demodulator_is_the_inline_demodulator(D, S, tune, lpc, cus):
     chunks = [8192, 1024, 32, 4096, 8192, 64, 2048, 8192, 8192, 96, 8192, 8192]
     x, kinds = zoo_tracks(S, nch, sum(chunks), 6)
     tune("ACG_MSK_LPC", str(lpc))
-    tune("ACG_MSK_LEAN4", "1")                      # (4 lanes per channel take the lean kernel on request only)
     if cus is not None:
         tune("ACG_MSK_CUS", str(cus))
     lean = run(D, K, x, chunks, bitlog=False)
