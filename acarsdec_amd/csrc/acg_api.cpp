@@ -1436,8 +1436,12 @@ extern "C" int acg_get_state(acg_ctx* ctx, int ch, acg_chan_state* st) { return 
 extern "C" int acg_set_state_n(acg_ctx* ctx, int ch0, int n, const acg_chan_state* st)
 {
     if (!ctx || !st || ch0 < 0 || n < 1 || ch0 + n > ctx->cfg.nch) return ACG_EINVAL;
-    for (int i = 0; i < n; ++i)
+    for (int i = 0; i < n; ++i) {
         if (st[i].idx >= ACG_FLEN) return fail(ctx, ACG_EINVAL, "idx out of range");
+        // blk_len indexes the channel's 256-byte text row on the device (acars.c:304 `blk->txt[blk->len] = r`; the reference resets a
+        // block beyond 240 bytes, acars.c:336): a length no decodeAcars() leaves behind is refused instead of written through
+        if (st[i].blk_len < 0 || st[i].blk_len > 241) return fail(ctx, ACG_EINVAL, "blk_len out of range");
+    }
     HIPCHK(ctx, hipSetDevice(ctx->cfg.device));
     HIPCHK(ctx, hipDeviceSynchronize());
     // read-modify-write: the bookkeeping that is not part of channel_t (bit / sample counters, the held CRC byte) stays as the

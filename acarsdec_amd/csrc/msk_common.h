@@ -204,10 +204,23 @@ __device__ __forceinline__ void sincos_tab(double x, const double* __restrict__ 
     const double2 e = *(const double2*)(tab + 2 * (q & (ACG_SINCOS_N - 1)));
     const double cj = e.x, sj = e.y;
     const double z = r * r;
+#ifdef ACG_MSK_AB_FMA3
+    // A/B build: the Horner steps as three-address v_fma_f64 with the constants as scalar / resident vector operands (left to the
+    // compiler each becomes v_mov_b64 + v_fmac_f64: the accumulator form overwrites the constant it starts from)
+    double ps, pc;
+    {
+        const double c2 = 8.33333333333333333333e-03, c5 = 4.16666666666666666667e-02;
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(ps) : "v"(z), "s"(-1.98412698412698412698e-04), "v"(c2));
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(ps) : "v"(z), "v"(ps), "s"(-1.66666666666666666667e-01));
+        asm("v_fma_f64 %0, %1, %2, %3" : "=v"(pc) : "v"(z), "s"(-1.38888888888888888889e-03), "v"(c5));
+    }
+    const double sm = (r * z) * ps;                                              // sin r - r
+#else
     double ps = __builtin_fma(z, -1.98412698412698412698e-04, 8.33333333333333333333e-03);
     ps = __builtin_fma(z, ps, -1.66666666666666666667e-01);
     const double sm = (r * z) * ps;                                              // sin r - r
     double pc = __builtin_fma(z, -1.38888888888888888889e-03, 4.16666666666666666667e-02);
+#endif
     pc = __builtin_fma(z, pc, -0.5);
     const double cm1 = z * pc;                                                   // cos r - 1
     const double sr = r + sm;

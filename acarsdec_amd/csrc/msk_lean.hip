@@ -46,7 +46,11 @@ __global__ __launch_bounds__(64 * WPG) void msk_lean_kernel(const MskArgs a)
     static_assert(6 * (SEG + 1) <= WB - 1 && 12 * (SEG + 1) <= 2 * WB - 1, "a segment and its closing period stay inside the dm window");
     static_assert(LPC == 4 || LPC == 8, "lane groups of 4 or 8");
     struct alignas(16) Lds {
+#ifdef ACG_LEAN_AB_HT
+        float hs[(MFLTOVER + 1) * 12];             // A/B build: h[] by tap phase, hs[o][j] = h[o + 12 j]: the 11 taps of a period are three b128 reads
+#else
         float hs[(FLEN * MFLTOVER + 1 + 3) & ~3];
+#endif
         double sc[2 * ACG_SINCOS_N];
         float2 ring_all[WPG][3 * FLEN + 1][CPW];
         float win_all[WPG][CPW][WSTR];
@@ -54,7 +58,11 @@ __global__ __launch_bounds__(64 * WPG) void msk_lean_kernel(const MskArgs a)
     __shared__ Lds lds;
     float* hs = lds.hs;
 
+#ifdef ACG_LEAN_AB_HT
+    for (int i = threadIdx.x; i < (MFLTOVER + 1) * 12; i += 64 * WPG) hs[i] = (i % 12) < FLEN ? a.h[i / 12 + MFLTOVER * (i % 12)] : 0.f;
+#else
     for (int i = threadIdx.x; i < FLEN * MFLTOVER + 1; i += 64 * WPG) hs[i] = a.h[i];
+#endif
     for (int i = threadIdx.x; i < 2 * ACG_SINCOS_N; i += 64 * WPG) lds.sc[i] = a.sctab[i];
 
     const int wv = threadIdx.x >> 6;
@@ -212,12 +220,20 @@ __global__ __launch_bounds__(64 * WPG) void msk_lean_kernel(const MskArgs a)
         if (o < 0) o = 0;
         acc = f2v{0.f, 0.f};
         {
+#ifdef ACG_LEAN_AB_HT
+            typedef float f4h __attribute__((ext_vector_type(4)));
+            const f4h* hp = (const f4h*)&hs[o * 12];
+            const f4h q0 = hp[0], q1 = hp[1], q2 = hp[2];
+            hv2[0] = f2v{q0.x, q0.y}; hv2[1] = f2v{q0.z, q0.w}; hv2[2] = f2v{q1.x, q1.y};
+            hv2[3] = f2v{q1.z, q1.w}; hv2[4] = f2v{q2.x, q2.y}; hv2[5] = f2v{q2.z, q2.w};
+#else
             const float* hp = &hs[o];
 #pragma unroll
             for (int j = 0; j < FLEN; j += 2) {
                 hv2[j / 2].x = hp[j * MFLTOVER];
                 hv2[j / 2].y = hp[j + 1 < FLEN ? (j + 1) * MFLTOVER : j * MFLTOVER + 1];
             }
+#endif
         }
         float2 xo[5];
         {
@@ -285,7 +301,8 @@ __global__ __launch_bounds__(64 * WPG) void msk_lean_kernel(const MskArgs a)
         // state in which the next possible reset of the loop is at least a byte away, else up to the bit before the byte closes
         const unsigned int aS = (unsigned int)L.astate;
         const bool isW = aS == WSYN, isT = aS == TXT;
-        const bool safe = isW | (isT & (L.berr <= MAXPERR) & (L.blen <= 239)) | (aS == CRC1);
+        // (nbits outside 1..8 can only come from a state a host wrote with acg_set_state: such a channel takes msk.hip's way)
+        const bool safe = (isW | (isT & (L.berr <= MAXPERR) & (L.blen <= 239)) | (aS == CRC1)) & ((unsigned int)(L.nbits - 1) < 8u);
         // (with a bit log: and the segment's records fit -- they are stored without the clamp of the inline path)
         const int lim = (safe & (!LOG || nb + SEG <= a.bit_cap)) ? SEG : L.nbits - 1;
         float2* const brec = LOG ? bits + nb : nullptr;
@@ -353,7 +370,7 @@ __global__ __launch_bounds__(64 * WPG) void msk_lean_kernel(const MskArgs a)
             dif |= X << 2;
             dif |= X << 1;
             dif |= X;
-            const unsigned int valid = (((1u << uc) - 1u) >> (m - 1u)) << (m - 1u);
+            const unsigned int valid = reach ? (((1u << uc) - 1u) >> (m - 1u)) << (m - 1u) : 0u;
             const unsigned int hit = ~dif;
             const unsigned int mlo = (hit >> 7) & valid, mhi = (hit >> 23) & valid;
             const unsigned int mm = mlo | mhi;

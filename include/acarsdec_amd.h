@@ -259,7 +259,7 @@ int  acg_bit_capacity(const acg_ctx *ctx);
 /* dm_buffer of the last call (rtl.c:353), n floats of channel ch */
 int  acg_read_dm(acg_ctx *ctx, int ch, float *dm, int n);
 int  acg_get_state(acg_ctx *ctx, int ch, acg_chan_state *st);
-int  acg_set_state(acg_ctx *ctx, int ch, const acg_chan_state *st);
+int  acg_set_state(acg_ctx *ctx, int ch, const acg_chan_state *st);     /* ACG_EINVAL: idx >= 11, blk_len outside 0..241 */
 /* the same for channels ch0 .. ch0+n-1 in ONE transfer each way (the legacy view moves all of a dongle's channels per
  * callback: rtl.c:344-360), and dm_buffer of the last call for n channels: row i at dm + i*pitch_floats, nfloats each */
 int  acg_get_state_n(acg_ctx *ctx, int ch0, int n, acg_chan_state *st);

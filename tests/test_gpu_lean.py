@@ -171,3 +171,50 @@ def test_lean_demodulator_against_the_oracle(D, O, S):
     assert len(ref) > 40
     assert sorted(got) == sorted(ref)
     dec.close()
+
+
+def test_lean_demodulator_with_a_bit_count_only_a_host_could_have_written(D, S, tune):
+    """nbits outside 1..8 never arises from decodeAcars(); a host can write it with acg_set_state.  Such a channel takes the inline
+    path until its count is back in range: both kernels agree call by call."""
+    from acarsdec_amd import _capi as K
+    nch = 24
+    chunks = [4096, 8192, 8192]
+    x, kinds = zoo_tracks(S, nch, sum(chunks) + 4096, 21)
+
+    def go():
+        dec = D.Decoder(nch, max_blocks=8, bitlog=False)
+        dec.demod_msk(x[:, :4096])
+        dec.sync()
+        st = (K.ChanState * nch)()
+        dec._chk(dec.L.acg_get_state_n(dec.ctx, 0, nch, st))
+        for ch in range(nch):
+            st[ch].nbits = (0, -3, 9, 13, 40, 1000)[ch % 6]
+        dec._chk(dec.L.acg_set_state_n(dec.ctx, 0, nch, st))
+        out = []
+        a0 = 4096
+        for n in chunks:
+            dec.demod_msk(x[:, a0:a0 + n])
+            dec.sync()
+            out.append(snapshot(dec, K))
+            a0 += n
+        dec.close()
+        return out
+
+    lean = go()
+    tune("ACG_MSK_NOLEAN", "1")
+    inline = go()
+    for i, (a, b) in enumerate(zip(lean, inline)):
+        assert a == b, "call %d" % i
+
+
+def test_set_state_refuses_a_block_length_beyond_the_text_row(D):
+    from acarsdec_amd import _capi as K
+    dec = D.Decoder(4, max_blocks=1, bitlog=False)
+    st = K.ChanState()
+    dec._chk(dec.L.acg_get_state(dec.ctx, 1, C.byref(st)))
+    for bad in (-1, 242, 300, 1 << 20):
+        st.blk_len = bad
+        assert dec.L.acg_set_state(dec.ctx, 1, C.byref(st)) == K.EINVAL
+    st.blk_len = 241
+    assert dec.L.acg_set_state(dec.ctx, 1, C.byref(st)) == K.OK
+    dec.close()

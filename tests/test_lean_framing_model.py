@@ -108,7 +108,7 @@ def ref_bit(st, P, N, i):
 
 def lim_of(st):
     """how many bits of this channel may wait (msk_lean.hip, segment setup)"""
-    safe = st.astate == WSYN or (st.astate == TXT and st.berr <= MAXPERR and st.blen <= 239) or st.astate == CRC1
+    safe = (st.astate == WSYN or (st.astate == TXT and st.berr <= MAXPERR and st.blen <= 239) or st.astate == CRC1) and 1 <= st.nbits <= 8
     return SEG if safe else st.nbits - 1
 
 
@@ -139,7 +139,7 @@ def lean_segment(st, Ps, Ns, i0):
     X = (((~V) << 16) | V) & M32
     Y = ~X & M32
     dif = (X << 7) | (Y << 6) | (Y << 5) | (X << 4) | (Y << 3) | (X << 2) | (X << 1) | X
-    valid = ((((1 << c) - 1) >> (m - 1)) << (m - 1)) & M32
+    valid = (((((1 << c) - 1) >> (m - 1)) << (m - 1)) & M32) if reach else 0
     hit = ~dif & M32
     mlo, mhi = (hit >> 7) & valid, (hit >> 23) & valid
     mm = mlo | mhi
