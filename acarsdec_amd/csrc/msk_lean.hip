@@ -42,9 +42,13 @@ __global__ __launch_bounds__(64 * WPG) void msk_lean_kernel(const MskArgs a)
     constexpr int WB = 64;                         // dm samples per refill block (msk.hip)
     constexpr int SPB = WB / LPC;
     constexpr int WSTR = 2 * WB + 4;
-    constexpr int SEG = 8;                         // bit periods per segment: 6 SEG <= WB - 1, and <= 8 so that a segment closes at most one byte
+#ifndef ACG_LEAN_SEG
+#define ACG_LEAN_SEG 8                             /* (A/B builds: 4, 6) */
+#endif
+    constexpr int SEG = ACG_LEAN_SEG;                         // bit periods per segment: 6 SEG <= WB - 1, and <= 8 so that a segment closes at most one byte
     static_assert(6 * (SEG + 1) <= WB - 1 && 12 * (SEG + 1) <= 2 * WB - 1, "a segment and its closing period stay inside the dm window");
     static_assert(LPC == 4 || LPC == 8, "lane groups of 4 or 8");
+    static_assert(SEG >= 1 && SEG <= 8, "a segment closes at most one byte");
     struct alignas(16) Lds {
 #ifdef ACG_LEAN_AB_HT
         float hs[(MFLTOVER + 1) * 12];             // A/B build: h[] by tap phase, hs[o][j] = h[o + 12 j]: the 11 taps of a period are three b128 reads
@@ -312,8 +316,10 @@ __global__ __launch_bounds__(64 * WPG) void msk_lean_kernel(const MskArgs a)
         unsigned int P = 0, N = 0;                 // (vo > 0), (vo < 0) of the segment's bits, oldest in the highest place
         float lvk[SEG];
         int nk[SEG];
+#ifndef ACG_LEAN_AB_NOINIT
 #pragma unroll
         for (int k = 0; k < SEG; ++k) { lvk[k] = 0.f; nk[k] = 0; }
+#endif
         int c = 0;                                 // bits whose framing waits (wave-uniform)
         bool tail = false;                         // a period's front part is done and its bit decision is not
 #pragma unroll
