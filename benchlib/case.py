@@ -336,7 +336,8 @@ def run_case(J, name, case, args, steps, warmup, headline):
         waves_per_simd = max(1.0, msk_waves / (4.0 * msk_cus))
         cyc = us_bit * clk_mid / waves_per_simd
         # (mirrors acg_launch_msk: in_callback-shaped launches with 8 lanes per channel take msk_lean.hip)
-        lean = dec_lpc in (4, 8) and (cb * 1024) % 32 == 0 and not os.environ.get("ACG_MSK_NOLEAN")
+        nolean = os.environ.get("ACG_ALLOW_TUNING") == "1" and os.environ.get("ACG_MSK_NOLEAN", "0") not in ("", "0")   # (the A/B switch, if this run carries it)
+        lean = dec_lpc in (4, 8) and (cb * 1024) % 32 == 0 and not nolean
         # (4 lanes per channel: two mixer evaluations per lane and period, ~40 instructions more in either kernel)
         ipb = (275 if lean else 325) + (40 if dec_lpc == 4 else 0)
         roofline_msk = {"bound": "issue", "kernel": "msk_lean_kernel" if lean else "msk_demod_kernel", "us_per_bit": round(us_bit, 4),
